@@ -1,0 +1,116 @@
+"""ctypes bindings of libgswt_hip.so (include/gswt_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or fails to
+load, importing the renderer raises.  Build it with ``__graft_entry__.build()`` or
+``make -C gswt_renderer_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgswt_hip.so")
+
+GSWT_OK = 0
+GSWT_ERR_BAD_ARG = -1
+GSWT_ERR_CAPACITY = -2
+GSWT_ERR_HIP = -3
+GSWT_ERR_STATE = -4
+GSWT_ORDER_REFERENCE = 0
+GSWT_ORDER_DEPTH = 1
+GSWT_OPT_NO_LOD_PREFILTER = 1
+GSWT_OPT_DEBUG_VARYINGS = 2
+
+
+class CameraUniforms(C.Structure):
+    """camera.rs:158-167"""
+    _fields_ = [("projection", C.c_float * 16), ("view", C.c_float * 16), ("focal", C.c_float * 2),
+                ("viewport", C.c_float * 2), ("htan_fov", C.c_float * 4), ("cam_pos", C.c_float * 4)]
+
+
+class SceneUniforms(C.Structure):
+    """renderer.rs:602-622"""
+    _fields_ = [("splat_scale", C.c_float), ("tile_width", C.c_float), ("use_clip", C.c_uint32),
+                ("clip_height", C.c_float), ("surface_type", C.c_uint32), ("sphere_radius", C.c_float),
+                ("point_cloud_radius", C.c_float), ("transition_width_ratio", C.c_float),
+                ("num_lod", C.c_uint32), ("draw_mode", C.c_uint32), ("map_half_wh", C.c_uint32 * 2),
+                ("center_coord", C.c_int32 * 2), ("_pad0", C.c_uint32 * 2),
+                ("transition_dist_vec", C.c_float * 16), ("height_map_scale", C.c_float * 4),
+                ("scene_scale", C.c_float * 4)]
+
+
+class TileUniforms(C.Structure):
+    """renderer.rs:675-689"""
+    _fields_ = [("single_draw", C.c_uint32), ("map_index", C.c_uint32), ("single_lod_id", C.c_int32),
+                ("valid_lod_id", C.c_int32), ("changing", C.c_uint32), ("changing_to_lower", C.c_int32),
+                ("_pad0", C.c_uint32 * 2), ("tile_id", C.c_uint32 * 4), ("offset", C.c_float * 4),
+                ("map_coord", C.c_uint32 * 4)]
+
+
+class BaseList(C.Structure):
+    _fields_ = [("gs_index", C.c_void_p), ("gs_lod_id", C.c_void_p), ("splat_count", C.c_uint32),
+                ("_pad", C.c_uint32)]
+
+
+class Draw(C.Structure):
+    _fields_ = [("tile", TileUniforms), ("merged", C.c_uint32), ("base_lod", C.c_uint32),
+                ("base_tile", C.c_uint32), ("base_view", C.c_uint32), ("merged_offset", C.c_uint32),
+                ("merged_count", C.c_uint32), ("merged_has_lod", C.c_uint32), ("cull_enable", C.c_uint32),
+                ("corners", C.c_float * 12), ("lod", C.c_uint32), ("_pad", C.c_uint32 * 3)]
+
+
+class RenderConfig(C.Structure):
+    _fields_ = [("culling_dist", C.c_float), ("lod_enable_mask", C.c_uint32), ("order_mode", C.c_int32),
+                ("transmittance_eps", C.c_float), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
+                ("_pad", C.c_uint32 * 2)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms_project", C.c_float), ("ms_scan", C.c_float), ("ms_emit", C.c_float),
+                ("ms_sort", C.c_float), ("ms_ranges", C.c_float), ("ms_composite", C.c_float),
+                ("ms_total", C.c_float), ("n_draws", C.c_uint32), ("n_instanced", C.c_uint64),
+                ("n_visible", C.c_uint64), ("n_pairs", C.c_uint64), ("n_tiles", C.c_uint32),
+                ("_pad", C.c_uint32)]
+
+
+assert C.sizeof(CameraUniforms) == 176 and C.sizeof(SceneUniforms) == 160 and C.sizeof(TileUniforms) == 80
+
+# every symbol include/gswt_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "gswt_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "gswt_destroy": (None, [_P]),
+    "gswt_last_error": (C.c_char_p, [_P]),
+    "gswt_set_stream": (C.c_int, [_P, _P]),
+    "gswt_set_option": (C.c_int, [_P, C.c_int, C.c_int]),
+    "gswt_upload_scene": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, C.c_int, C.c_int]),
+    "gswt_configure": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "gswt_set_draws": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_size_t]),
+    "gswt_render": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int]),
+    "gswt_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "gswt_shard_rows_padded": (C.c_int, [C.c_int, C.c_int]),
+    "gswt_unshard": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "gswt_synchronize": (C.c_int, [_P]),
+    "gswt_last_timings": (C.c_int, [_P, _P]),
+    "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgswt_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the GSWT hot path has no CPU fallback. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gswt_renderer_amd/csrc`.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib

@@ -1,0 +1,524 @@
+// gswt_api.hip -- C ABI of libgswt_hip.so (include/gswt_hip.h): context, HBM buffers and the
+// per-frame launch sequence project -> scan -> emit -> sort -> ranges -> composite.
+//
+// HBM layout (all resident, sized for a 288 GB part; nothing is re-uploaded per frame):
+//   tex          U x 32 B      packed splat records, exactly Scene.tex_data (scene.rs:306-411)
+//   static_list  4 B / entry   every base list [lod][tile][view], entry = gs_index | lod_id << 28,
+//                              stored twice: interleaved (as the reference binds it) and
+//                              LOD-filtered (what survives A1 for a plain tile)
+//   merged_*     4+4 B / entry per-sort-event merged-group lists (gs_index|lod, map_id)
+//   draws        DrawDev[]     one per reference draw call; chunk_tab maps a 256-entry workgroup
+//                              to (draw, first entry)
+//   rects/recs   8 + 48 B / slot  per-frame projection output, slot = composite order
+//   keys/vals    2 x (4+4) B / pair  ping-pong for the tile sort
+#include "../../include/gswt_hip.h"
+#include "gswt_device.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace gswt {
+void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, const uint32_t*, const uint32_t*,
+                    const uint32_t*, const uint4*, const float*, uint2*, Rec*, uint32_t*, unsigned long long*, Varyings*);
+void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uint32_t*);
+void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, uint32_t*, uint32_t*);
+int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, int, uint32_t*, uint32_t*, uint32_t*);
+void launch_ranges(hipStream_t, const uint32_t*, uint32_t, uint2*, uint32_t);
+void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int);
+void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
+}  // namespace gswt
+
+using namespace gswt;
+
+namespace {
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;  // elements
+    hipError_t ensure(size_t n, bool keep = false, hipStream_t s = nullptr)
+    {
+        if (n <= cap) return hipSuccess;
+        size_t ncap = n + n / 4 + 1024;
+        T* np = nullptr;
+        hipError_t e = hipMalloc(&np, ncap * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) hipMemcpy(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
+        (void)s;
+        if (p) hipFree(p);
+        p = np; cap = ncap;
+        return hipSuccess;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct ListRef { uint32_t pair_base, pair_count, self_base, self_count; };
+
+}  // namespace
+
+struct gswt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    // scene
+    DevBuf<uint4> tex;
+    size_t n_splats = 0;
+    DevBuf<uint32_t> static_list;
+    std::vector<ListRef> lists;
+    int n_lod = 0, n_tile = 0, n_view = 0;
+    bool scene_ready = false;
+    DevBuf<float> hmap;
+    int hm_w = 0, hm_h = 0;
+    // draws
+    DevBuf<DrawDev> draws;
+    DevBuf<uint2> chunk_tab;
+    DevBuf<uint32_t> merged_list, merged_map;
+    uint32_t n_draws = 0, n_chunks = 0;
+    uint64_t n_entries = 0;
+    bool draws_ready = false;
+    // frame
+    DevBuf<uint2> rects;
+    DevBuf<Rec> recs;
+    DevBuf<uint32_t> block_sums, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
+    DevBuf<uint2> ranges;
+    DevBuf<unsigned long long> counters;   // [0] visible, [1] (u32) total pairs, [2] scratch
+    DevBuf<float4> bg_rgba, out_img;
+    DevBuf<float> bg_depth;
+    DevBuf<Varyings> dbg;
+    // options
+    int opt_no_prefilter = 0;
+    int opt_debug_varyings = 0;
+    // timing
+    hipEvent_t ev[8] = {};
+    gswt_timings timings = {};
+};
+
+namespace {
+
+int fail(gswt_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) return fail((c), GSWT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+// cgmath Matrix4 * Matrix4 (camera.rs:86-88): out[c][r] = sum_k a[k][r] * b[c][k], left to right
+void mat4_mul(const float* a, const float* b, float* out)
+{
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) {
+            float acc = a[r] * b[4 * c];
+            for (int k = 1; k < 4; k++) acc = acc + a[4 * k + r] * b[4 * c + k];
+            out[4 * c + r] = acc;
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gswt_create(int device_id, gswt_ctx** out)
+{
+    if (!out) return GSWT_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GSWT_ERR_HIP;
+    if (device_id < 0 || device_id >= ndev) return GSWT_ERR_BAD_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return GSWT_ERR_HIP;
+    gswt_ctx* c = new (std::nothrow) gswt_ctx();
+    if (!c) return GSWT_ERR_CAPACITY;
+    c->device = device_id;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+    if (c->counters.ensure(8) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+    *out = c;
+    return GSWT_OK;
+}
+
+void gswt_destroy(gswt_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release();
+    c->merged_list.release(); c->merged_map.release(); c->rects.release(); c->recs.release(); c->block_sums.release();
+    c->scan_ws.release(); c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release();
+    c->ghist.release(); c->ranges.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
+    c->bg_depth.release(); c->dbg.release();
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* gswt_last_error(const gswt_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int gswt_set_stream(gswt_ctx* c, void* hip_stream)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    hipStreamSynchronize(c->stream);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return GSWT_OK;
+}
+
+int gswt_set_option(gswt_ctx* c, int key, int value)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    switch (key) {
+    case GSWT_OPT_NO_LOD_PREFILTER: c->opt_no_prefilter = value; c->draws_ready = false; return GSWT_OK;
+    case GSWT_OPT_DEBUG_VARYINGS: c->opt_debug_varyings = value; return GSWT_OK;
+    default: return fail(c, GSWT_ERR_BAD_ARG, "unknown option %d", key);
+    }
+}
+
+int gswt_upload_scene(gswt_ctx* c, const uint32_t* tex_data, size_t n_splats, const gswt_base_list* lists, int n_lod,
+                      int n_tile, int n_view)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    if (!tex_data || n_splats == 0 || !lists || n_lod <= 0 || n_tile <= 0 || n_view <= 0)
+        return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_scene: empty scene");
+    if (n_lod > 16) return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_scene: n_lod %d > 16 (transition_dist_vec holds 16)", n_lod);
+    if (n_splats > (size_t)kIdxMask) return fail(c, GSWT_ERR_CAPACITY, "gswt_upload_scene: %zu splats exceed 2^28", n_splats);
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->scene_ready = false; c->draws_ready = false;
+    HIP_TRY(c, c->tex.ensure(2 * n_splats));
+    HIP_TRY(c, hipMemcpy(c->tex.p, tex_data, n_splats * 32, hipMemcpyHostToDevice));
+    c->n_splats = n_splats;
+    const size_t nl = (size_t)n_lod * n_tile * n_view;
+    c->lists.assign(nl, ListRef{});
+    std::vector<uint32_t> arena;
+    size_t total = 0;
+    for (size_t i = 0; i < nl; i++) total += lists[i].splat_count;
+    arena.reserve(2 * total);
+    for (size_t i = 0; i < nl; i++) {
+        const gswt_base_list& L = lists[i];
+        const uint32_t lod = (uint32_t)(i / ((size_t)n_tile * n_view));
+        if (L.splat_count && (!L.gs_index || !L.gs_lod_id)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_scene: list %zu has null arrays", i);
+        ListRef ref;
+        ref.pair_base = (uint32_t)arena.size();
+        ref.pair_count = L.splat_count;
+        for (uint32_t j = 0; j < L.splat_count; j++) {
+            if (L.gs_index[j] >= n_splats) return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_scene: list %zu entry %u out of range", i, j);
+            if (L.gs_lod_id[j] > 15u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_scene: list %zu lod id out of range", i);
+            arena.push_back(L.gs_index[j] | (L.gs_lod_id[j] << kLodShift));
+        }
+        ref.self_base = (uint32_t)arena.size();
+        for (uint32_t j = 0; j < L.splat_count; j++)
+            if (L.gs_lod_id[j] == lod) arena.push_back(L.gs_index[j] | (lod << kLodShift));
+        ref.self_count = (uint32_t)arena.size() - ref.self_base;
+        c->lists[i] = ref;
+    }
+    if (arena.size() >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_upload_scene: static lists exceed 2^32 entries");
+    HIP_TRY(c, c->static_list.ensure(arena.size() + 1));
+    HIP_TRY(c, hipMemcpy(c->static_list.p, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    c->n_lod = n_lod; c->n_tile = n_tile; c->n_view = n_view;
+    c->scene_ready = true;
+    return GSWT_OK;
+}
+
+int gswt_configure(gswt_ctx* c, const float* height_map, int hm_w, int hm_h)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!height_map || hm_w <= 0 || hm_h <= 0) { c->hm_w = c->hm_h = 0; return GSWT_OK; }
+    HIP_TRY(c, c->hmap.ensure((size_t)hm_w * hm_h));
+    HIP_TRY(c, hipMemcpy(c->hmap.p, height_map, (size_t)hm_w * hm_h * 4, hipMemcpyHostToDevice));
+    c->hm_w = hm_w; c->hm_h = hm_h;
+    return GSWT_OK;
+}
+
+int gswt_set_draws(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint32_t* merged_gs_index,
+                   const uint32_t* merged_map_id, const uint32_t* merged_lod_id, size_t n_merged)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    if (!c->scene_ready) return fail(c, GSWT_ERR_STATE, "gswt_set_draws before gswt_upload_scene");
+    if (n_draws < 0 || (n_draws > 0 && !draws)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: bad draw list");
+    if (n_merged && (!merged_gs_index || !merged_map_id)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged arrays missing");
+    if (n_merged >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: merged lists exceed 2^32 entries");
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->draws_ready = false;
+    std::vector<DrawDev> dd((size_t)n_draws);
+    uint64_t entries = 0;
+    for (int i = 0; i < n_draws; i++) {
+        const gswt_draw& g = draws[i];
+        DrawDev& d = dd[i];
+        memset(&d, 0, sizeof(d));
+        d.single_draw = g.tile.single_draw;
+        d.valid_lod_id = g.tile.valid_lod_id;
+        d.changing = g.tile.changing;
+        d.changing_to_lower = g.tile.changing_to_lower;
+        d.tile_lod = g.tile.tile_id[0];
+        d.off[0] = g.tile.offset[0]; d.off[1] = g.tile.offset[1]; d.off[2] = g.tile.offset[2];
+        d.cull_enable = g.cull_enable;
+        d.lod = g.lod;
+        memcpy(d.corners, g.corners, sizeof(d.corners));
+        if (g.merged) {
+            if ((size_t)g.merged_offset + g.merged_count > n_merged)
+                return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: draw %d merged range out of bounds", i);
+            if (g.merged_has_lod && !merged_lod_id)
+                return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: draw %d needs merged_lod_id", i);
+            if (g.tile.single_draw != 1u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged draw %d without single_draw", i);
+            d.merged = 1; d.list_base = g.merged_offset; d.count = g.merged_count;
+        } else {
+            if (g.tile.single_draw == 1u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: single_draw on static draw %d", i);
+            if ((int)g.base_lod >= c->n_lod || (int)g.base_tile >= c->n_tile || (int)g.base_view >= c->n_view)
+                return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: draw %d base list (%u,%u,%u) out of range", i, g.base_lod,
+                            g.base_tile, g.base_view);
+            const ListRef& L = c->lists[((size_t)g.base_lod * c->n_tile + g.base_tile) * c->n_view + g.base_view];
+            const bool prefilter = !c->opt_no_prefilter && g.tile.valid_lod_id >= 0 && (uint32_t)g.tile.valid_lod_id == g.base_lod;
+            d.merged = 0;
+            d.list_base = prefilter ? L.self_base : L.pair_base;
+            d.count = prefilter ? L.self_count : L.pair_count;
+        }
+        d.entry_base = (uint32_t)entries;
+        entries += d.count;
+    }
+    if (entries >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: %llu list entries exceed 2^32", (unsigned long long)entries);
+    // composite-order slots: the LAST draw is nearest (drawn last = on top), so it gets the lowest slots
+    std::vector<uint2> chunks;
+    uint64_t slot = 0;
+    for (int i = n_draws - 1; i >= 0; i--) {
+        DrawDev& d = dd[i];
+        d.slot_base = (uint32_t)slot;
+        uint32_t nch = (d.count + kChunk - 1) / kChunk;
+        for (uint32_t k = 0; k < nch; k++) chunks.push_back(make_uint2((uint32_t)i, k * kChunk));
+        slot += (uint64_t)nch * kChunk;
+    }
+    if (slot >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: slot space exceeds 2^32");
+    HIP_TRY(c, c->draws.ensure(dd.size() + 1));
+    HIP_TRY(c, c->chunk_tab.ensure(chunks.size() + 1));
+    if (!dd.empty()) HIP_TRY(c, hipMemcpy(c->draws.p, dd.data(), dd.size() * sizeof(DrawDev), hipMemcpyHostToDevice));
+    if (!chunks.empty()) HIP_TRY(c, hipMemcpy(c->chunk_tab.p, chunks.data(), chunks.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    // merged arrays: pack gs_index | lod << 28
+    HIP_TRY(c, c->merged_list.ensure(n_merged + 1));
+    HIP_TRY(c, c->merged_map.ensure(n_merged + 1));
+    if (n_merged) {
+        std::vector<uint32_t> packed(n_merged);
+        for (size_t k = 0; k < n_merged; k++) {
+            if (merged_gs_index[k] >= c->n_splats) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged gs_index[%zu] out of range", k);
+            packed[k] = merged_gs_index[k];
+        }
+        for (int i = 0; i < n_draws; i++) {
+            const gswt_draw& g = draws[i];
+            if (g.merged && g.merged_has_lod)
+                for (uint32_t k = 0; k < g.merged_count; k++) {
+                    uint32_t l = merged_lod_id[g.merged_offset + k];
+                    if (l > 15u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged lod id out of range");
+                    packed[g.merged_offset + k] |= l << kLodShift;
+                }
+        }
+        HIP_TRY(c, hipMemcpy(c->merged_list.p, packed.data(), n_merged * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->merged_map.p, merged_map_id, n_merged * 4, hipMemcpyHostToDevice));
+    }
+    c->n_draws = (uint32_t)n_draws;
+    c->n_chunks = (uint32_t)chunks.size();
+    c->n_entries = entries;
+    // per-slot frame buffers
+    const size_t n_slots = (size_t)c->n_chunks * kChunk;
+    HIP_TRY(c, c->rects.ensure(n_slots + 1));
+    HIP_TRY(c, c->recs.ensure(n_slots + 1));
+    HIP_TRY(c, c->block_sums.ensure((size_t)c->n_chunks + 1));
+    c->draws_ready = true;
+    return GSWT_OK;
+}
+
+int gswt_shard_rows_padded(int height, int shard_count)
+{
+    int tiles_y = (height + kTile - 1) / kTile;
+    int sc = shard_count <= 1 ? 1 : shard_count;
+    return ((tiles_y + sc - 1) / sc) * kTile;
+}
+
+int gswt_shard_rows(int height, int shard_index, int shard_count)
+{
+    int sc = shard_count <= 1 ? 1 : shard_count;
+    if (shard_index < 0 || shard_index >= sc) return 0;
+    int rows = 0;
+    for (int y = 0; y < height; y++) if (((y / kTile) % sc) == shard_index) rows++;
+    return rows;
+}
+
+int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_uniforms* su, const gswt_render_config* cfg,
+                int width, int height, const float* bg_rgba, const float* bg_depth, int bg_on_device, float* out_rgba,
+                int out_on_device)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    if (!cam || !su || !cfg || !out_rgba) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: null argument");
+    if (!c->draws_ready) return fail(c, GSWT_ERR_STATE, "gswt_render before gswt_set_draws");
+    if (width <= 0 || height <= 0 || width > 65535 * kTile || height > 65535 * kTile)
+        return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: bad target size %dx%d", width, height);
+    if ((float)width != cam->viewport[0] || (float)height != cam->viewport[1])
+        return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: camera viewport (%g,%g) != target %dx%d", cam->viewport[0], cam->viewport[1], width, height);
+    if (su->surface_type == 1u && (c->hm_w == 0 || c->hm_h == 0))
+        return fail(c, GSWT_ERR_STATE, "gswt_render: surface_type HeightMap without gswt_configure height map");
+    if (su->surface_type > 1u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: surface_type %u not supported yet", su->surface_type);
+    if (su->draw_mode != 0u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: debug draw modes are not part of the hot path");
+    if (cfg->order_mode != GSWT_ORDER_REFERENCE) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: order mode %d not supported yet", cfg->order_mode);
+    const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
+    if (sc > 1 && (cfg->shard_index < 0 || cfg->shard_index >= sc)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: bad shard index");
+    hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+
+    Frame f;
+    memset(&f, 0, sizeof(f));
+    memcpy(f.V, cam->view, 64);
+    for (int cc = 0; cc < 4; cc++) {          // opengl_to_wgpu * projection, gswt.wgsl:152-160
+        const float* P = cam->projection;
+        f.GP[4 * cc + 0] = P[4 * cc + 0];
+        f.GP[4 * cc + 1] = P[4 * cc + 1];
+        f.GP[4 * cc + 2] = 0.5f * P[4 * cc + 2] + 0.5f * P[4 * cc + 3];
+        f.GP[4 * cc + 3] = P[4 * cc + 3];
+    }
+    mat4_mul(cam->projection, cam->view, f.VP);
+    f.focal[0] = cam->focal[0]; f.focal[1] = cam->focal[1];
+    f.htan[0] = cam->htan_fov[0]; f.htan[1] = cam->htan_fov[1];
+    f.cam_pos[0] = cam->cam_pos[0]; f.cam_pos[1] = cam->cam_pos[1]; f.cam_pos[2] = cam->cam_pos[2];
+    f.W = (float)width; f.H = (float)height;
+    f.splat_scale = su->splat_scale; f.tile_width = su->tile_width; f.clip_height = su->clip_height;
+    f.point_cloud_radius = su->point_cloud_radius; f.transition_width_ratio = su->transition_width_ratio;
+    f.use_clip = su->use_clip; f.surface_type = su->surface_type; f.num_lod = su->num_lod; f.draw_mode = su->draw_mode;
+    f.map_half_wh[0] = su->map_half_wh[0]; f.map_half_wh[1] = su->map_half_wh[1];
+    f.center_coord[0] = su->center_coord[0]; f.center_coord[1] = su->center_coord[1];
+    memcpy(f.transition_dist, su->transition_dist_vec, 64);
+    for (int k = 0; k < 3; k++) { f.height_map_scale[k] = su->height_map_scale[k]; f.scene_scale[k] = su->scene_scale[k]; }
+    f.culling_dist = cfg->culling_dist; f.lod_enable_mask = cfg->lod_enable_mask; f.t_eps = cfg->transmittance_eps;
+    f.has_depth = bg_depth ? 1 : 0;
+    f.width = width; f.height = height;
+    f.tiles_x = (width + kTile - 1) / kTile; f.tiles_y = (height + kTile - 1) / kTile;
+    f.shard_index = sc > 1 ? cfg->shard_index : 0; f.shard_count = sc;
+    f.hm_w = c->hm_w; f.hm_h = c->hm_h;
+
+    const int tiles_y_local = sc > 1 ? (f.tiles_y - f.shard_index + sc - 1) / sc : f.tiles_y;
+    const int n_tiles = f.tiles_x * (tiles_y_local > 0 ? tiles_y_local : 0);
+    const int out_rows = sc > 1 ? gswt_shard_rows_padded(height, sc) : height;
+    const size_t out_px = (size_t)out_rows * width;
+    const size_t npx = (size_t)width * height;
+
+    // inputs / outputs
+    const float4* d_bg = nullptr; const float* d_bgd = nullptr; float4* d_out = nullptr;
+    if (bg_rgba) {
+        if (bg_on_device) d_bg = reinterpret_cast<const float4*>(bg_rgba);
+        else { HIP_TRY(c, c->bg_rgba.ensure(npx)); HIP_TRY(c, hipMemcpyAsync(c->bg_rgba.p, bg_rgba, npx * 16, hipMemcpyHostToDevice, s)); d_bg = c->bg_rgba.p; }
+    }
+    if (bg_depth) {
+        if (bg_on_device) d_bgd = bg_depth;
+        else { HIP_TRY(c, c->bg_depth.ensure(npx)); HIP_TRY(c, hipMemcpyAsync(c->bg_depth.p, bg_depth, npx * 4, hipMemcpyHostToDevice, s)); d_bgd = c->bg_depth.p; }
+    }
+    if (out_on_device) d_out = reinterpret_cast<float4*>(out_rgba);
+    else { HIP_TRY(c, c->out_img.ensure(out_px)); d_out = c->out_img.p; }
+    HIP_TRY(c, c->ranges.ensure((size_t)n_tiles + 1));
+    HIP_TRY(c, c->scan_ws.ensure((size_t)c->n_chunks / 1024 + 4096));
+    const bool dbg = c->opt_debug_varyings != 0;
+    if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)c->n_entries + 1));
+    if (sc > 1 && out_rows * width > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
+
+    // ---- project
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), s));
+    launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
+                   c->tex.p, c->hmap.p, c->rects.p, c->recs.p, c->block_sums.p, c->counters.p, c->dbg.p);
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    // ---- scan of per-workgroup pair counts; total pairs -> counters[1]
+    launch_scan(s, c->block_sums.p, c->block_sums.p, c->n_chunks, reinterpret_cast<uint32_t*>(c->counters.p + 1), c->scan_ws.p);
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    unsigned long long host_counters[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(host_counters, c->counters.p, sizeof(host_counters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint32_t P = (uint32_t)(host_counters[1] & 0xFFFFFFFFull);
+    // ---- emit
+    HIP_TRY(c, c->keys_a.ensure((size_t)P + 1)); HIP_TRY(c, c->keys_b.ensure((size_t)P + 1));
+    HIP_TRY(c, c->vals_a.ensure((size_t)P + 1)); HIP_TRY(c, c->vals_b.ensure((size_t)P + 1));
+    const uint32_t nblk = (P + 4095) / 4096;
+    HIP_TRY(c, c->ghist.ensure((size_t)256 * nblk + 1));
+    HIP_TRY(c, c->scan_ws.ensure((size_t)256 * nblk / 1024 + 4096));
+    launch_emit(s, f, c->n_chunks, c->rects.p, c->block_sums.p, c->keys_a.p, c->vals_a.p);
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    // ---- stable sort on the tile bits
+    int key_bits = 1;
+    while ((1 << key_bits) < n_tiles) key_bits++;
+    int where = launch_sort(s, c->keys_a.p, c->vals_a.p, c->keys_b.p, c->vals_b.p, P, key_bits, c->ghist.p, c->scan_ws.p,
+                            reinterpret_cast<uint32_t*>(c->counters.p + 2));
+    const uint32_t* keys_sorted = where ? c->keys_b.p : c->keys_a.p;
+    const uint32_t* vals_sorted = where ? c->vals_b.p : c->vals_a.p;
+    HIP_TRY(c, hipEventRecord(c->ev[4], s));
+    // ---- ranges
+    launch_ranges(s, keys_sorted, P, c->ranges.p, (uint32_t)n_tiles);
+    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    // ---- composite
+    launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows);
+    HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    HIP_TRY(c, hipGetLastError());
+    if (!out_on_device) HIP_TRY(c, hipMemcpyAsync(out_rgba, d_out, out_px * 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+
+    gswt_timings& t = c->timings;
+    memset(&t, 0, sizeof(t));
+    hipEventElapsedTime(&t.ms_project, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&t.ms_scan, c->ev[1], c->ev[2]);
+    hipEventElapsedTime(&t.ms_emit, c->ev[2], c->ev[3]);
+    hipEventElapsedTime(&t.ms_sort, c->ev[3], c->ev[4]);
+    hipEventElapsedTime(&t.ms_ranges, c->ev[4], c->ev[5]);
+    hipEventElapsedTime(&t.ms_composite, c->ev[5], c->ev[6]);
+    hipEventElapsedTime(&t.ms_total, c->ev[0], c->ev[6]);
+    t.n_draws = c->n_draws; t.n_instanced = c->n_entries; t.n_visible = host_counters[0]; t.n_pairs = P; t.n_tiles = (uint32_t)n_tiles;
+    return GSWT_OK;
+}
+
+int gswt_unshard(gswt_ctx* c, const float* gathered, int width, int height, int shard_count, float* out_rgba)
+{
+    if (!c || !gathered || !out_rgba || width <= 0 || height <= 0 || shard_count < 1) return GSWT_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    launch_unshard(c->stream, reinterpret_cast<const float4*>(gathered), reinterpret_cast<float4*>(out_rgba), width, height,
+                   shard_count, gswt_shard_rows_padded(height, shard_count));
+    HIP_TRY(c, hipGetLastError());
+    return GSWT_OK;
+}
+
+int gswt_synchronize(gswt_ctx* c)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return GSWT_OK;
+}
+
+int gswt_last_timings(const gswt_ctx* c, gswt_timings* out)
+{
+    if (!c || !out) return GSWT_ERR_BAD_ARG;
+    *out = c->timings;
+    return GSWT_OK;
+}
+
+int gswt_debug_read_projected(gswt_ctx* c, void* out, size_t capacity_entries, size_t* n_entries)
+{
+    if (!c || !n_entries) return GSWT_ERR_BAD_ARG;
+    *n_entries = (size_t)c->n_entries;
+    if (!out) return GSWT_OK;
+    if (!c->opt_debug_varyings || !c->dbg.p) return fail(c, GSWT_ERR_STATE, "enable GSWT_OPT_DEBUG_VARYINGS and render first");
+    if (capacity_entries < c->n_entries) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu entries, need %llu", capacity_entries, (unsigned long long)c->n_entries);
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->dbg.p, (size_t)c->n_entries * sizeof(Varyings), hipMemcpyDeviceToHost));
+    return GSWT_OK;
+}
+
+}  // extern "C"

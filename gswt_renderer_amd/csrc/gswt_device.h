@@ -1,0 +1,79 @@
+// gswt_device.h -- device-side data layout shared by the kernels and the C-ABI host code.
+// Internal to libgswt_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gswt {
+
+constexpr int kTile = 16;            // screen tile edge, pixels (BASELINE north_star: 16x16 binning)
+constexpr int kChunk = 256;          // list entries per projection workgroup
+constexpr uint32_t kLodShift = 28;   // packed list entry = gs_index | lod_id << 28
+constexpr uint32_t kIdxMask = (1u << kLodShift) - 1u;
+
+// Device-side draw descriptor: what one reference draw call binds (renderer.rs:499-590).
+struct DrawDev {
+    uint32_t single_draw;
+    int32_t valid_lod_id;
+    uint32_t changing;
+    int32_t changing_to_lower;
+    uint32_t tile_lod;        // tile_id.x
+    float off[3];             // tile offset
+    uint32_t list_base;       // first packed entry of this draw's list in its arena
+    uint32_t count;           // list length
+    uint32_t merged;          // 0: static arena, 1: merged arena (has map ids)
+    uint32_t slot_base;       // first composite-order slot of this draw (multiple of kChunk)
+    uint32_t cull_enable;
+    uint32_t lod;             // tid.0 for lod_enable
+    float corners[12];
+    uint32_t entry_base;      // index of the first entry in draw order (debug output)
+    uint32_t _pad;
+};
+
+// Per-frame constants (kernel argument, by value).
+struct Frame {
+    float V[16];       // view
+    float GP[16];      // opengl_to_wgpu * projection   (gswt.wgsl:152-160)
+    float VP[16];      // projection * view             (camera.rs:86-88) for the tile cull
+    float focal[2];
+    float htan[2];
+    float cam_pos[3];
+    float W, H;
+    // scene uniforms
+    float splat_scale, tile_width, clip_height, point_cloud_radius, transition_width_ratio;
+    uint32_t use_clip, surface_type, num_lod, draw_mode;
+    uint32_t map_half_wh[2];
+    int32_t center_coord[2];
+    float transition_dist[16];
+    float height_map_scale[3];
+    float scene_scale[3];
+    // render config
+    float culling_dist;
+    uint32_t lod_enable_mask;
+    float t_eps;
+    int32_t has_depth;       // proxy depth buffer bound
+    // screen tiling / sharding
+    int32_t width, height, tiles_x, tiles_y;
+    int32_t shard_index, shard_count;
+    int32_t hm_w, hm_h;
+};
+
+// Projected splat record consumed by the compositor (48 B, three 16-B words).
+//   q0 = (iux, iuy, cxp, alpha)   q1 = (ivx, ivy, cyp, depth)   q2 = (r, g, b, 0)
+struct __attribute__((aligned(16))) Rec {
+    float iux, iuy, cxp, alpha;
+    float ivx, ivy, cyp, depth;
+    float r, g, b, pad;
+};
+
+// vs_main varyings for the debug/parity hook (48 B, same layout as the oracle's orc_splat)
+struct Varyings {
+    int32_t visible;
+    float ndc[2];
+    float depth;
+    float major[2];
+    float minor[2];
+    float rgba[4];
+};
+
+}  // namespace gswt

@@ -1,0 +1,698 @@
+// gswt_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the GSWT hot path.
+//
+//   k_project   : Wang-tile instancing + vs_main (gswt.wgsl:27-422) per list entry
+//   k_emit      : (splat, 16x16 screen tile) pair emission in composite order
+//   radix sort  : stable LSD sort of the pairs on the tile bits only
+//   k_ranges    : per-screen-tile [start, end) of the sorted pair list
+//   k_composite : front-to-back alpha compositing (fs_main gswt.wgsl:425-435 +
+//                 blend/depth state renderer.rs:118-129,179-185), LDS-staged lists,
+//                 wave ballot early termination
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.  Contraction is OFF for the
+// whole file: the float sequences that feed discontinuous decisions (culling, |p|^2 <= 4,
+// depth test) are the canonical sequences of DESIGN.md and must round exactly like the
+// CPU oracle; every fused multiply-add below is an explicit fmaf().
+// Wavefront = 64 lanes everywhere in this file.
+#include "gswt_device.h"
+
+namespace gswt {
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ float clampf(float e, float lo, float hi) { return fminf(fmaxf(e, lo), hi); }
+
+// halfToFloat, gswt.wgsl:478-494: normals as IEEE; subnormals scale 2^-15 (f * 2^-25);
+// Inf/NaN -> 0.
+__device__ __forceinline__ float half_decode(uint32_t h)
+{
+    uint32_t e = (h >> 10) & 0x1Fu;
+    uint32_t f = h & 0x3FFu;
+    uint32_t s = (h & 0x8000u) << 16;
+    if (e == 0u) return u2f(s | __float_as_uint((float)f * 2.98023223876953125e-08f));  // 2^-25
+    if (e == 31u) return 0.0f;
+    return u2f(s | ((e + 112u) << 23) | (f << 13));
+}
+
+// WebGPU bilinear sample, R32Float, repeat addressing, level 0 (renderer.rs:376-388).
+__device__ __forceinline__ float sample_height(const float* __restrict__ hm, int w, int h, float u, float v)
+{
+    float x = u * (float)w - 0.5f;
+    float y = v * (float)h - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float tx = x - fx0, ty = y - fy0;
+    long x0 = (long)fx0, y0 = (long)fy0;
+    long xa = ((x0 % w) + w) % w, xb = (((x0 + 1) % w) + w) % w;
+    long ya = ((y0 % h) + h) % h, yb = (((y0 + 1) % h) + h) % h;
+    float i00 = hm[ya * w + xa], i10 = hm[ya * w + xb];
+    float i01 = hm[yb * w + xa], i11 = hm[yb * w + xb];
+    float i0 = i00 * (1.0f - tx) + i10 * tx;
+    float i1 = i01 * (1.0f - tx) + i11 * tx;
+    return i0 * (1.0f - ty) + i1 * ty;
+}
+
+// Number of 16-px tile rows in [ty0, ty1] owned by this shard (row % count == index).
+__device__ __forceinline__ int owned_rows(int ty0, int ty1, int index, int count)
+{
+    if (count <= 1) return ty1 - ty0 + 1;
+    // first owned row >= ty0
+    int first = ty0 + ((index - ty0 % count) + count) % count;
+    if (first > ty1) return 0;
+    return (ty1 - first) / count + 1;
+}
+
+// ------------------------------------------------------------------------------------
+// k_project
+// One workgroup = one 256-entry chunk of one draw, in composite (front-to-back) order:
+// slot = slot_base + r, r-th entry from the END of the draw's list.
+// ------------------------------------------------------------------------------------
+template <bool DEBUG>
+__global__ __launch_bounds__(256) void k_project(
+    const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
+    const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
+    const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
+    const float* __restrict__ hmap, uint2* __restrict__ rects, Rec* __restrict__ recs,
+    uint32_t* __restrict__ block_sums, unsigned long long* __restrict__ counters,
+    Varyings* __restrict__ dbg)
+{
+    __shared__ int s_culled;
+    __shared__ uint32_t s_wsum[4], s_wvis[4];
+    const uint2 ct = chunk_tab[blockIdx.x];
+    const DrawDev& d = draws[ct.x];
+    const uint32_t tid = threadIdx.x;
+
+    // CPU viewport culling of renderer.rs:472-497, done once per workgroup
+    if (tid == 0) {
+        int culled = 0;
+        if (d.cull_enable) {
+            float mx = 3.402823466e+38f, my = 3.402823466e+38f, mz = -3.402823466e+38f;
+            for (int ci = 0; ci < 4; ci++) {
+                float px = d.corners[3 * ci], py = d.corners[3 * ci + 1], pz = d.corners[3 * ci + 2];
+                float c4[4];
+                for (int r = 0; r < 4; r++)
+                    c4[r] = ((f.VP[r] * px + f.VP[4 + r] * py) + f.VP[8 + r] * pz) + f.VP[12 + r] * 1.0f;
+                float cx = c4[0] / c4[3], cy = c4[1] / c4[3], cz = c4[2] / c4[3];
+                if (fabsf(cx) < mx) mx = fabsf(cx);
+                if (fabsf(cy) < my) my = fabsf(cy);
+                if (cz > mz) mz = cz;
+            }
+            float clip = f.culling_dist;
+            if (mz < -clip || mx > clip || my > clip) culled = 1;
+        }
+        if (!((f.lod_enable_mask >> (d.lod & 31u)) & 1u)) culled = 1;
+        s_culled = culled;
+    }
+    __syncthreads();
+
+    const uint32_t r = ct.y + tid;
+    const uint32_t slot = d.slot_base + r;
+    const bool in_list = r < d.count;
+    uint32_t count = 0;
+    bool visible = false;
+    Varyings vout;
+    if (DEBUG) { vout.visible = 0; vout.ndc[0] = vout.ndc[1] = vout.depth = 0.f; vout.major[0] = vout.major[1] = 0.f;
+                 vout.minor[0] = vout.minor[1] = 0.f; vout.rgba[0] = vout.rgba[1] = vout.rgba[2] = vout.rgba[3] = 0.f; }
+
+    if (in_list && !s_culled) {
+        const uint32_t j = d.count - 1u - r;
+        const uint32_t* list = d.merged ? merged_list : static_list;
+        const uint32_t entry = list[d.list_base + j];
+        const uint32_t gs_index = entry & kIdxMask;
+        const uint32_t lod_id = entry >> kLodShift;
+        do {
+            // A1 gswt.wgsl:38-42
+            if (d.valid_lod_id >= 0 && d.valid_lod_id != (int32_t)lod_id) break;
+            // A2 :45-49
+            const uint4 w0 = tex[2 * (size_t)gs_index];
+            const uint4 w1 = tex[2 * (size_t)gs_index + 1];
+            // A3 :52-65
+            float ox = d.off[0], oy = d.off[1], oz = d.off[2];
+            if (d.single_draw == 1u) {
+                const uint32_t map_id = merged_map[d.list_base + j];
+                uint32_t map_wh_y = 2u * f.map_half_wh[1];
+                if (f.surface_type != 2u) map_wh_y += 1u;
+                ox = (float)((int32_t)(map_id / map_wh_y - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
+                oy = (float)((int32_t)(map_id % map_wh_y - f.map_half_wh[1]) + f.center_coord[1]) * f.tile_width;
+                oz = 0.0f;
+            }
+            float c0 = (u2f(w0.x) + ox) * f.scene_scale[0];
+            float c1 = (u2f(w0.y) + oy) * f.scene_scale[1];
+            float c2 = (u2f(w0.z) + oz) * f.scene_scale[2];
+            // A4 :75-87
+            float mapped_z = 0.0f;
+            float F[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            if (f.surface_type == 1u) {
+                const float DELTA = 0.001f;
+                float xr = (2.0f * (float)f.map_half_wh[0] + 1.0f) * f.tile_width * f.height_map_scale[0];
+                float yr = (2.0f * (float)f.map_half_wh[1] + 1.0f) * f.tile_width * f.height_map_scale[1];
+                float h_u = (c0 + (float)f.map_half_wh[0] * f.tile_width) / xr;
+                float h_v = (c1 + (float)f.map_half_wh[1] * f.tile_width) / yr;
+                float hz = f.height_map_scale[2];
+                float nz = sample_height(hmap, f.hm_w, f.hm_h, h_u, h_v) * hz;
+                float dt = DELTA;
+                float h_r = sample_height(hmap, f.hm_w, f.hm_h, h_u + dt, h_v) * hz;
+                float h_l = sample_height(hmap, f.hm_w, f.hm_h, h_u - dt, h_v) * hz;
+                float h_up = sample_height(hmap, f.hm_w, f.hm_h, h_u, h_v + dt) * hz;
+                float h_d = sample_height(hmap, f.hm_w, f.hm_h, h_u, h_v - dt) * hz;
+                float lx[3] = {1.0f, 0.0f, (h_r - h_l) / (2.0f * dt * xr)};
+                float ly[3] = {0.0f, 1.0f, (h_up - h_d) / (2.0f * dt * yr)};
+                float cz0 = lx[1] * ly[2] - lx[2] * ly[1];
+                float cz1 = lx[2] * ly[0] - lx[0] * ly[2];
+                float cz2 = lx[0] * ly[1] - lx[1] * ly[0];
+                float len = sqrtf((cz0 * cz0 + cz1 * cz1) + cz2 * cz2);
+                F[0] = lx[0]; F[1] = lx[1]; F[2] = lx[2];
+                F[3] = ly[0]; F[4] = ly[1]; F[5] = ly[2];
+                F[6] = cz0 / len; F[7] = cz1 / len; F[8] = cz2 / len;
+                float z = c2;
+                c0 = c0 + F[6] * z;
+                c1 = c1 + F[7] * z;
+                c2 = nz + F[8] * z;
+                mapped_z = nz;
+            } else if (f.surface_type == 2u) {
+                break;  // sphere mapping not built yet
+            }
+            if (f.use_clip == 1u && mapped_z < f.clip_height) break;
+            // A5 :91-150
+            float t_ratio = -1.0f;
+            uint32_t higher_lod = 0u;
+            if (d.changing == 1u) {
+                float dx = c0 - f.cam_pos[0], dy = c1 - f.cam_pos[1], dz = c2 - f.cam_pos[2];
+                float cam_dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+                if (d.single_draw == 1u) {
+                    if (lod_id == 0u) higher_lod = 0u;
+                    else if (lod_id == f.num_lod - 1u) higher_lod = lod_id - 1u;
+                    else {
+                        float d1 = f.transition_dist[(lod_id - 1u) & 15u];
+                        float d2 = f.transition_dist[lod_id & 15u];
+                        higher_lod = (cam_dist - d1 < d2 - cam_dist) ? lod_id - 1u : lod_id;
+                    }
+                } else {
+                    higher_lod = (d.changing_to_lower == 1) ? d.tile_lod : d.tile_lod - 1u;
+                }
+                float td = f.transition_dist[higher_lod & 15u];
+                float thw = f.transition_width_ratio * td;
+                t_ratio = clampf((cam_dist - td) / thw + 0.5f, 0.0f, 1.0f);
+                if ((lod_id == higher_lod + 1u && t_ratio == 0.0f) || (lod_id == higher_lod && t_ratio == 1.0f)) break;
+            }
+            // A6 :152-167
+            float cv[4], q[4];
+            for (int rr = 0; rr < 4; rr++) cv[rr] = ((f.V[rr] * c0 + f.V[4 + rr] * c1) + f.V[8 + rr] * c2) + f.V[12 + rr];
+            for (int rr = 0; rr < 4; rr++)
+                q[rr] = ((f.GP[rr] * cv[0] + f.GP[4 + rr] * cv[1]) + f.GP[8 + rr] * cv[2]) + f.GP[12 + rr] * cv[3];
+            float clip = 1.2f * q[3];
+            if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) break;
+            // A7 :169-205
+            float K[9];
+            {
+                float a = half_decode(w1.x & 0xFFFFu), b = half_decode(w1.x >> 16);
+                float cc = half_decode(w1.y & 0xFFFFu), dd = half_decode(w1.y >> 16);
+                float e = half_decode(w1.z & 0xFFFFu), ff = half_decode(w1.z >> 16);
+                K[0] = a; K[1] = b; K[2] = cc; K[3] = b; K[4] = dd; K[5] = e; K[6] = cc; K[7] = e; K[8] = ff;
+            }
+            if (f.point_cloud_radius > 0.0f) {
+                float pr = f.point_cloud_radius;
+                if (f.draw_mode > 0u) pr *= ldexpf(1.0f, (int)d.tile_lod);
+                K[0] = pr; K[1] = 0; K[2] = 0; K[3] = 0; K[4] = pr; K[5] = 0; K[6] = 0; K[7] = 0; K[8] = pr;
+            }
+            if (f.surface_type > 0u) {
+                float FK[9], R[9];
+                for (int cc = 0; cc < 3; cc++)
+                    for (int rr = 0; rr < 3; rr++)
+                        FK[3 * cc + rr] = (F[rr] * K[3 * cc] + F[3 + rr] * K[3 * cc + 1]) + F[6 + rr] * K[3 * cc + 2];
+                for (int cc = 0; cc < 3; cc++)
+                    for (int rr = 0; rr < 3; rr++)
+                        R[3 * cc + rr] = (FK[rr] * F[cc] + FK[3 + rr] * F[3 + cc]) + FK[6 + rr] * F[6 + cc];
+                for (int k = 0; k < 9; k++) K[k] = R[k];
+            }
+            for (int cc = 0; cc < 3; cc++)
+                for (int rr = 0; rr < 3; rr++) K[3 * cc + rr] = (f.scene_scale[rr] * K[3 * cc + rr]) * f.scene_scale[cc];
+            // A8 :207-258
+            float d0 = c0 - f.cam_pos[0], d1 = c1 - f.cam_pos[1], d2 = c2 - f.cam_pos[2];
+            float t[3];
+            for (int rr = 0; rr < 3; rr++) t[rr] = (f.V[rr] * d0 + f.V[4 + rr] * d1) + f.V[8 + rr] * d2;
+            float txtz = t[0] / t[2], tytz = t[1] / t[2];
+            float limx = 1.3f * f.htan[0], limy = 1.3f * f.htan[1];
+            t[0] = clampf(txtz, -limx, limx) * t[2];
+            t[1] = clampf(tytz, -limy, limy) * t[2];
+            float tz2 = t[2] * t[2];
+            float j00 = f.focal[0] / t[2], j02 = -((f.focal[0] * t[0]) / tz2);
+            float j11 = f.focal[1] / t[2], j12 = -((f.focal[1] * t[1]) / tz2);
+            float T0[3], T1[3];
+            for (int rr = 0; rr < 3; rr++) {
+                T0[rr] = f.V[4 * rr + 0] * j00 + f.V[4 * rr + 2] * j02;
+                T1[rr] = f.V[4 * rr + 1] * j11 + f.V[4 * rr + 2] * j12;
+            }
+            float A0[3], A1[3];
+            for (int k = 0; k < 3; k++) {
+                A0[k] = (T0[0] * K[3 * k] + T0[1] * K[3 * k + 1]) + T0[2] * K[3 * k + 2];
+                A1[k] = (T1[0] * K[3 * k] + T1[1] * K[3 * k + 1]) + T1[2] * K[3 * k + 2];
+            }
+            float c00 = (A0[0] * T0[0] + A0[1] * T0[1]) + A0[2] * T0[2];
+            float c01 = (A1[0] * T0[0] + A1[1] * T0[1]) + A1[2] * T0[2];
+            float c11 = (A1[0] * T1[0] + A1[1] * T1[1]) + A1[2] * T1[2];
+            float mid = 0.5f * (c00 + c11);
+            float hxx = 0.5f * (c00 - c11);
+            float radius = sqrtf(hxx * hxx + c01 * c01);
+            float l1 = mid + radius, l2 = mid - radius;
+            if (l2 < 0.0f) break;
+            float vx = c01, vy = l1 - c00;
+            float vlen = sqrtf(vx * vx + vy * vy);
+            float ex = vx / vlen, ey = vy / vlen;
+            float smaj = fminf(sqrtf(2.0f * l1), 1024.0f);
+            float smin = fminf(sqrtf(2.0f * l2), 1024.0f);
+            float majx = smaj * ex, majy = smaj * ey;
+            float minx = smin * ey, miny = smin * -ex;
+            // A9 :260-265, 402-410
+            float cr = (float)(w1.w & 0xFFu) / 255.0f;
+            float cg = (float)((w1.w >> 8) & 0xFFu) / 255.0f;
+            float cb = (float)((w1.w >> 16) & 0xFFu) / 255.0f;
+            float ca = (float)((w1.w >> 24) & 0xFFu) / 255.0f;
+            if (d.changing == 1u) {
+                if (lod_id != higher_lod) ca = ca * t_ratio;
+                else ca = ca * (1.0f - t_ratio);
+            }
+            // rgba *= clamp(z/w + 1, 0, 1): identically 1 for 0 <= z/w, kept for the debug output only
+            // A10 :415-419
+            float ndcx = q[0] / q[3], ndcy = q[1] / q[3], depth = q[2] / q[3];
+            if (DEBUG) {
+                float fade = clampf(q[2] / q[3] + 1.0f, 0.0f, 1.0f);
+                vout.ndc[0] = ndcx; vout.ndc[1] = ndcy; vout.depth = depth;
+                vout.major[0] = majx; vout.major[1] = majy; vout.minor[0] = minx; vout.minor[1] = miny;
+                vout.rgba[0] = cr * fade; vout.rgba[1] = cg * fade; vout.rgba[2] = cb * fade; vout.rgba[3] = ca * fade;
+            }
+            if (!(depth >= 0.0f && depth <= 1.0f)) break;
+            // Fragment setup F1, F2: pixel-space centre and inverse affine map
+            float cxp = (0.5f * ndcx + 0.5f) * f.W;
+            float cyp = (0.5f - 0.5f * ndcy) * f.H;
+            float hs = 0.5f * f.splat_scale;
+            float ux = hs * majx, uy = -(hs * majy);
+            float wx = hs * minx, wy = -(hs * miny);
+            float uu = ux * ux + uy * uy;
+            float ww = wx * wx + wy * wy;
+            if (!((uu > 0.0f) && (ww > 0.0f) && (uu < __builtin_inff()) && (ww < __builtin_inff()))) break;
+            if (DEBUG) vout.visible = 1;
+            visible = true;
+            // depth_compare Less against the 1.0 clear when no proxy depth is bound (renderer.rs:182,436)
+            if (!f.has_depth && !(depth < 1.0f)) { visible = false; break; }
+            Rec rec;
+            rec.iux = ux / uu; rec.iuy = uy / uu;
+            rec.ivx = wx / ww; rec.ivy = wy / ww;
+            rec.cxp = cxp; rec.cyp = cyp; rec.alpha = ca; rec.depth = depth;
+            rec.r = cr; rec.g = cg; rec.b = cb; rec.pad = 0.0f;
+            float hx = 2.0f * sqrtf(ux * ux + wx * wx) + 1.0f;
+            float hy = 2.0f * sqrtf(uy * uy + wy * wy) + 1.0f;
+            float fx0 = floorf(cxp - hx), fx1 = ceilf(cxp + hx);
+            float fy0 = floorf(cyp - hy), fy1 = ceilf(cyp + hy);
+            if (fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= f.W - 1.0f && fy0 <= f.H - 1.0f) {
+                int x0 = fx0 < 0.0f ? 0 : (int)fx0, x1 = fx1 > f.W - 1.0f ? f.width - 1 : (int)fx1;
+                int y0 = fy0 < 0.0f ? 0 : (int)fy0, y1 = fy1 > f.H - 1.0f ? f.height - 1 : (int)fy1;
+                int tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
+                int rows = owned_rows(ty0, ty1, f.shard_index, f.shard_count);
+                count = (uint32_t)((tx1 - tx0 + 1) * rows);
+                if (count) {
+                    rects[slot] = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
+                    Rec* dst = recs + slot;
+                    reinterpret_cast<float4*>(dst)[0] = make_float4(rec.iux, rec.iuy, rec.cxp, rec.alpha);
+                    reinterpret_cast<float4*>(dst)[1] = make_float4(rec.ivx, rec.ivy, rec.cyp, rec.depth);
+                    reinterpret_cast<float4*>(dst)[2] = make_float4(rec.r, rec.g, rec.b, 0.0f);
+                }
+            }
+        } while (0);
+    }
+    if (count == 0) rects[slot] = make_uint2(1u, 0u);  // empty: tx0 = 1 > tx1 = 0
+    if (DEBUG && in_list) dbg[d.entry_base + (d.count - 1u - r)] = vout;
+
+    // workgroup sums: pairs and visible splats
+    uint32_t wsum = count, wvis = visible ? 1u : 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+        wsum += __shfl_down(wsum, off, 64);
+        wvis += __shfl_down(wvis, off, 64);
+    }
+    if ((tid & 63u) == 0) { s_wsum[tid >> 6] = wsum; s_wvis[tid >> 6] = wvis; }
+    __syncthreads();
+    if (tid == 0) {
+        block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        uint32_t v = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
+        if (v) atomicAdd(&counters[0], (unsigned long long)v);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Exclusive scan (u32), reduce-then-scan, 1024 items per workgroup
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
+{
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t n = __shfl_up(v, off, 64);
+        if (lane >= (uint32_t)off) v += n;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix,
+// *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w /*[4]*/, uint32_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63u) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < w; i++) base += s_w[i];
+    *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ partial)
+{
+    __shared__ uint32_t s_w[4];
+    size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t s = 0;
+    for (int k = 0; k < 4; k++) if (base + k < n) s += in[base + k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// single workgroup: exclusive scan of n items in place (loops with carry); total -> *total_out
+__global__ __launch_bounds__(256) void k_scan_single(uint32_t* __restrict__ data, size_t n, uint32_t* __restrict__ total_out)
+{
+    __shared__ uint32_t s_w[4];
+    uint32_t carry = 0;
+    for (size_t base = 0; base < n; base += 1024) {
+        size_t i = base + threadIdx.x * 4;
+        uint32_t v[4], s = 0;
+        for (int k = 0; k < 4; k++) { v[k] = (i + k < n) ? data[i + k] : 0u; s += v[k]; }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(s, s_w, &tot) + carry;
+        for (int k = 0; k < 4; k++) { if (i + k < n) data[i + k] = ex; ex += v[k]; }
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
+                                                    const uint32_t* __restrict__ partial_scanned)
+{
+    __shared__ uint32_t s_w[4];
+    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+    uint32_t v[4], s = 0;
+    for (int k = 0; k < 4; k++) { v[k] = (i + k < n) ? in[i + k] : 0u; s += v[k]; }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(s, s_w, &tot) + partial_scanned[blockIdx.x];
+    for (int k = 0; k < 4; k++) { if (i + k < n) out[i + k] = ex; ex += v[k]; }
+}
+
+// ------------------------------------------------------------------------------------
+// k_emit: one thread per slot; pairs written at block_off[blk] + local exclusive prefix,
+// so the pair array is in composite (slot) order before the stable tile sort.
+// key = screen tile index local to the shard; val = slot.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __restrict__ rects,
+                                              const uint32_t* __restrict__ block_off,
+                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint2 rc = rects[slot];
+    const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
+    uint32_t count = 0;
+    if (tx1 >= tx0) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
+    uint32_t tot;
+    uint32_t off = block_off[blockIdx.x] + block_excl_scan(count, s_w, &tot);
+    if (count == 0) return;
+    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
+    int ty = ty0;
+    if (sc > 1) ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc;
+    for (; ty <= ty1; ty += sc) {
+        const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
+        for (int tx = tx0; tx <= tx1; tx++) {
+            keys[off] = row + (uint32_t)tx;
+            vals[off] = slot;
+            off++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Stable LSD radix sort pass on `nbits` (<= 8) key bits starting at `shift`.
+// 4096 items per workgroup; each of the 4 waves owns 1024 consecutive items and ranks
+// them 64 at a time with ballot match-any, so in-wave order == memory order.
+// ------------------------------------------------------------------------------------
+constexpr int kSortItems = 16;   // per thread
+constexpr int kSortBlock = 256 * kSortItems;
+
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
+                                                    uint32_t mask, uint32_t* __restrict__ ghist, uint32_t nblk)
+{
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t base = blockIdx.x * kSortBlock + w * (64 * kSortItems);
+    for (int k = 0; k < kSortItems; k++) {
+        uint32_t i = base + k * 64 + lane;
+        if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    ghist[threadIdx.x * nblk + blockIdx.x] = s_h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                                                       uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                       uint32_t n, uint32_t shift, uint32_t mask, uint32_t nbits,
+                                                       const uint32_t* __restrict__ ghist_scanned, uint32_t nblk)
+{
+    __shared__ uint32_t s_h[4][256];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (int k = 0; k < 4; k++) s_h[k][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortBlock + w * (64 * kSortItems);
+    uint32_t key[kSortItems], val[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        uint32_t i = base + k * 64 + lane;
+        if (i < n) {
+            key[k] = keys_in[i];
+            val[k] = vals_in[i];
+            atomicAdd(&s_h[w][(key[k] >> shift) & mask], 1u);
+        }
+    }
+    __syncthreads();
+    {   // digit = threadIdx.x: turn per-wave counts into per-wave global bases
+        uint32_t b = ghist_scanned[threadIdx.x * nblk + blockIdx.x];
+        for (int k = 0; k < 4; k++) { uint32_t c = s_h[k][threadIdx.x]; s_h[k][threadIdx.x] = b; b += c; }
+    }
+    __syncthreads();
+    volatile uint32_t* h = s_h[w];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        uint32_t i = base + k * 64 + lane;
+        bool valid = i < n;
+        uint32_t dgt = valid ? ((key[k] >> shift) & mask) : 0u;
+        unsigned long long peers = __ballot(valid);
+        for (uint32_t b = 0; b < nbits; b++) {
+            bool bit = (dgt >> b) & 1u;
+            unsigned long long m = __ballot(valid && bit);
+            peers &= bit ? m : ~m;
+        }
+        if (valid) {
+            uint32_t rank = __popcll(peers & lt);
+            uint32_t pos = h[dgt];
+            __builtin_amdgcn_wave_barrier();
+            if (rank == 0) h[dgt] = pos + __popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            keys_out[pos + rank] = key[k];
+            vals_out[pos + rank] = val[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_ranges: [start, end) of each screen tile in the sorted pair list (ranges pre-zeroed)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ keys, uint32_t n, uint2* __restrict__ ranges)
+{
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) ranges[k].x = i;
+    if (i == n - 1 || keys[i + 1] != k) ranges[k].y = i + 1;
+}
+
+// ------------------------------------------------------------------------------------
+// k_composite v1: one workgroup (4 waves) per 16x16 screen tile, one pixel per lane.
+// Batches of 256 pairs are staged through LDS (12 KB), each lane evaluating the canonical
+// per-pixel sequence F3/F4 of DESIGN.md; a wave stops reading when the ballot of
+// "transmittance still above eps" is empty, the workgroup when all four waves have.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
+                                                   const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
+                                                   const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
+                                                   float4* __restrict__ out, int n_tiles, int out_rows)
+{
+    __shared__ float4 s_q0[256], s_q1[256], s_q2[256];
+    // XCD-aware mapping: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch), give
+    // each XCD a contiguous band of screen tiles so neighbouring tiles share the XCD's L2.
+    const int nb = (int)gridDim.x;
+    const int per_xcd = (nb + 7) / 8;
+    int tile = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+    if (tile >= n_tiles) return;
+    const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
+    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
+    const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
+    const int bx = tx * kTile, by = ty * kTile;
+    const int lxi = threadIdx.x & 15, lyi = threadIdx.x >> 4;
+    const int px = bx + lxi, py = by + lyi;
+    const bool inside = px < f.width && py < f.height;
+    const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
+    const float fbx = (float)bx, fby = (float)by;
+    const uint2 rg = ranges[tile];
+    float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    float dbuf = 1.0f;
+    if (inside && f.has_depth) dbuf = bg_depth[(size_t)py * f.width + px];
+    bool done = !inside;
+    for (uint32_t base = rg.x; base < rg.y; base += 256u) {
+        const uint32_t n = min(256u, rg.y - base);
+        if (threadIdx.x < n) {
+            const uint32_t slot = vals[base + threadIdx.x];
+            const float4* rp = reinterpret_cast<const float4*>(recs + slot);
+            float4 a = rp[0], b = rp[1], c = rp[2];
+            // F3: per-(splat, tile) constants
+            float ox = a.z - fbx, oy = b.z - fby;
+            float nku = -fmaf(a.x, ox, a.y * oy);
+            float nkv = -fmaf(b.x, ox, b.y * oy);
+            s_q0[threadIdx.x] = make_float4(a.x, a.y, nku, a.w);
+            s_q1[threadIdx.x] = make_float4(b.x, b.y, nkv, b.w);
+            s_q2[threadIdx.x] = c;
+        }
+        __syncthreads();
+        for (uint32_t k = 0; k < n; k++) {
+            const float4 q0 = s_q0[k], q1 = s_q1[k];
+            // F4: per-pixel
+            float pu_y = fmaf(q0.y, ly, q0.z);
+            float pv_y = fmaf(q1.y, ly, q1.z);
+            float ppx = fmaf(q0.x, lx, pu_y);
+            float ppy = fmaf(q1.x, lx, pv_y);
+            float r2 = fmaf(ppy, ppy, ppx * ppx);
+            if (!done && r2 <= 4.0f && q1.w < dbuf) {
+                float Bv = __builtin_amdgcn_exp2f(r2 * -1.4426950408889634f) * q0.w;
+                float wgt = T * Bv;
+                const float4 q2 = s_q2[k];
+                ar = fmaf(wgt, q2.x, ar);
+                ag = fmaf(wgt, q2.y, ag);
+                ab = fmaf(wgt, q2.z, ab);
+                T = T - wgt;
+                done = T < f.t_eps;
+            }
+            if (__ballot(!done) == 0ull) break;   // whole wave saturated
+        }
+        if (__syncthreads_and(done ? 1 : 0)) break;
+    }
+    if (inside) {
+        float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bg_rgba) bg = bg_rgba[(size_t)py * f.width + px];
+        float4 o;
+        o.x = fmaf(T, bg.x, ar);
+        o.y = fmaf(T, bg.y, ag);
+        o.z = fmaf(T, bg.z, ab);
+        o.w = fmaf(T, bg.w, 1.0f - T);
+        const int orow = tyl * kTile + lyi;      // compacted row inside the shard image
+        if (orow < out_rows) out[(size_t)orow * f.width + px] = o;
+    }
+}
+
+// Zero-fill helper for shard padding rows / unshard scatter
+__global__ void k_unshard(const float4* __restrict__ gathered, float4* __restrict__ out, int width, int height,
+                          int shard_count, int rows_padded)
+{
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (x >= width || y >= height) return;
+    int ty = y >> 4;
+    int shard = ty % shard_count, tyl = ty / shard_count;
+    size_t src = ((size_t)shard * rows_padded + (size_t)tyl * kTile + (y & 15)) * width + x;
+    out[(size_t)y * width + x] = gathered[src];
+}
+
+// ---- launch wrappers (called from gswt_api.hip) -------------------------------------
+void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_chunks,
+                    const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
+                    const float* hmap, uint2* rects, Rec* recs, uint32_t* block_sums, unsigned long long* counters, Varyings* dbg)
+{
+    if (n_chunks == 0) return;
+    if (debug)
+        hipLaunchKernelGGL(k_project<true>, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,
+                           merged_map, tex, hmap, rects, recs, block_sums, counters, dbg);
+    else
+        hipLaunchKernelGGL(k_project<false>, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,
+                           merged_map, tex, hmap, rects, recs, block_sums, counters, dbg);
+}
+
+// exclusive scan of `n` u32 in `data` -> `out` (may alias), total -> *total_out.
+// ws: workspace of at least (n/1024 + 2) + (n/1048576 + 2) u32.
+void launch_scan(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* ws)
+{
+    if (n == 0) { hipMemsetAsync(total_out, 0, 4, s); return; }
+    size_t nb1 = (n + 1023) / 1024;
+    if (nb1 == 1) {
+        if (in != out) hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, s);
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(256), 0, s, out, n, total_out);
+        return;
+    }
+    uint32_t* p1 = ws;
+    hipLaunchKernelGGL(k_scan_reduce, dim3((uint32_t)nb1), dim3(256), 0, s, in, n, p1);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(256), 0, s, p1, nb1, total_out);
+    hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)nb1), dim3(256), 0, s, in, out, n, p1);
+}
+
+void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* rects, const uint32_t* block_off,
+                 uint32_t* keys, uint32_t* vals)
+{
+    if (n_chunks == 0) return;
+    hipLaunchKernelGGL(k_emit, dim3(n_chunks), dim3(256), 0, s, f, rects, block_off, keys, vals);
+}
+
+// Sorts (keys, vals) by key bits [0, key_bits); result ends in (keys_a, vals_a) or (keys_b, vals_b):
+// returns 0 if in a, 1 if in b.  ghist: 256 * nblk u32 (+ scan workspace after it).
+int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
+                int key_bits, uint32_t* ghist, uint32_t* scan_ws, uint32_t* scratch_total)
+{
+    if (n == 0) return 0;
+    uint32_t nblk = (n + kSortBlock - 1) / kSortBlock;
+    int cur = 0;
+    for (int shift = 0; shift < key_bits; shift += 8) {
+        uint32_t nbits = (uint32_t)((key_bits - shift) < 8 ? (key_bits - shift) : 8);
+        uint32_t mask = (1u << nbits) - 1u;
+        uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
+        uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, ki, n, (uint32_t)shift, mask, ghist, nblk);
+        launch_scan(s, ghist, ghist, (size_t)256 * nblk, scratch_total, scan_ws);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, ki, vi, ko, vo, n, (uint32_t)shift, mask, nbits, ghist, nblk);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n, uint2* ranges, uint32_t n_tiles)
+{
+    hipMemsetAsync(ranges, 0, (size_t)n_tiles * sizeof(uint2), s);
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_ranges, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, ranges);
+}
+
+void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
+                      const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows)
+{
+    if (n_tiles == 0) return;
+    int grid = ((n_tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, s, f, ranges, vals, recs, bg_rgba, bg_depth, out, n_tiles, out_rows);
+}
+
+void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded)
+{
+    hipLaunchKernelGGL(k_unshard, dim3((width + 255) / 256, height), dim3(256), 0, s, gathered, out, width, height, shard_count, rows_padded);
+}
+
+}  // namespace gswt

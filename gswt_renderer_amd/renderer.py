@@ -1,0 +1,169 @@
+"""Host-side mirror of the reference's ``renderer::GSWTRenderer`` over the C ABI.
+
+``GSWTRenderer.new / configure / render`` keep the reference's names and argument
+meaning (renderer.rs:31,351,407); device work is done by libgswt_hip.so.  There is no
+CPU fallback: constructing a renderer without the HIP library or a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+class GSWTError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"gswt error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def make_draw(tile: L.TileUniforms, *, base=None, merged_range=None, merged_has_lod=False, corners=None,
+              lod=None) -> L.Draw:
+    """One draw of the loop renderer.rs:466-591.  base = (lod, tile, view) of a static list or
+    merged_range = (offset, count) into the merged arrays."""
+    d = L.Draw()
+    d.tile = tile
+    if merged_range is not None:
+        d.merged = 1
+        d.merged_offset, d.merged_count = int(merged_range[0]), int(merged_range[1])
+        d.merged_has_lod = 1 if merged_has_lod else 0
+    else:
+        d.merged = 0
+        d.base_lod, d.base_tile, d.base_view = int(base[0]), int(base[1]), int(base[2])
+    if corners is not None:
+        d.cull_enable = 1
+        d.corners[:] = [float(x) for x in np.asarray(corners, dtype=np.float32).reshape(12)]
+    d.lod = int(tile.tile_id[0] if lod is None else lod)
+    return d
+
+
+class GSWTRenderer:
+    """renderer.rs:10-29.  Owns the device context and all HBM buffers."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        rc = self._lib.gswt_create(device_id, C.byref(h))
+        if rc != L.GSWT_OK:
+            raise GSWTError(rc, "gswt_create failed (no HIP device?)")
+        self._h = h
+        self.n_lists = (0, 0, 0)
+
+    # -- lifecycle ---------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gswt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != L.GSWT_OK:
+            raise GSWTError(rc, self._lib.gswt_last_error(self._h).decode())
+
+    def set_option(self, key: int, value: int):
+        self._check(self._lib.gswt_set_option(self._h, key, value))
+
+    def set_stream(self, hip_stream: int):
+        self._check(self._lib.gswt_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    # -- GSWTRenderer::new (renderer.rs:31): PreloadData upload ------------------------
+    def upload_scene(self, tex_data: np.ndarray, gs_index, gs_lod_id):
+        """tex_data [U, 8] u32 (Scene.tex_data); gs_index / gs_lod_id nested [lod][tile][view]."""
+        tex = np.ascontiguousarray(tex_data, dtype=np.uint32).reshape(-1, 8)
+        n_lod, n_tile, n_view = len(gs_index), len(gs_index[0]), len(gs_index[0][0])
+        arr = (L.BaseList * (n_lod * n_tile * n_view))()
+        keep = []
+        i = 0
+        for l in range(n_lod):
+            for t in range(n_tile):
+                for v in range(n_view):
+                    gi = np.ascontiguousarray(gs_index[l][t][v], dtype=np.uint32)
+                    li = np.ascontiguousarray(gs_lod_id[l][t][v], dtype=np.uint32)
+                    keep += [gi, li]
+                    arr[i].gs_index, arr[i].gs_lod_id, arr[i].splat_count = gi.ctypes.data, li.ctypes.data, gi.shape[0]
+                    i += 1
+        self._check(self._lib.gswt_upload_scene(self._h, _ptr(tex), tex.shape[0], arr, n_lod, n_tile, n_view))
+        self.n_lists = (n_lod, n_tile, n_view)
+
+    # -- GSWTRenderer::configure (renderer.rs:351) -----------------------------------
+    def configure(self, height_map: np.ndarray | None):
+        if height_map is None:
+            self._check(self._lib.gswt_configure(self._h, None, 0, 0))
+        else:
+            hm = np.ascontiguousarray(height_map, dtype=np.float32)
+            self._check(self._lib.gswt_configure(self._h, _ptr(hm), hm.shape[1], hm.shape[0]))
+
+    # -- SortData swap-in (state.rs:361-376) -------------------------------------------
+    def set_draws(self, draws, merged_gs_index=None, merged_map_id=None, merged_lod_id=None):
+        arr = (L.Draw * max(1, len(draws)))(*draws)
+        gi = np.ascontiguousarray(merged_gs_index, dtype=np.uint32) if merged_gs_index is not None else None
+        mi = np.ascontiguousarray(merged_map_id, dtype=np.uint32) if merged_map_id is not None else None
+        li = np.ascontiguousarray(merged_lod_id, dtype=np.uint32) if merged_lod_id is not None else None
+        n = 0 if gi is None else gi.shape[0]
+        self._check(self._lib.gswt_set_draws(self._h, arr, len(draws), _ptr(gi), _ptr(mi), _ptr(li), n))
+
+    # -- GSWTRenderer::render (renderer.rs:407) ---------------------------------------
+    def render(self, camera, scene, width: int, height: int, *, culling_dist: float = 1.0,
+               lod_enable_mask: int = 0xFFFFFFFF, order_mode: int = L.GSWT_ORDER_REFERENCE,
+               transmittance_eps: float = 0.0, shard=(0, 1), bg_rgba=None, bg_depth=None,
+               out_device_ptr: int | None = None, bg_on_device: bool = False):
+        """camera / scene: 176 / 160-byte uniform blocks (any ctypes struct or bytes of that layout).
+        Returns the image [rows, W, 4] f32 on the host, or None when out_device_ptr is given."""
+        cam = (C.c_char * 176).from_buffer_copy(bytes(camera))
+        sc = (C.c_char * 160).from_buffer_copy(bytes(scene))
+        cfg = L.RenderConfig()
+        cfg.culling_dist, cfg.lod_enable_mask, cfg.order_mode = culling_dist, lod_enable_mask & 0xFFFFFFFF, order_mode
+        cfg.transmittance_eps = transmittance_eps
+        cfg.shard_index, cfg.shard_count = int(shard[0]), int(shard[1])
+        rows = height if shard[1] <= 1 else self._lib.gswt_shard_rows_padded(height, shard[1])
+        if bg_on_device:
+            bgc = C.c_void_p(bg_rgba) if bg_rgba else None
+            bgd = C.c_void_p(bg_depth) if bg_depth else None
+        else:
+            bgc_a = np.ascontiguousarray(bg_rgba, dtype=np.float32) if bg_rgba is not None else None
+            bgd_a = np.ascontiguousarray(bg_depth, dtype=np.float32) if bg_depth is not None else None
+            bgc, bgd = _ptr(bgc_a), _ptr(bgd_a)
+        if out_device_ptr is not None:
+            self._check(self._lib.gswt_render(self._h, cam, sc, C.byref(cfg), width, height, bgc, bgd,
+                                              1 if bg_on_device else 0, C.c_void_p(out_device_ptr), 1))
+            return None
+        out = np.empty((rows, width, 4), dtype=np.float32)
+        self._check(self._lib.gswt_render(self._h, cam, sc, C.byref(cfg), width, height, bgc, bgd,
+                                          1 if bg_on_device else 0, _ptr(out), 0))
+        return out
+
+    def shard_rows_padded(self, height: int, shard_count: int) -> int:
+        return int(self._lib.gswt_shard_rows_padded(height, shard_count))
+
+    def unshard(self, gathered_device_ptr: int, width: int, height: int, shard_count: int, out_device_ptr: int):
+        self._check(self._lib.gswt_unshard(self._h, C.c_void_p(gathered_device_ptr), width, height, shard_count,
+                                           C.c_void_p(out_device_ptr)))
+
+    def synchronize(self):
+        self._check(self._lib.gswt_synchronize(self._h))
+
+    def timings(self) -> dict:
+        t = L.Timings()
+        self._check(self._lib.gswt_last_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in L.Timings._fields_ if k != "_pad"}
+
+    VARYINGS_DTYPE = np.dtype([("visible", "<i4"), ("ndc", "<f4", 2), ("depth", "<f4"), ("major", "<f4", 2),
+                               ("minor", "<f4", 2), ("rgba", "<f4", 4)])
+
+    def read_projected(self) -> np.ndarray:
+        n = C.c_size_t(0)
+        self._check(self._lib.gswt_debug_read_projected(self._h, None, 0, C.byref(n)))
+        out = np.zeros(max(1, n.value), dtype=self.VARYINGS_DTYPE)
+        self._check(self._lib.gswt_debug_read_projected(self._h, _ptr(out), out.shape[0], C.byref(n)))
+        return out[:n.value]

@@ -1,0 +1,213 @@
+/*
+ * gswt_hip.h -- C ABI of libgswt_hip.so, the MI355X-native drop-in for the GPU half
+ * of the GSWT hot path: per-frame Wang-tile instancing, Gaussian projection,
+ * ordering, 16x16 screen-tile binning and alpha compositing.
+ *
+ * Each entry point names the reference interface it replaces (file:line are into
+ * zengyf131/gswt_renderer).  Plain pointers and sizes only; no C++/torch types.
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Threading (mirrors renderer.rs: render runs on the main thread only): a ctx is
+ * single-owner, one caller thread at a time.  A ctx owns one HIP stream; all work
+ * of a call is enqueued on it.  Every host pointer is borrowed for the duration of
+ * the call only.  No call aborts or throws across the ABI: all return an int status
+ * and gswt_last_error() holds the text of the last failure on that ctx.
+ */
+#ifndef GSWT_HIP_H
+#define GSWT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSWT_API __attribute__((visibility("default")))
+
+typedef struct gswt_ctx gswt_ctx;
+
+enum {
+    GSWT_OK = 0,
+    GSWT_ERR_BAD_ARG = -1,   /* reference: assert!/unwrap panic on malformed input      */
+    GSWT_ERR_CAPACITY = -2,  /* reference: silent wgpu validation error past 20 000 draws
+                                / 10 M merged splats (renderer.rs:253,273); here buffers
+                                grow on demand, this code only reports a failed grow     */
+    GSWT_ERR_HIP = -3,       /* any HIP runtime error                                    */
+    GSWT_ERR_STATE = -4      /* call order violated (e.g. render before upload_scene)    */
+};
+
+/* Composite order.  REFERENCE reproduces the reference's order exactly: draw rank
+ * (back-to-front tile list, wangtile.rs:489-499) x position in that draw's presorted
+ * list (scene.rs:685-695).  DEPTH is a true per-splat global depth sort. */
+enum { GSWT_ORDER_REFERENCE = 0, GSWT_ORDER_DEPTH = 1 };
+
+/* ---- byte-exact mirrors of the reference's uniform blocks ------------------------ */
+
+/* CameraUniforms, camera.rs:158-167 / gswt.wgsl:437-444 (176 bytes) */
+typedef struct {
+    float projection[16]; /* column-major */
+    float view[16];
+    float focal[2];
+    float viewport[2];
+    float htan_fov[4];
+    float cam_pos[4];
+} gswt_camera_uniforms;
+
+/* SceneUniforms, renderer.rs:602-622 / gswt.wgsl:446-463 (160 bytes) */
+typedef struct {
+    float splat_scale;
+    float tile_width;
+    uint32_t use_clip;
+    float clip_height;
+    uint32_t surface_type; /* 0 None, 1 HeightMap, 2 Sphere (structure.rs:435-440) */
+    float sphere_radius;
+    float point_cloud_radius;
+    float transition_width_ratio;
+    uint32_t num_lod;
+    uint32_t draw_mode;
+    uint32_t map_half_wh[2];
+    int32_t center_coord[2];
+    uint32_t _pad0[2];
+    float transition_dist_vec[16];
+    float height_map_scale[4];
+    float scene_scale[4];
+} gswt_scene_uniforms;
+
+/* TileUniforms, renderer.rs:675-689 / gswt.wgsl:465-476 (80 bytes) */
+typedef struct {
+    uint32_t single_draw;
+    uint32_t map_index;
+    int32_t single_lod_id;
+    int32_t valid_lod_id;
+    uint32_t changing;
+    int32_t changing_to_lower;
+    uint32_t _pad0[2];
+    uint32_t tile_id[4]; /* lod, tile, view, 0 */
+    float offset[4];
+    uint32_t map_coord[4];
+} gswt_tile_uniforms;
+
+/* One static presorted list of PreloadData.tile_base_data[lod][tile][view]
+ * (structure.rs:546-554: gs_index + gs_lod_id, splat_count entries each). */
+typedef struct {
+    const uint32_t *gs_index;
+    const uint32_t *gs_lod_id;
+    uint32_t splat_count;
+    uint32_t _pad;
+} gswt_base_list;
+
+/* One iteration of the draw loop in GSWTRenderer::render (renderer.rs:466-591):
+ * the tile uniforms written at :499-515 plus which instance buffers get bound. */
+typedef struct {
+    gswt_tile_uniforms tile;
+    /* list selection, renderer.rs:517-579 */
+    uint32_t merged;        /* 1: merged group (Some(render_data_value)) -> range of the
+                               merged arrays passed to gswt_set_draws; 0: static base list */
+    uint32_t base_lod;      /* static list [base_lod][base_tile][base_view]; the caller   */
+    uint32_t base_tile;     /* applies renderer.rs:564-572 (Changing(false) -> lod-1)     */
+    uint32_t base_view;
+    uint32_t merged_offset; /* first element of this draw in the merged arrays            */
+    uint32_t merged_count;  /* render_data_value.splat_count                              */
+    uint32_t merged_has_lod;/* 1 iff single_lod_id == -1 (gs_lod_id uploaded, :544-556)   */
+    /* CPU viewport culling inputs, renderer.rs:472-494 (non-merged draws only) */
+    uint32_t cull_enable;   /* 1 iff render_data_key.tid.len() == 1                        */
+    float corners[12];      /* tile_instance.corner_data[ci].0, ci = 0..3                  */
+    uint32_t lod;           /* tid.0, index into lod_enable (renderer.rs:495)              */
+    uint32_t _pad[3];
+} gswt_draw;
+
+/* The parts of RenderConfig (structure.rs:346-388) read on the hot path. */
+typedef struct {
+    float culling_dist;       /* render_config.culling_dist, renderer.rs:490 */
+    uint32_t lod_enable_mask; /* bit l = render_config.lod_enable[l], renderer.rs:495 */
+    int32_t order_mode;       /* GSWT_ORDER_* */
+    float transmittance_eps;  /* front-to-back early-out threshold; 0 = never stop early */
+    /* screen-tile sharding for multi-GPU: this ctx composites only 16-px tile rows with
+       (row % shard_count) == shard_index and writes them compacted, in row order.
+       shard_count <= 1 renders the whole frame. */
+    int32_t shard_index;
+    int32_t shard_count;
+    uint32_t _pad[2];
+} gswt_render_config;
+
+/* Per-stage device times of the last gswt_render (hipEvent, ms) and workload sizes. */
+typedef struct {
+    float ms_project, ms_scan, ms_emit, ms_sort, ms_ranges, ms_composite, ms_total;
+    uint32_t n_draws;
+    uint64_t n_instanced; /* N: list entries iterated             */
+    uint64_t n_visible;   /* survivors of the vertex stage        */
+    uint64_t n_pairs;     /* P: (splat, 16x16 screen tile) pairs  */
+    uint32_t n_tiles;     /* screen tiles composited by this ctx  */
+    uint32_t _pad;
+} gswt_timings;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+
+/* wgpu adapter/device acquisition in State::new (state.rs:56-92). */
+GSWT_API int gswt_create(int device_id, gswt_ctx **out);
+GSWT_API void gswt_destroy(gswt_ctx *ctx);
+GSWT_API const char *gswt_last_error(const gswt_ctx *ctx);
+/* Runs on a user-provided HIP stream (hipStream_t as void*) instead of the ctx's own. */
+GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
+
+/* Options (no reference counterpart; test / profiling switches).
+ * NO_LOD_PREFILTER: a plain tile iterates the interleaved LOD l / l+1 base list exactly as the
+ *   reference binds it (renderer.rs:571-578) instead of the pre-filtered own-LOD list; results
+ *   are identical (gswt.wgsl:38-42 discards the other LOD), only the entry count differs.
+ * DEBUG_VARYINGS: keep vs_main's per-entry outputs for gswt_debug_read_projected. */
+enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2 };
+GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
+
+/* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data
+ * (8 u32 per splat, renderer.rs:236-248) and all static base lists (renderer.rs:290-327).
+ * lists is [n_lod][n_tile][n_view] row-major. */
+GSWT_API int gswt_upload_scene(gswt_ctx *ctx, const uint32_t *tex_data, size_t n_splats,
+                               const gswt_base_list *lists, int n_lod, int n_tile, int n_view);
+
+/* GSWTRenderer::configure (renderer.rs:351-405): height map, R32Float / linear / repeat.
+ * height_map may be NULL (surface_type None). */
+GSWT_API int gswt_configure(gswt_ctx *ctx, const float *height_map, int hm_w, int hm_h);
+
+/* Swap-in of a SortData (state.rs:361-376) = the per-sort-event part of render():
+ * the ordered draw list (back-to-front, renderer.rs:466) and the concatenated
+ * gs_index / gs_map_id / gs_lod_id arrays of all merged groups (renderer.rs:517-561).
+ * merged_lod_id may be NULL when no draw has merged_has_lod. */
+GSWT_API int gswt_set_draws(gswt_ctx *ctx, const gswt_draw *draws, int n_draws,
+                            const uint32_t *merged_gs_index, const uint32_t *merged_map_id,
+                            const uint32_t *merged_lod_id, size_t n_merged);
+
+/* GSWTRenderer::render (renderer.rs:407-592), per frame.  bg_rgba (W*H*4 f32) is the
+ * colour attachment content the pass loads (LoadOp::Load, :425; skybox/proxy output) or
+ * NULL for transparent black; bg_depth (W*H f32) is the proxy depth buffer (:433-434) or
+ * NULL for the 1.0 clear (:436).  out_rgba receives rows_out*W*4 f32 where rows_out = H,
+ * or the shard's rows when cfg->shard_count > 1 (see gswt_shard_rows).  Pointers are
+ * device pointers when *_on_device is nonzero, host pointers otherwise. */
+GSWT_API int gswt_render(gswt_ctx *ctx, const gswt_camera_uniforms *camera,
+                         const gswt_scene_uniforms *scene, const gswt_render_config *cfg,
+                         int width, int height,
+                         const float *bg_rgba, const float *bg_depth, int bg_on_device,
+                         float *out_rgba, int out_on_device);
+
+/* Number of pixel rows the shard (index, count) owns for a frame of `height` rows. */
+GSWT_API int gswt_shard_rows(int height, int shard_index, int shard_count);
+/* Scatter `shard_count` gathered shard images (concatenated in shard order, as an
+ * all-gather delivers them; each padded to gswt_shard_rows_padded rows) back into a full
+ * H x W frame.  Device pointers; runs on the ctx stream. */
+GSWT_API int gswt_shard_rows_padded(int height, int shard_count);
+GSWT_API int gswt_unshard(gswt_ctx *ctx, const float *gathered, int width, int height,
+                          int shard_count, float *out_rgba);
+
+GSWT_API int gswt_synchronize(gswt_ctx *ctx);
+GSWT_API int gswt_last_timings(const gswt_ctx *ctx, gswt_timings *out);
+
+/* Test / profiling hook: per-splat vertex-stage output of the last gswt_render, one
+ * 48-byte record per list entry in draw order (visible, ndc.xy, depth, major.xy,
+ * minor.xy, rgba) -- the varyings of vs_main (gswt.wgsl:4-8,412-419). Host pointer. */
+GSWT_API int gswt_debug_read_projected(gswt_ctx *ctx, void *out, size_t capacity_entries,
+                                       size_t *n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSWT_HIP_H */

@@ -1,0 +1,810 @@
+/*
+ * gswt_oracle.c -- CPU ORACLE for the GSWT hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is a plain-C restatement of the reference's algorithm
+ * (zengyf131/gswt_renderer: src/gswt.wgsl, src/renderer.rs, src/scene.rs,
+ * src/utils.rs), written from the source text.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load it.  The product
+ * (gswt_renderer_amd/) never links, imports or calls anything in oracle/.
+ *
+ * PARITY STATUS: "parity unpinned by the reference".  The reference (Rust ->
+ * wasm32 + WGSL on wgpu) cannot be compiled or run in this environment and it
+ * ships no tests, golden images or known-answer vectors.  This restatement is
+ * pinned instead by known-answer tests derived from the source text (tests/
+ * test_oracle_kat.py: K1..K15 of SURVEY.md section 8c) and by committed golden
+ * fixtures generated from it (tests/golden/).
+ *
+ * Arithmetic: every float operation below is IEEE-754 binary32, one rounding per
+ * written operator, no contraction (build with -ffp-contract=off).  Where a fused
+ * multiply-add is part of the canonical sequence it is written fmaf() explicitly.
+ * DESIGN.md "Canonical float sequences" lists the sequences the HIP kernels must
+ * reproduce bit-for-bit (everything that feeds a discontinuous decision: culling,
+ * the |p|^2 <= 4 coverage test, the depth test).
+ *
+ * Conventions: matrices are column-major, m[4*c + r] (cgmath / WGSL layout).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* Bit-level helpers                                                          */
+/* ------------------------------------------------------------------------- */
+
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* halfToFloat, gswt.wgsl:478-494.  NOT IEEE: subnormals scale by 2^-15 (not
+ * 2^-14) and Inf/NaN decode to 0.  pow(2, k) with integer k is exact -> ldexpf. */
+ORC_API float orc_half_to_float(uint32_t h)
+{
+    float s = (float)((h >> 15) & 0x1u);
+    uint32_t e = (h >> 10) & 0x1Fu;
+    float f = (float)(h & 0x3FFu);
+    float sign = 1.0f - 2.0f * s;
+    if (e == 0u) {
+        return ldexpf(1.0f, -15) * (f / 1024.0f) * sign;
+    } else if (e == 31u) {
+        return 0.0f;
+    }
+    return ldexpf(1.0f, (int)e - 15) * (1.0f + f / 1024.0f) * sign;
+}
+
+/* half::f16::from_f32 (half 2.7.1): IEEE binary16, round-to-nearest-even.
+ * Call site utils.rs:66-73. */
+ORC_API uint32_t orc_float_to_half(float value)
+{
+    uint32_t x = f2u(value);
+    uint32_t sign = x & 0x80000000u;
+    uint32_t exp = x & 0x7F800000u;
+    uint32_t man = x & 0x007FFFFFu;
+    if (exp == 0x7F800000u) {                       /* Inf / NaN */
+        uint32_t nan_bit = man == 0 ? 0 : 0x0200u;
+        return (sign >> 16) | 0x7C00u | nan_bit | (man >> 13);
+    }
+    uint32_t half_sign = sign >> 16;
+    int32_t unbiased = (int32_t)(exp >> 23) - 127;
+    int32_t half_exp = unbiased + 15;
+    if (half_exp >= 0x1F) return half_sign | 0x7C00u;  /* overflow -> Inf */
+    if (half_exp <= 0) {                            /* subnormal or zero */
+        if (14 - half_exp > 24) return half_sign;
+        man |= 0x00800000u;
+        uint32_t shift = (uint32_t)(14 - half_exp);
+        uint32_t half_man = man >> shift;
+        uint32_t round_bit = 1u << (shift - 1);
+        if ((man & round_bit) != 0 && (man & (3 * round_bit - 1)) != 0) half_man += 1;
+        return half_sign | half_man;
+    }
+    uint32_t half_e = (uint32_t)half_exp << 10;
+    uint32_t half_man = man >> 13;
+    uint32_t round_bit = 0x00001000u;
+    if ((man & round_bit) != 0 && (man & (3 * round_bit - 1)) != 0)
+        return (half_sign | half_e | half_man) + 1;
+    return half_sign | half_e | half_man;
+}
+
+/* pack_half_2x16, utils.rs:66-73 */
+ORC_API uint32_t orc_pack_half_2x16(float x, float y)
+{
+    return orc_float_to_half(x) | (orc_float_to_half(y) << 16);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Scene::generate_texture, scene.rs:306-411                                  */
+/* rows32: n rows of [pos f32x3][scale f32x3][rgba u8x4][rot u8x4]            */
+/* tex   : 8 u32 per splat [pos x3][0][ab][cd][ef][rgba]                      */
+/* ------------------------------------------------------------------------- */
+ORC_API void orc_generate_texture(const uint8_t *rows32, size_t n, uint32_t *tex)
+{
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *row = rows32 + 32 * i;
+        float fb[6];
+        memcpy(fb, row, 24);
+        uint32_t *t = tex + 8 * i;
+        memcpy(t, row, 12);                 /* position, :330-336 */
+        t[3] = 0;
+        memcpy(&t[7], row + 24, 4);         /* rgba, :341-349 */
+        float scale[3] = { fb[3], fb[4], fb[5] };
+        float rot[4];
+        for (int k = 0; k < 4; k++)          /* :361-367, no renormalisation */
+            rot[k] = ((float)row[28 + k] / 255.0f) * 2.0f - 1.0f;
+        /* R column-major, :369-380 */
+        float r[9];
+        r[0] = 1.0f - 2.0f * (rot[2] * rot[2] + rot[3] * rot[3]);
+        r[1] = 2.0f * (rot[1] * rot[2] + rot[0] * rot[3]);
+        r[2] = 2.0f * (rot[1] * rot[3] - rot[0] * rot[2]);
+        r[3] = 2.0f * (rot[1] * rot[2] - rot[0] * rot[3]);
+        r[4] = 1.0f - 2.0f * (rot[1] * rot[1] + rot[3] * rot[3]);
+        r[5] = 2.0f * (rot[2] * rot[3] + rot[0] * rot[1]);
+        r[6] = 2.0f * (rot[1] * rot[3] + rot[0] * rot[2]);
+        r[7] = 2.0f * (rot[2] * rot[3] - rot[0] * rot[1]);
+        r[8] = 1.0f - 2.0f * (rot[1] * rot[1] + rot[2] * rot[2]);
+        /* m = r * diag(scale), cgmath Matrix3 * Matrix3: each element is
+         * r[0][row]*s[c][0] + r[1][row]*s[c][1] + r[2][row]*s[c][2] with the two
+         * off-diagonal zeros of s -> exactly r[c][row]*scale[c] (x*0 adds +-0). */
+        float m[9];
+        for (int c = 0; c < 3; c++)
+            for (int rr = 0; rr < 3; rr++) {
+                float acc = 0.0f;
+                for (int k = 0; k < 3; k++) {
+                    float sk = (k == c) ? scale[c] : 0.0f;
+                    float term = r[3 * k + rr] * sk;
+                    acc = (k == 0) ? term : acc + term;
+                }
+                m[3 * c + rr] = acc;
+            }
+        /* sigma, :391-398 */
+        float sigma[6];
+        sigma[0] = m[0] * m[0] + m[3] * m[3] + m[6] * m[6];
+        sigma[1] = m[0] * m[1] + m[3] * m[4] + m[6] * m[7];
+        sigma[2] = m[0] * m[2] + m[3] * m[5] + m[6] * m[8];
+        sigma[3] = m[1] * m[1] + m[4] * m[4] + m[7] * m[7];
+        sigma[4] = m[1] * m[2] + m[4] * m[5] + m[7] * m[8];
+        sigma[5] = m[2] * m[2] + m[5] * m[5] + m[8] * m[8];
+        t[4] = orc_pack_half_2x16(4.0f * sigma[0], 4.0f * sigma[1]);  /* :403-405 */
+        t[5] = orc_pack_half_2x16(4.0f * sigma[2], 4.0f * sigma[3]);
+        t[6] = orc_pack_half_2x16(4.0f * sigma[4], 4.0f * sigma[5]);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Scene::sort_raw_depth_vec, scene.rs:655-698 (same kernel as sort_self      */
+/* :557-583).  depths: concatenated segments; order_out[j] = index into the    */
+/* concatenation (caller maps back to (segment, index-in-segment)).            */
+/* Rust `as i32` on f32 saturates and maps NaN to 0.                           */
+/* ------------------------------------------------------------------------- */
+static inline int32_t rust_f32_as_i32(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+
+ORC_API void orc_sort_raw_depth(const int32_t *depths, size_t n, uint32_t *order_out)
+{
+    if (n == 0) return;
+    int32_t mn = depths[0], mx = depths[0];
+    for (size_t i = 1; i < n; i++) {
+        if (depths[i] < mn) mn = depths[i];
+        if (depths[i] > mx) mx = depths[i];
+    }
+    const int32_t size16 = 65536;
+    /* (max - min) is an i32 subtraction in Rust (debug builds would panic on
+     * overflow; release wraps).  Raw depths are bounded by 4096*|pos| so no wrap. */
+    float depth_inv = (float)(size16 - 1) / (float)(int32_t)(mx - mn);
+    uint32_t *counts = (uint32_t *)calloc((size_t)size16, 4);
+    uint32_t *starts = (uint32_t *)calloc((size_t)size16, 4);
+    int32_t *bucket = (int32_t *)malloc(n * 4);
+    for (size_t i = 0; i < n; i++) {
+        float v = floorf((float)(int32_t)(depths[i] - mn) * depth_inv);
+        int32_t d = rust_f32_as_i32(v);
+        if (d < 0) d = 0;
+        if (d > size16 - 1) d = size16 - 1;
+        bucket[i] = d;
+        counts[d]++;
+    }
+    for (int32_t i = 1; i < size16; i++) starts[i] = starts[i - 1] + counts[i - 1];
+    for (size_t i = 0; i < n; i++) {
+        uint32_t j = starts[bucket[i]]++;
+        order_out[j] = (uint32_t)i;
+    }
+    for (size_t a = 0, b = n - 1; a < b; a++, b--) {   /* depth_index.reverse() */
+        uint32_t t = order_out[a]; order_out[a] = order_out[b]; order_out[b] = t;
+    }
+    free(counts); free(starts); free(bucket);
+}
+
+/* raw depth of sort_self, scene.rs:537-552: ((vp[2]x + vp[6]y + vp[10]z)*4096) as i32 */
+ORC_API void orc_raw_depth(const uint8_t *rows32, size_t n, const float *view_proj16, int32_t *out)
+{
+    for (size_t i = 0; i < n; i++) {
+        float p[3];
+        memcpy(p, rows32 + 32 * i, 12);
+        float d = (view_proj16[2] * p[0] + view_proj16[6] * p[1] + view_proj16[10] * p[2]) * 4096.0f;
+        out[i] = rust_f32_as_i32(d);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Uniform blocks (byte layouts: renderer.rs:602-726, camera.rs:158-189,       */
+/* gswt.wgsl:437-476)                                                          */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    float projection[16];   /*   0 */
+    float view[16];         /*  64 */
+    float focal[2];         /* 128 */
+    float viewport[2];      /* 136 */
+    float htan_fov[4];      /* 144 */
+    float cam_pos[4];       /* 160 */
+} orc_camera;               /* 176 B */
+
+typedef struct {
+    float splat_scale;      /*  0 */
+    float tile_width;       /*  4 */
+    uint32_t use_clip;      /*  8 */
+    float clip_height;      /* 12 */
+    uint32_t surface_type;  /* 16 */
+    float sphere_radius;    /* 20 */
+    float point_cloud_radius; /* 24 */
+    float transition_width_ratio; /* 28 */
+    uint32_t num_lod;       /* 32 */
+    uint32_t draw_mode;     /* 36 */
+    uint32_t map_half_wh[2];/* 40 */
+    int32_t center_coord[2];/* 48 */
+    uint32_t _pad0[2];      /* 56 */
+    float transition_dist[16]; /* 64 */
+    float height_map_scale[4]; /* 128 */
+    float scene_scale[4];   /* 144 */
+} orc_scene;                /* 160 B */
+
+typedef struct {
+    uint32_t single_draw;   /*  0 */
+    uint32_t map_index;     /*  4 */
+    int32_t single_lod_id;  /*  8 */
+    int32_t valid_lod_id;   /* 12 */
+    uint32_t changing;      /* 16 */
+    int32_t changing_to_lower; /* 20 */
+    uint32_t _pad0[2];      /* 24 */
+    uint32_t tile_id[4];    /* 32 */
+    float offset[4];        /* 48 */
+    uint32_t map_coord[4];  /* 64 */
+} orc_tile;                 /* 80 B */
+
+/* One draw call of GSWTRenderer::render (renderer.rs:466-590): tile uniforms +
+ * the three instance-rate vertex buffers (gs_index, map_id, lod_id) and the
+ * instance count.  map_id / lod_id may be NULL where the shader never reads them
+ * (renderer.rs:558,576 bind stale buffers in those cases). */
+typedef struct {
+    orc_tile tile;
+    const uint32_t *gs_index;
+    const uint32_t *map_id;
+    const uint32_t *lod_id;
+    uint32_t count;
+    uint32_t _pad;
+} orc_draw;
+
+/* Per-splat vertex-stage result (gswt.wgsl:27-422) */
+typedef struct {
+    int32_t visible;     /* 0 = discarded / clipped */
+    float ndc[2];        /* vCenter.xy */
+    float depth;         /* vCenter.z  */
+    float major[2];      /* majorAxis  */
+    float minor[2];      /* minorAxis  */
+    float rgba[4];       /* v_color    */
+} orc_splat;
+
+static inline float clampf(float e, float lo, float hi) { return fminf(fmaxf(e, lo), hi); }
+
+/* WebGPU textureSampleLevel on an R32Float texture, FilterMode::Linear,
+ * AddressMode::Repeat, level 0 (renderer.rs:376-388).  Texel centres at +0.5. */
+static float sample_height(const float *hm, int w, int h, float u, float v)
+{
+    float x = u * (float)w - 0.5f;
+    float y = v * (float)h - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float tx = x - fx0, ty = y - fy0;
+    long x0 = (long)fx0, y0 = (long)fy0;
+    long xa = ((x0 % w) + w) % w, xb = (((x0 + 1) % w) + w) % w;
+    long ya = ((y0 % h) + h) % h, yb = (((y0 + 1) % h) + h) % h;
+    float i00 = hm[ya * w + xa], i10 = hm[ya * w + xb];
+    float i01 = hm[yb * w + xa], i11 = hm[yb * w + xb];
+    float i0 = i00 * (1.0f - tx) + i10 * tx;
+    float i1 = i01 * (1.0f - tx) + i11 * tx;
+    return i0 * (1.0f - ty) + i1 * ty;
+}
+
+/* surface_mapping, gswt.wgsl:565-624, HeightMap branch (surface_type == 1).
+ * transform is column-major 3x3: cols local_x, local_y, local_z. */
+static void surface_mapping_hmap(const orc_scene *s, const float *hm, int hw, int hh,
+                                 float px, float py, float new_pos[3], float tr[9])
+{
+    const float DELTA = 0.001f;
+    float xr = (2.0f * (float)s->map_half_wh[0] + 1.0f) * s->tile_width * s->height_map_scale[0];
+    float yr = (2.0f * (float)s->map_half_wh[1] + 1.0f) * s->tile_width * s->height_map_scale[1];
+    float h_u = (px + (float)s->map_half_wh[0] * s->tile_width) / xr;
+    float h_v = (py + (float)s->map_half_wh[1] * s->tile_width) / yr;
+    float hz = s->height_map_scale[2];
+    new_pos[0] = px; new_pos[1] = py;
+    new_pos[2] = sample_height(hm, hw, hh, h_u, h_v) * hz;
+    float dt = DELTA;
+    float h_r = sample_height(hm, hw, hh, h_u + dt, h_v) * hz;
+    float h_l = sample_height(hm, hw, hh, h_u - dt, h_v) * hz;
+    float h_up = sample_height(hm, hw, hh, h_u, h_v + dt) * hz;
+    float h_d = sample_height(hm, hw, hh, h_u, h_v - dt) * hz;
+    float lx[3] = { 1.0f, 0.0f, (h_r - h_l) / (2.0f * dt * xr) };
+    float ly[3] = { 0.0f, 1.0f, (h_up - h_d) / (2.0f * dt * yr) };
+    /* cross(lx, ly) */
+    float cz[3] = { lx[1] * ly[2] - lx[2] * ly[1],
+                    lx[2] * ly[0] - lx[0] * ly[2],
+                    lx[0] * ly[1] - lx[1] * ly[0] };
+    float len = sqrtf((cz[0] * cz[0] + cz[1] * cz[1]) + cz[2] * cz[2]);
+    tr[0] = lx[0]; tr[1] = lx[1]; tr[2] = lx[2];
+    tr[3] = ly[0]; tr[4] = ly[1]; tr[5] = ly[2];
+    tr[6] = cz[0] / len; tr[7] = cz[1] / len; tr[8] = cz[2] / len;
+}
+
+/* vs_main, gswt.wgsl:27-422, draw_mode 0.  Canonical float sequence "A1..A10"
+ * of DESIGN.md.  Returns out->visible. */
+ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_tile *u,
+                        const uint32_t *tex, uint32_t gs_index, uint32_t map_id, uint32_t lod_id,
+                        const float *hmap, int hm_w, int hm_h, orc_splat *out)
+{
+    memset(out, 0, sizeof(*out));
+    /* A1 :38-42 */
+    if (u->valid_lod_id >= 0 && u->valid_lod_id != (int32_t)lod_id) return 0;
+    /* A2 :45-49  texel (u,v) == linear u32[8*i .. 8*i+8] */
+    const uint32_t *rec = tex + 8 * (size_t)gs_index;
+    float pos[3] = { u2f(rec[0]), u2f(rec[1]), u2f(rec[2]) };
+    /* A3 :52-65 */
+    float off[3] = { u->offset[0], u->offset[1], u->offset[2] };
+    uint32_t map_wh_y = 2u * s->map_half_wh[1];
+    if (s->surface_type != 2u) map_wh_y += 1u;
+    if (u->single_draw == 1u) {
+        off[0] = (float)((int32_t)(map_id / map_wh_y - s->map_half_wh[0]) + s->center_coord[0]) * s->tile_width;
+        off[1] = (float)((int32_t)(map_id % map_wh_y - s->map_half_wh[1]) + s->center_coord[1]) * s->tile_width;
+        off[2] = 0.0f;
+    }
+    float c[3];
+    for (int k = 0; k < 3; k++) c[k] = (pos[k] + off[k]) * s->scene_scale[k];
+    /* A4 :75-87 */
+    float mapped_z = 0.0f;
+    float F[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    if (s->surface_type == 1u) {
+        float np[3];
+        surface_mapping_hmap(s, hmap, hm_w, hm_h, c[0], c[1], np, F);
+        /* center = mapped + transform * (0,0,z): col2 * z (the two zero terms add +-0) */
+        float z = c[2];
+        c[0] = np[0] + F[6] * z;
+        c[1] = np[1] + F[7] * z;
+        c[2] = np[2] + F[8] * z;
+        mapped_z = np[2];
+    } else if (s->surface_type == 2u) {
+        return 0;   /* sphere mapping: SURVEY 8f rank 4, not restated yet */
+    }
+    if (s->use_clip == 1u && mapped_z < s->clip_height) return 0;
+    /* A5 :91-150 */
+    float t_ratio = -1.0f;
+    uint32_t higher_lod = 0u;
+    if (u->changing == 1u) {
+        float dx = c[0] - cam->cam_pos[0], dy = c[1] - cam->cam_pos[1], dz = c[2] - cam->cam_pos[2];
+        float cam_dist = sqrtf((dx * dx + dy * dy) + dz * dz);
+        if (u->single_draw == 1u) {
+            if (lod_id == 0u) higher_lod = 0u;
+            else if (lod_id == s->num_lod - 1u) higher_lod = lod_id - 1u;
+            else {
+                float d1 = s->transition_dist[lod_id - 1u];
+                float d2 = s->transition_dist[lod_id];
+                higher_lod = (cam_dist - d1 < d2 - cam_dist) ? lod_id - 1u : lod_id;
+            }
+        } else {
+            higher_lod = (u->changing_to_lower == 1) ? u->tile_id[0] : u->tile_id[0] - 1u;
+        }
+        float td = s->transition_dist[higher_lod & 15u];
+        float thw = s->transition_width_ratio * td;
+        t_ratio = clampf((cam_dist - td) / thw + 0.5f, 0.0f, 1.0f);
+        if ((lod_id == higher_lod + 1u && t_ratio == 0.0f) || (lod_id == higher_lod && t_ratio == 1.0f))
+            return 0;
+    }
+    /* A6 :152-167.  pos2d = (opengl_to_wgpu * projection) * (view * center) */
+    const float *V = cam->view, *P = cam->projection;
+    float cv[4];
+    for (int r = 0; r < 4; r++) cv[r] = ((V[r] * c[0] + V[4 + r] * c[1]) + V[8 + r] * c[2]) + V[12 + r];
+    float GP[16];
+    for (int cc = 0; cc < 4; cc++) {
+        GP[4 * cc + 0] = P[4 * cc + 0];
+        GP[4 * cc + 1] = P[4 * cc + 1];
+        GP[4 * cc + 2] = 0.5f * P[4 * cc + 2] + 0.5f * P[4 * cc + 3];
+        GP[4 * cc + 3] = P[4 * cc + 3];
+    }
+    float q[4];
+    for (int r = 0; r < 4; r++)
+        q[r] = ((GP[r] * cv[0] + GP[4 + r] * cv[1]) + GP[8 + r] * cv[2]) + GP[12 + r] * cv[3];
+    float clip = 1.2f * q[3];
+    if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) return 0;
+    /* A7 :169-205 */
+    float a = orc_half_to_float(rec[4] & 0xFFFFu), b = orc_half_to_float(rec[4] >> 16);
+    float c2 = orc_half_to_float(rec[5] & 0xFFFFu), d = orc_half_to_float(rec[5] >> 16);
+    float e = orc_half_to_float(rec[6] & 0xFFFFu), f = orc_half_to_float(rec[6] >> 16);
+    /* Vrk column-major symmetric */
+    float K[9] = { a, b, c2, b, d, e, c2, e, f };
+    if (s->point_cloud_radius > 0.0f) {
+        float pr = s->point_cloud_radius;
+        if (s->draw_mode > 0u) pr *= ldexpf(1.0f, (int)u->tile_id[0]);
+        K[0] = pr; K[1] = 0; K[2] = 0; K[3] = 0; K[4] = pr; K[5] = 0; K[6] = 0; K[7] = 0; K[8] = pr;
+    }
+    if (s->surface_type > 0u) {
+        /* Vrk = F * Vrk * F^T : (F*K)[c][r] = sum_k F[k][r]*K[c][k]; then * F^T */
+        float FK[9], R[9];
+        for (int cc = 0; cc < 3; cc++)
+            for (int r = 0; r < 3; r++)
+                FK[3 * cc + r] = (F[r] * K[3 * cc] + F[3 + r] * K[3 * cc + 1]) + F[6 + r] * K[3 * cc + 2];
+        /* (FK * F^T)[c][r] = sum_k FK[k][r] * F^T[c][k] = sum_k FK[k][r] * F[k][c] */
+        for (int cc = 0; cc < 3; cc++)
+            for (int r = 0; r < 3; r++)
+                R[3 * cc + r] = (FK[r] * F[cc] + FK[3 + r] * F[3 + cc]) + FK[6 + r] * F[6 + cc];
+        memcpy(K, R, sizeof(K));
+    }
+    for (int cc = 0; cc < 3; cc++)          /* S * Vrk * S^T, S = diag(scene_scale) */
+        for (int r = 0; r < 3; r++)
+            K[3 * cc + r] = (s->scene_scale[r] * K[3 * cc + r]) * s->scene_scale[cc];
+    /* A8 :207-258 */
+    float dd[3] = { c[0] - cam->cam_pos[0], c[1] - cam->cam_pos[1], c[2] - cam->cam_pos[2] };
+    float t[3];
+    for (int r = 0; r < 3; r++) t[r] = (V[r] * dd[0] + V[4 + r] * dd[1]) + V[8 + r] * dd[2];
+    float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    float limx = 1.3f * cam->htan_fov[0], limy = 1.3f * cam->htan_fov[1];
+    t[0] = clampf(txtz, -limx, limx) * t[2];
+    t[1] = clampf(tytz, -limy, limy) * t[2];
+    float tz2 = t[2] * t[2];
+    float j00 = cam->focal[0] / t[2], j02 = -((cam->focal[0] * t[0]) / tz2);
+    float j11 = cam->focal[1] / t[2], j12 = -((cam->focal[1] * t[1]) / tz2);
+    /* T = transpose(view3) * J_T ; T col0 = (dot(view3 col r, J col0))_r etc. */
+    float T0[3], T1[3];
+    for (int r = 0; r < 3; r++) {
+        T0[r] = V[4 * r + 0] * j00 + V[4 * r + 2] * j02;
+        T1[r] = V[4 * r + 1] * j11 + V[4 * r + 2] * j12;
+    }
+    /* A = T^T * Vrk : A[k][r] = dot(T_r, Vrk col k) ; cov2d[c][r] = sum_k A[k][r]*T_c[k] */
+    float A0[3], A1[3];
+    for (int k = 0; k < 3; k++) {
+        A0[k] = (T0[0] * K[3 * k] + T0[1] * K[3 * k + 1]) + T0[2] * K[3 * k + 2];
+        A1[k] = (T1[0] * K[3 * k] + T1[1] * K[3 * k + 1]) + T1[2] * K[3 * k + 2];
+    }
+    float c00 = (A0[0] * T0[0] + A0[1] * T0[1]) + A0[2] * T0[2];
+    float c01 = (A1[0] * T0[0] + A1[1] * T0[1]) + A1[2] * T0[2];   /* cov2d[0][1] */
+    float c11 = (A1[0] * T1[0] + A1[1] * T1[1]) + A1[2] * T1[2];
+    float mid = 0.5f * (c00 + c11);
+    float hx = 0.5f * (c00 - c11);
+    float radius = sqrtf(hx * hx + c01 * c01);
+    float l1 = mid + radius, l2 = mid - radius;
+    if (l2 < 0.0f) return 0;
+    float vx = c01, vy = l1 - c00;
+    float vlen = sqrtf(vx * vx + vy * vy);
+    float ex = vx / vlen, ey = vy / vlen;       /* normalize(): 0/0 -> NaN -> nothing drawn */
+    float smaj = fminf(sqrtf(2.0f * l1), 1024.0f);
+    float smin = fminf(sqrtf(2.0f * l2), 1024.0f);
+    out->major[0] = smaj * ex; out->major[1] = smaj * ey;
+    out->minor[0] = smin * ey; out->minor[1] = smin * -ex;
+    /* A9 :260-265, 402-410 */
+    uint32_t cw = rec[7];
+    out->rgba[0] = (float)(cw & 0xFFu) / 255.0f;
+    out->rgba[1] = (float)((cw >> 8) & 0xFFu) / 255.0f;
+    out->rgba[2] = (float)((cw >> 16) & 0xFFu) / 255.0f;
+    out->rgba[3] = (float)((cw >> 24) & 0xFFu) / 255.0f;
+    if (u->changing == 1u) {
+        if (lod_id != higher_lod) out->rgba[3] = out->rgba[3] * t_ratio;
+        else out->rgba[3] = out->rgba[3] * (1.0f - t_ratio);
+    }
+    float fade = clampf(q[2] / q[3] + 1.0f, 0.0f, 1.0f);
+    for (int k = 0; k < 4; k++) out->rgba[k] = out->rgba[k] * fade;
+    /* A10 :415-419.  Hardware clip keeps 0 <= z <= w with w_out = 1. */
+    out->ndc[0] = q[0] / q[3];
+    out->ndc[1] = q[1] / q[3];
+    out->depth = q[2] / q[3];
+    if (!(out->depth >= 0.0f && out->depth <= 1.0f)) return 0;
+    out->visible = 1;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Fragment stage (fs_main gswt.wgsl:425-435 + blend renderer.rs:118-129 +     */
+/* depth state :179-185), restated analytically.   */
+/*                                                                             */
+/* Canonical sequence "F1..F4" (DESIGN.md).  The +-2 quad is an affine image of */
+/* quad space, w_out = 1, so v_position at a pixel centre is the affine inverse */
+/* evaluated there.  It is evaluated relative to the origin of the 16x16 pixel  */
+/* block containing the pixel (well conditioned, and what the HIP compositor    */
+/* does per screen tile).                                                       */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    float cxp, cyp;       /* pixel-space centre                     */
+    float iux, iuy;       /* quad-x row of the inverse affine map   */
+    float ivx, ivy;       /* quad-y row                             */
+    float hx, hy;         /* conservative half extents in pixels    */
+    int ok;
+} orc_frag_setup;
+
+static void frag_setup(const orc_splat *sp, float splat_scale, float W, float H, orc_frag_setup *fs)
+{
+    /* F1: pixel-space centre */
+    fs->cxp = (0.5f * sp->ndc[0] + 0.5f) * W;
+    fs->cyp = (0.5f - 0.5f * sp->ndc[1]) * H;
+    /* F2: pixel-space image of the unit quad axes (framebuffer y is down) */
+    float hs = 0.5f * splat_scale;
+    float ux = hs * sp->major[0], uy = -(hs * sp->major[1]);
+    float vx = hs * sp->minor[0], vy = -(hs * sp->minor[1]);
+    float uu = ux * ux + uy * uy;
+    float vv = vx * vx + vy * vy;
+    fs->ok = (uu > 0.0f) && (vv > 0.0f) && (uu < INFINITY) && (vv < INFINITY);  /* false for NaN */
+    if (!fs->ok) return;
+    fs->iux = ux / uu; fs->iuy = uy / uu;
+    fs->ivx = vx / vv; fs->ivy = vy / vv;
+    /* conservative extent of |p| <= 2 : |dX| <= 2 sqrt(ux^2 + vx^2) */
+    fs->hx = 2.0f * sqrtf(ux * ux + vx * vx) + 1.0f;
+    fs->hy = 2.0f * sqrtf(uy * uy + vy * vy) + 1.0f;
+}
+
+/* Rasterise one projected splat into rows [y_lo, y_hi) with "over" blending
+ * dst = src + dst * (1 - src.a), back-to-front (renderer.rs:118-129). */
+static void raster_over(const orc_splat *sp, const orc_frag_setup *fs, int W, int H,
+                        int y_lo, int y_hi, const float *bg_depth, float *img)
+{
+    float fx0 = floorf(fs->cxp - fs->hx), fx1 = ceilf(fs->cxp + fs->hx);
+    float fy0 = floorf(fs->cyp - fs->hy), fy1 = ceilf(fs->cyp + fs->hy);
+    if (!(fx1 >= 0.0f) || !(fy1 >= 0.0f) || !(fx0 <= (float)W) || !(fy0 <= (float)H)) return;
+    int x0 = fx0 < 0.0f ? 0 : (int)fx0, x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
+    int y0 = fy0 < (float)y_lo ? y_lo : (int)fy0, y1 = fy1 > (float)(y_hi - 1) ? y_hi - 1 : (int)fy1;
+    for (int by = y0 & ~15; by <= y1; by += 16) {
+        for (int bx = x0 & ~15; bx <= x1; bx += 16) {
+            /* F3: per-block constants */
+            float ox = fs->cxp - (float)bx, oy = fs->cyp - (float)by;
+            float nku = -fmaf(fs->iux, ox, fs->iuy * oy);
+            float nkv = -fmaf(fs->ivx, ox, fs->ivy * oy);
+            int ya = by < y0 ? y0 : by, yb = by + 15 > y1 ? y1 : by + 15;
+            int xa = bx < x0 ? x0 : bx, xb = bx + 15 > x1 ? x1 : bx + 15;
+            for (int y = ya; y <= yb; y++) {
+                float ly = (float)(y - by) + 0.5f;
+                float pu_y = fmaf(fs->iuy, ly, nku);
+                float pv_y = fmaf(fs->ivy, ly, nkv);
+                for (int x = xa; x <= xb; x++) {
+                    /* F4: per-pixel */
+                    float lx = (float)(x - bx) + 0.5f;
+                    float px = fmaf(fs->iux, lx, pu_y);
+                    float py = fmaf(fs->ivx, lx, pv_y);
+                    float r2 = fmaf(py, py, px * px);
+                    if (!(r2 <= 4.0f)) continue;                 /* discard if A < -4 */
+                    /* depth_compare Less against the proxy depth, or the 1.0 clear value */
+                    float dbuf = bg_depth ? bg_depth[(size_t)y * W + x] : 1.0f;
+                    if (!(sp->depth < dbuf)) continue;
+                    float Bv = expf(-r2) * sp->rgba[3];
+                    float om = 1.0f - Bv;
+                    float *dst = img + 4 * ((size_t)y * W + x);
+                    dst[0] = Bv * sp->rgba[0] + dst[0] * om;
+                    dst[1] = Bv * sp->rgba[1] + dst[1] * om;
+                    dst[2] = Bv * sp->rgba[2] + dst[2] * om;
+                    dst[3] = Bv + dst[3] * om;
+                }
+            }
+        }
+    }
+}
+
+/* Render statistics filled by orc_render */
+typedef struct {
+    uint64_t n_instanced;   /* sum of draw counts                */
+    uint64_t n_visible;     /* survivors of the vertex stage     */
+    uint64_t n_pairs16;     /* (splat, 16x16 block) bbox pairs   */
+} orc_stats;
+
+/*
+ * GSWTRenderer::render (renderer.rs:407-592) for an already culled draw list:
+ * colour LoadOp::Load over `bg_rgba` (NULL = transparent black), depth buffer =
+ * `bg_depth` (NULL = cleared to 1.0, which every visible splat passes because
+ * depth <= 1 ... strictly: depth < 1.0 is required, renderer.rs:182), draws in
+ * order, each draw's instances in order.
+ *
+ * order_mode 0 = REFERENCE (draw rank, list position); 1 = DEPTH (all visible
+ * splats stably re-sorted by descending depth before blending).
+ */
+ORC_API int orc_render(const orc_camera *cam, const orc_scene *scene, const uint32_t *tex,
+                       const orc_draw *draws, int n_draws,
+                       const float *hmap, int hm_w, int hm_h,
+                       int W, int H, const float *bg_rgba, const float *bg_depth,
+                       int order_mode, int n_threads, float *out_rgba, orc_stats *stats)
+{
+    if (W <= 0 || H <= 0) return -1;
+    if ((float)W != cam->viewport[0] || (float)H != cam->viewport[1]) return -2;
+    uint64_t n_total = 0;
+    uint64_t *prefix = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n_draws + 1));
+    for (int d = 0; d < n_draws; d++) { prefix[d] = n_total; n_total += draws[d].count; }
+    prefix[n_draws] = n_total;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#endif
+    /* vertex stage for every instance, in draw order */
+    orc_splat *sp = (orc_splat *)malloc(sizeof(orc_splat) * (size_t)(n_total ? n_total : 1));
+    orc_frag_setup *fs = (orc_frag_setup *)malloc(sizeof(orc_frag_setup) * (size_t)(n_total ? n_total : 1));
+    uint64_t n_vis = 0, n_pairs = 0;
+    for (int d = 0; d < n_draws; d++) {
+        const orc_draw *dr = &draws[d];
+        long cnt = (long)dr->count;
+        uint64_t vis_d = 0, pairs_d = 0;
+#pragma omp parallel for schedule(static) reduction(+ : vis_d, pairs_d)
+        for (long j = 0; j < cnt; j++) {
+            uint64_t k = prefix[d] + (uint64_t)j;
+            uint32_t mid = dr->map_id ? dr->map_id[j] : 0u;
+            uint32_t lid = dr->lod_id ? dr->lod_id[j] : 0u;
+            orc_project(cam, scene, &dr->tile, tex, dr->gs_index[j], mid, lid, hmap, hm_w, hm_h, &sp[k]);
+            fs[k].ok = 0;
+            if (sp[k].visible) {
+                frag_setup(&sp[k], scene->splat_scale, (float)W, (float)H, &fs[k]);
+                if (!fs[k].ok) sp[k].visible = 0;
+            }
+            if (sp[k].visible) {
+                vis_d++;
+                float fx0 = floorf(fs[k].cxp - fs[k].hx), fx1 = ceilf(fs[k].cxp + fs[k].hx);
+                float fy0 = floorf(fs[k].cyp - fs[k].hy), fy1 = ceilf(fs[k].cyp + fs[k].hy);
+                if (fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1)) {
+                    int x0 = fx0 < 0 ? 0 : (int)fx0, x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
+                    int y0 = fy0 < 0 ? 0 : (int)fy0, y1 = fy1 > (float)(H - 1) ? H - 1 : (int)fy1;
+                    pairs_d += (uint64_t)((x1 >> 4) - (x0 >> 4) + 1) * (uint64_t)((y1 >> 4) - (y0 >> 4) + 1);
+                }
+            }
+        }
+        n_vis += vis_d; n_pairs += pairs_d;
+    }
+    /* composite order */
+    uint64_t *order = NULL;
+    uint64_t n_order = 0;
+    if (order_mode == 1) {
+        /* stable sort by descending depth (back-to-front); ties keep draw order */
+        order = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n_vis ? n_vis : 1));
+        for (uint64_t k = 0; k < n_total; k++) if (sp[k].visible) order[n_order++] = k;
+        /* bottom-up merge sort, stable */
+        uint64_t *tmp = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n_order ? n_order : 1));
+        for (uint64_t width = 1; width < n_order; width *= 2) {
+            for (uint64_t lo = 0; lo < n_order; lo += 2 * width) {
+                uint64_t mid = lo + width < n_order ? lo + width : n_order;
+                uint64_t hi = lo + 2 * width < n_order ? lo + 2 * width : n_order;
+                uint64_t i = lo, j = mid, o = lo;
+                while (i < mid && j < hi) {
+                    if (sp[order[j]].depth > sp[order[i]].depth) tmp[o++] = order[j++];
+                    else tmp[o++] = order[i++];
+                }
+                while (i < mid) tmp[o++] = order[i++];
+                while (j < hi) tmp[o++] = order[j++];
+            }
+            uint64_t *sw = order; order = tmp; tmp = sw;
+        }
+        free(tmp);
+    }
+    /* framebuffer: LoadOp::Load */
+    size_t npx = (size_t)W * (size_t)H;
+    if (bg_rgba) memcpy(out_rgba, bg_rgba, npx * 16);
+    else memset(out_rgba, 0, npx * 16);
+    /* fragment stage: horizontal bands of 16 rows are independent.  Bin the
+     * ordered visible list per band first (order inside a band is preserved). */
+    if (order_mode != 1) {
+        order = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n_vis ? n_vis : 1));
+        n_order = 0;
+        for (uint64_t k = 0; k < n_total; k++) if (sp[k].visible) order[n_order++] = k;
+    }
+    int n_bands = (H + 15) / 16;
+    uint64_t *band_off = (uint64_t *)calloc((size_t)n_bands + 1, sizeof(uint64_t));
+    for (int pass = 0; pass < 2; pass++) {
+        uint64_t *fill = NULL, *blist = NULL;
+        if (pass == 1) {
+            uint64_t acc = 0;
+            for (int b = 0; b < n_bands; b++) { uint64_t c = band_off[b]; band_off[b] = acc; acc += c; }
+            band_off[n_bands] = acc;
+            blist = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(acc ? acc : 1));
+            fill = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n_bands);
+            memcpy(fill, band_off, sizeof(uint64_t) * (size_t)n_bands);
+        }
+        for (uint64_t i = 0; i < n_order; i++) {
+            uint64_t k = order[i];
+            float fy0 = floorf(fs[k].cyp - fs[k].hy), fy1 = ceilf(fs[k].cyp + fs[k].hy);
+            if (!(fy1 >= 0.0f) || !(fy0 <= (float)H)) continue;
+            int b0 = fy0 < 0.0f ? 0 : ((int)fy0) >> 4;
+            int b1 = fy1 > (float)(H - 1) ? n_bands - 1 : ((int)fy1) >> 4;
+            if (b1 > n_bands - 1) b1 = n_bands - 1;
+            for (int b = b0; b <= b1; b++) {
+                if (pass == 0) band_off[b]++;
+                else blist[fill[b]++] = k;
+            }
+        }
+        if (pass == 1) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int band = 0; band < n_bands; band++) {
+                int y_lo = band * 16, y_hi = y_lo + 16 > H ? H : y_lo + 16;
+                for (uint64_t i = band_off[band]; i < band_off[band + 1]; i++) {
+                    uint64_t k = blist[i];
+                    raster_over(&sp[k], &fs[k], W, H, y_lo, y_hi, bg_depth, out_rgba);
+                }
+            }
+            free(fill); free(blist);
+        }
+    }
+    free(band_off);
+    if (stats) { stats->n_instanced = n_total; stats->n_visible = n_vis; stats->n_pairs16 = n_pairs; }
+    free(order); free(sp); free(fs); free(prefix);
+    return 0;
+}
+
+/* Vertex stage only, for per-splat parity checks: out[k] for every instance. */
+ORC_API int orc_project_draws(const orc_camera *cam, const orc_scene *scene, const uint32_t *tex,
+                              const orc_draw *draws, int n_draws,
+                              const float *hmap, int hm_w, int hm_h, orc_splat *out)
+{
+    uint64_t k = 0;
+    for (int d = 0; d < n_draws; d++) {
+        const orc_draw *dr = &draws[d];
+        for (uint32_t j = 0; j < dr->count; j++, k++) {
+            uint32_t mid = dr->map_id ? dr->map_id[j] : 0u;
+            uint32_t lid = dr->lod_id ? dr->lod_id[j] : 0u;
+            orc_project(cam, scene, &dr->tile, tex, dr->gs_index[j], mid, lid, hmap, hm_w, hm_h, &out[k]);
+        }
+    }
+    return 0;
+}
+
+ORC_API int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* Scene::load, scene.rs:115-212: 62-float PLY vertex records -> 32 B rows     */
+/* sorted by descending importance exp(s0)exp(s1)exp(s2)*sigmoid(opacity).     */
+/* verts: n x 62 f32 = pos3, normal3, f_dc3 + f_rest45, opacity, scale3, rot4  */
+/* (scene.rs:19-26).  Rust `as u8` saturates, NaN -> 0.                         */
+/* ------------------------------------------------------------------------- */
+static inline uint8_t rust_f32_as_u8(float v)
+{
+    if (v != v) return 0;
+    if (v <= 0.0f) return 0;
+    if (v >= 255.0f) return 255;
+    return (uint8_t)v;
+}
+
+typedef struct { float key; uint32_t idx; } orc_imp;
+
+/* stable merge sort, descending key; comparator = partial_cmp(...).unwrap_or(Equal) */
+static void imp_sort(orc_imp *a, orc_imp *tmp, size_t n)
+{
+    for (size_t width = 1; width < n; width *= 2) {
+        for (size_t lo = 0; lo < n; lo += 2 * width) {
+            size_t mid = lo + width < n ? lo + width : n;
+            size_t hi = lo + 2 * width < n ? lo + 2 * width : n;
+            size_t i = lo, j = mid, o = lo;
+            while (i < mid && j < hi) {
+                if (a[j].key > a[i].key) tmp[o++] = a[j++];
+                else tmp[o++] = a[i++];
+            }
+            while (i < mid) tmp[o++] = a[i++];
+            while (j < hi) tmp[o++] = a[j++];
+        }
+        memcpy(a, tmp, n * sizeof(orc_imp));
+    }
+}
+
+ORC_API void orc_scene_load(const float *verts62, size_t n, uint8_t *rows32)
+{
+    const float SH_C0 = 0.28209479177387814f;    /* scene.rs:15 */
+    orc_imp *imp = (orc_imp *)malloc(sizeof(orc_imp) * (n ? n : 1));
+    orc_imp *tmp = (orc_imp *)malloc(sizeof(orc_imp) * (n ? n : 1));
+    for (size_t i = 0; i < n; i++) {
+        const float *s = verts62 + 62 * i;
+        float size = expf(s[55]) * expf(s[56]) * expf(s[57]);       /* :132 */
+        float opacity = 1.0f / (1.0f + expf(-s[54]));               /* :133 */
+        imp[i].key = size * opacity;
+        imp[i].idx = (uint32_t)i;
+    }
+    imp_sort(imp, tmp, n);
+    for (size_t i = 0; i < n; i++) {
+        const float *s = verts62 + 62 * (size_t)imp[i].idx;
+        uint8_t *row = rows32 + 32 * i;
+        float f[6] = { s[0], s[1], s[2], expf(s[55]), expf(s[56]), expf(s[57]) };
+        memcpy(row, f, 24);
+        row[24] = rust_f32_as_u8((0.5f + SH_C0 * s[6]) * 255.0f);   /* :188-191 */
+        row[25] = rust_f32_as_u8((0.5f + SH_C0 * s[7]) * 255.0f);
+        row[26] = rust_f32_as_u8((0.5f + SH_C0 * s[8]) * 255.0f);
+        row[27] = rust_f32_as_u8((1.0f / (1.0f + expf(-s[54]))) * 255.0f);
+        /* powi(2) = x*x ; sum left to right, :199-203 */
+        float qlen = sqrtf(((s[58] * s[58] + s[59] * s[59]) + s[60] * s[60]) + s[61] * s[61]);
+        for (int k = 0; k < 4; k++)
+            row[28 + k] = rust_f32_as_u8(((s[58 + k] / qlen) + 1.0f) * 0.5f * 255.0f);  /* :205-208 */
+    }
+    free(imp); free(tmp);
+}
