@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the GSWT hot path on MI355X (BASELINE.json metric).
+
+A "step" is one frame: gswt_render over the resident draw list of the workload (Wang-tile
+instancing -> projection -> pair emit -> tile sort -> compositing), inputs already in HBM.
+N=1 renders the whole frame on one GPU.  N>1 (launched by torch.distributed.run, one rank per
+GPU) shards the frame by interleaved 16-px screen-tile rows, every rank renders its rows and the
+final framebuffer is all-gathered over RCCL (torch.distributed backend "nccl") and de-interleaved
+on the device; total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line (rank 0) with `roofline` (composite kernel, algorithmic bytes / hipEvent
+time on the kernel's own stream) and, at N=1, `cpu_baseline` (the CPU oracle timed on the host
+cores for one frame of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_workload(name: str, lod0_override: int | None = None):
+    from gswt_renderer_amd import host, synth, workloads
+    w = dict(workloads.WORKLOADS[name])
+    if lod0_override:
+        w["lod0"] = lod0_override
+    verts = synth.make_tileset(n_lod=w["n_lod"], n_tile=16, lod0_count=w["lod0"])
+    ts = host.TileSet.from_vertices(verts)
+    wang = host.WangTile(ts)
+    user = host.user_data(tile_map_half_wh=w["half"], **w["user"])
+    wang.configure(user)
+    cam = workloads.DEFAULT_CAMERA
+    cu, vp = host.camera_uniforms(cam["pos"], cam["target"], cam["up"], cam["fovy"], cam["near"], cam["far"], w["width"], w["height"])
+    wang.build_tiles(cam["pos"])
+    sort = wang.sort_tiles(cam["pos"], vp)
+    return w, wang, cu, vp, sort
+
+
+def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0):
+    """Times the CPU oracle (oracle/gswt_oracle.c, OpenMP) on ONE frame of the same workload."""
+    from oracle import gswt_oracle as orc
+    tex, gi, li = wang.preload()
+    draws = []
+    f32 = np.float32
+    for t, d in zip(sort.tiles, sort.draws):
+        if t.key_len == 1:     # CPU viewport cull, renderer.rs:472-494 (the HIP path does this on the device)
+            c = np.array(t.corners[:], dtype=f32).reshape(4, 3)
+            mx = my = f32(np.finfo(np.float32).max)
+            mz = -mx
+            with np.errstate(all="ignore"):
+                for ci in range(4):
+                    p = orc.mat4_vec(vp, [c[ci, 0], c[ci, 1], c[ci, 2], f32(1.0)])
+                    p = (p[:3] / p[3]).astype(f32)
+                    mx, my, mz = min(mx, abs(p[0])), min(my, abs(p[1])), max(mz, p[2])
+            if mz < -culling_dist or mx > culling_dist or my > culling_dist:
+                continue
+        tu = orc.Tile80.from_buffer_copy(bytes(d.tile))
+        if d.merged:
+            a, b = d.merged_offset, d.merged_offset + d.merged_count
+            draws.append(orc.Draw(tu, sort.merged_gs_index[a:b], sort.merged_map_id[a:b], sort.merged_lod_id[a:b]))
+        else:
+            draws.append(orc.Draw(tu, gi[d.base_lod][d.base_tile][d.base_view], None, li[d.base_lod][d.base_tile][d.base_view]))
+    ocu = orc.Camera176.from_buffer_copy(bytes(cu))
+    osu = orc.Scene160.from_buffer_copy(bytes(su))
+    t0 = time.perf_counter()
+    img, st = orc.render(ocu, osu, tex, draws, W, H)
+    dt = time.perf_counter() - t0
+    return img, st, dt, orc.num_threads()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--lod0", type=int, default=0, help="override LOD0 splats per tile (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--t-eps", type=float, default=1e-5, help="front-to-back early-out threshold")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif n_gpus > 1:
+        raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from gswt_renderer_amd.renderer import GSWTRenderer
+    w, wang, cu, vp, sort = build_workload(args.workload, args.lod0 or None)
+    W, H = w["width"], w["height"]
+    r = GSWTRenderer(local_rank)                       # raises when libgswt_hip.so / the GPU is missing
+    stream = torch.cuda.Stream(device=dev)
+    r.set_stream(stream.cuda_stream)                    # kernels, hipEvents and the all-gather share this stream
+    wang.upload_to(r)
+    r.configure(None)
+    r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
+    su = wang.scene_uniforms()
+    shard = (rank, world) if world > 1 else (0, 1)
+    rows = r.shard_rows_padded(H, world) if world > 1 else H
+    out = torch.empty((rows, W, 4), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * rows, W, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if world > 1 else out
+
+    comp_ms, total_ms, pairs = [], [], []
+
+    def step():
+        with torch.cuda.stream(stream):
+            r.render(cu, su, W, H, transmittance_eps=args.t_eps, shard=shard, out_device_ptr=out.data_ptr())
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, out)
+                r.unshard(gathered.data_ptr(), W, H, world, frame.data_ptr())
+        t = r.timings()
+        comp_ms.append(t["ms_composite"]); total_ms.append(t["ms_total"]); pairs.append(t["n_pairs"])
+        return t
+
+    for _ in range(args.warmup):
+        step()
+    comp_ms.clear(); total_ms.clear(); pairs.clear()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        fps = args.steps / dt
+        P = float(np.mean(pairs))
+        comp = float(np.mean(comp_ms)) * 1e-3
+        n_px = (rows if world > 1 else H) * W
+        algo_bytes = 52.0 * P + 16.0 * n_px                     # (4 + 48) B per pair + 16 B per pixel
+        achieved = algo_bytes / comp / 1e9 if comp > 0 else 0.0
+        res = {
+            "metric": "frames/sec @1920x1080, 32x32 Wang-tile grid" if args.workload == "c3" else f"frames/sec ({args.workload})",
+            "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['desc']}", "map": [2 * w["half"][0] + 1, 2 * w["half"][1] + 1],
+                       "width": W, "height": H, "n_draws": int(last["n_draws"]), "n_instanced": int(last["n_instanced"]),
+                       "n_visible": int(last["n_visible"]), "n_pairs": int(last["n_pairs"]), "order": "reference",
+                       "transmittance_eps": args.t_eps,
+                       "parallelism": f"screen-tile-rows x{world} + RCCL all-gather" if world > 1 else "single GPU"},
+            "stage_ms": {k: float(last[k]) for k in ("ms_project", "ms_scan", "ms_emit", "ms_sort", "ms_ranges", "ms_composite", "ms_total")},
+            "roofline": {"bound": "hbm", "kernel": "k_composite", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": comp * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            img_cpu, st, cdt, nthr = cpu_baseline(wang, sort, cu, vp, su, W, H)
+            gpu_img = out.cpu().numpy()
+            res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": nthr, "kind": "port",
+                                   "sample": "1 frame of the same workload (oracle/gswt_oracle.c, OpenMP over 16-row bands)",
+                                   "max_abs_diff_vs_gpu": float(np.max(np.abs(gpu_img.astype(np.float64) - img_cpu.astype(np.float64))))}
+        print(json.dumps(res), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,45 @@
+"""BASELINE.json workload configurations (synthetic, seeded; SURVEY.md 8d / BASELINE.md 3).
+
+Each entry fixes the Wang-tile map, the per-tile splat budget, the render target and the
+UserData the reference's GUI would produce.  `c3` is the configuration BASELINE.json's metric
+is quoted on (32x32 grid -> nearest reference-valid map 33x33, ~10 M instanced Gaussians,
+1920x1080, LOD blending + selective merging on).
+"""
+from __future__ import annotations
+
+from . import host
+
+# lod_max_dist: the GUI default is 96 * tile_width on a 97x97 map (structure.rs:121-137,198-199).
+# For c3 it is 64 * tile_width so that the instanced count stays ~10 M (as BASELINE.json states)
+# while the LOD1 / LOD2 rings and their blending bands are present inside the 33x33 map.
+WORKLOADS = {
+    "c1": dict(desc="1x1 map, ~50k Gaussians, 640x480 (reference CPU-runnable plumbing case)",
+               half=(0, 0), lod0=50000, n_lod=3, width=640, height=480,
+               user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_DISTANCE, merge_type=host.MERGE_EDGE,
+                         lod_max_dist=96.0 * 4.0)),
+    "c2": dict(desc="5x5 map (4x4 grid nearest valid), ~1M instanced Gaussians, 1280x720, LOD off",
+               half=(2, 2), lod0=62500, n_lod=1, width=1280, height=720,
+               user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
+                         lod_blending=False, lod_max_dist=96.0 * 4.0)),
+    "c3": dict(desc="33x33 map (32x32 grid nearest valid), ~10M instanced Gaussians, 1920x1080, LOD blending + Edge merging",
+               half=(16, 16), lod0=9800, n_lod=3, width=1920, height=1080,
+               user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
+                         lod_blending=True, lod_transition_width_ratio=0.05, merge_topk=100, merge_dot_threshold=0.2,
+                         lod_max_dist=64.0 * 4.0)),
+    "c5": dict(desc="129x129 map (128x128 grid nearest valid), ~100M instanced Gaussians, 3840x2160, full LOD",
+               half=(64, 64), lod0=6100, n_lod=3, width=3840, height=2160,
+               user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
+                         lod_blending=True, lod_transition_width_ratio=0.05, merge_topk=100, merge_dot_threshold=0.2,
+                         lod_max_dist=256.0 * 4.0)),
+    # small variant for smoke tests
+    "tiny": dict(desc="7x7 map, 3 LODs, 320x240", half=(3, 3), lod0=600, n_lod=3, width=320, height=240,
+                 user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
+                           lod_max_dist=20.0)),
+}
+
+DEFAULT_CAMERA = dict(pos=(0.0, 0.0, 5.0), target=(0.0, 1.0, 5.0), up=(0.0, 0.0, 1.0), fovy=45.0, near=0.1, far=2400.0)  # state.rs:114-122
+
+
+def user_data_for(name: str) -> host.UserData:
+    w = WORKLOADS[name]
+    return host.user_data(tile_map_half_wh=w["half"], **w["user"])

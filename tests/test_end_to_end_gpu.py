@@ -62,7 +62,7 @@ def test_graph_edge_none_surface(renderer):
     cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
     img, ref, kinds, st = _run_case(renderer, cfg, ((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)), 384, 256)
     assert kinds["plain"] > 0 and kinds["blend"] > 0 and kinds["merged"] > 0, kinds
-    assert st["n_visible"] > 2000
+    assert st["n_visible"] > 500
     assert H.max_abs_diff(img, ref) <= TOL
 
 
@@ -70,7 +70,7 @@ def test_heightmap_surface_with_background_and_depth(renderer):
     cfg = dict(tile_map_half_wh=(3, 4), surface_type=1, lod_max_dist=24.0, tile_sort_type=3, merge_type=2,
                height_map_wh=(4, 4), height_map_scale=(1.0, 1.0, 0.3))
     img, ref, kinds, st = _run_case(renderer, cfg, ((0.5, 0.3, 5.0), (1.0, 1.0, 4.5)), 320, 240, bg=True)
-    assert st["n_visible"] > 1000
+    assert st["n_visible"] > 300
     assert H.max_abs_diff(img, ref) <= TOL
 
 
