@@ -21,6 +21,7 @@ GSWT_ORDER_REFERENCE = 0
 GSWT_ORDER_DEPTH = 1
 GSWT_OPT_NO_LOD_PREFILTER = 1
 GSWT_OPT_DEBUG_VARYINGS = 2
+GSWT_OPT_TILE_MAP = 3
 
 
 class CameraUniforms(C.Structure):
@@ -94,6 +95,7 @@ SYMBOLS = {
     "gswt_synchronize": (C.c_int, [_P]),
     "gswt_last_timings": (C.c_int, [_P, _P]),
     "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gswt_debug_read_ranges": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
 }
 
 _lib = None

@@ -27,7 +27,7 @@ void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uin
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, uint32_t*, uint32_t*);
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, int, uint32_t*, uint32_t*, uint32_t*);
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, uint2*, uint32_t);
-void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int);
+void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int, int);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
 }  // namespace gswt
 
@@ -92,6 +92,8 @@ struct gswt_ctx {
     // options
     int opt_no_prefilter = 0;
     int opt_debug_varyings = 0;
+    int opt_tile_map = 0;   // measured on MI355X, c3: identity 1.06 ms, XCD bands 2.14 ms, rows round-robin 1.27 ms
+    uint32_t last_n_tiles = 0;
     // timing
     hipEvent_t ev[8] = {};
     gswt_timings timings = {};
@@ -183,6 +185,7 @@ int gswt_set_option(gswt_ctx* c, int key, int value)
     switch (key) {
     case GSWT_OPT_NO_LOD_PREFILTER: c->opt_no_prefilter = value; c->draws_ready = false; return GSWT_OK;
     case GSWT_OPT_DEBUG_VARYINGS: c->opt_debug_varyings = value; return GSWT_OK;
+    case GSWT_OPT_TILE_MAP: c->opt_tile_map = value; return GSWT_OK;
     default: return fail(c, GSWT_ERR_BAD_ARG, "unknown option %d", key);
     }
 }
@@ -464,7 +467,8 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     launch_ranges(s, keys_sorted, P, c->ranges.p, (uint32_t)n_tiles);
     HIP_TRY(c, hipEventRecord(c->ev[5], s));
     // ---- composite
-    launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows);
+    launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows, c->opt_tile_map);
+    c->last_n_tiles = (uint32_t)n_tiles;
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     HIP_TRY(c, hipGetLastError());
     if (!out_on_device) HIP_TRY(c, hipMemcpyAsync(out_rgba, d_out, out_px * 16, hipMemcpyDeviceToHost, s));
@@ -505,6 +509,18 @@ int gswt_last_timings(const gswt_ctx* c, gswt_timings* out)
 {
     if (!c || !out) return GSWT_ERR_BAD_ARG;
     *out = c->timings;
+    return GSWT_OK;
+}
+
+int gswt_debug_read_ranges(gswt_ctx* c, uint32_t* out, size_t capacity_tiles, size_t* n_tiles)
+{
+    if (!c || !n_tiles) return GSWT_ERR_BAD_ARG;
+    *n_tiles = c->last_n_tiles;
+    if (!out) return GSWT_OK;
+    if (capacity_tiles < c->last_n_tiles) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu tiles, need %u", capacity_tiles, c->last_n_tiles);
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->ranges.p, (size_t)c->last_n_tiles * 8, hipMemcpyDeviceToHost));
     return GSWT_OK;
 }
 

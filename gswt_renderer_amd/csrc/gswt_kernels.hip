@@ -530,14 +530,24 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
                                                    const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
-                                                   float4* __restrict__ out, int n_tiles, int out_rows)
+                                                   float4* __restrict__ out, int n_tiles, int out_rows, int tile_map)
 {
     __shared__ float4 s_q0[256], s_q1[256], s_q2[256];
-    // XCD-aware mapping: workgroups b, b+8, b+16.. share an XCD (round-robin dispatch), give
-    // each XCD a contiguous band of screen tiles so neighbouring tiles share the XCD's L2.
+    // workgroup -> screen tile.  Workgroups b, b+8, b+16.. share an XCD (round-robin dispatch).
+    //   0: identity            1: contiguous band of tiles per XCD
+    //   2: tile rows dealt round-robin to XCDs (row r -> XCD r % 8): a row's neighbours share the
+    //      XCD's L2 while the heavy horizon rows spread over all eight XCDs
     const int nb = (int)gridDim.x;
-    const int per_xcd = (nb + 7) / 8;
-    int tile = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+    int tile = (int)blockIdx.x;
+    if (tile_map == 1) {
+        const int per_xcd = (nb + 7) / 8;
+        tile = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
+    } else if (tile_map == 2) {
+        const int xcd = (int)blockIdx.x % 8, i = (int)blockIdx.x / 8;     // i-th workgroup of this XCD
+        const int rows_local = (n_tiles + f.tiles_x - 1) / f.tiles_x;
+        const int row = (i / f.tiles_x) * 8 + xcd, col = i % f.tiles_x;
+        tile = row < rows_local ? row * f.tiles_x + col : n_tiles;
+    }
     if (tile >= n_tiles) return;
     const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
@@ -683,11 +693,15 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n, uint2* range
 }
 
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
-                      const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows)
+                      const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows, int tile_map)
 {
     if (n_tiles == 0) return;
     int grid = ((n_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, s, f, ranges, vals, recs, bg_rgba, bg_depth, out, n_tiles, out_rows);
+    if (tile_map == 2) {
+        const int rows_local = (n_tiles + f.tiles_x - 1) / f.tiles_x;
+        grid = ((rows_local + 7) / 8) * f.tiles_x * 8;
+    }
+    hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, s, f, ranges, vals, recs, bg_rgba, bg_depth, out, n_tiles, out_rows, tile_map);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded)

@@ -271,8 +271,8 @@ class WangTile:
         """WangTile::new (takes ownership of the tile set) -> preprocess."""
         lib = load()
         h = C.c_void_p()
-        _check(lib.gswt_wang_new(tileset._h, C.byref(h)))
-        tileset._h = None
+        th, tileset._h = tileset._h, None      # gswt_wang_new consumes the tile set, also when it fails
+        _check(lib.gswt_wang_new(th, C.byref(h)))
         self._h = h
         self._lib = lib
         self.user = None

@@ -167,3 +167,11 @@ class GSWTRenderer:
         out = np.zeros(max(1, n.value), dtype=self.VARYINGS_DTYPE)
         self._check(self._lib.gswt_debug_read_projected(self._h, _ptr(out), out.shape[0], C.byref(n)))
         return out[:n.value]
+
+    def read_ranges(self) -> np.ndarray:
+        """[n_tiles, 2] (start, end) of each screen tile's slice of the sorted pair list."""
+        n = C.c_size_t(0)
+        self._check(self._lib.gswt_debug_read_ranges(self._h, None, 0, C.byref(n)))
+        out = np.zeros((max(1, n.value), 2), dtype=np.uint32)
+        self._check(self._lib.gswt_debug_read_ranges(self._h, _ptr(out), out.shape[0], C.byref(n)))
+        return out[:n.value]

@@ -156,7 +156,8 @@ GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
  *   reference binds it (renderer.rs:571-578) instead of the pre-filtered own-LOD list; results
  *   are identical (gswt.wgsl:38-42 discards the other LOD), only the entry count differs.
  * DEBUG_VARYINGS: keep vs_main's per-entry outputs for gswt_debug_read_projected. */
-enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2 };
+enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
+       GSWT_OPT_TILE_MAP = 3 /* compositor workgroup -> screen tile mapping, 0/1/2 (profiling) */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data
@@ -206,6 +207,10 @@ GSWT_API int gswt_last_timings(const gswt_ctx *ctx, gswt_timings *out);
  * minor.xy, rgba) -- the varyings of vs_main (gswt.wgsl:4-8,412-419). Host pointer. */
 GSWT_API int gswt_debug_read_projected(gswt_ctx *ctx, void *out, size_t capacity_entries,
                                        size_t *n_entries);
+
+/* Test / profiling hook: [start, end) of every screen tile in the sorted pair list of the last
+ * gswt_render (2 u32 per tile, shard-local tile order). Host pointer. */
+GSWT_API int gswt_debug_read_ranges(gswt_ctx *ctx, uint32_t *out, size_t capacity_tiles, size_t *n_tiles);
 
 #ifdef __cplusplus
 }

@@ -144,7 +144,8 @@ typedef struct {
     const gswt_base_list *lists;      /* [n_lod][n_tile][n_view] */
 } gswt_preload;
 
-/* WangTile::new (wangtile.rs:41-69): takes ownership of the tile set, runs preprocess. */
+/* WangTile::new (wangtile.rs:41-69): takes ownership of the tile set (also on failure: the tile
+ * set is destroyed either way), runs preprocess. */
 GSWT_API int gswt_wang_new(gswt_tileset *ts, gswt_wang **out);
 GSWT_API void gswt_wang_destroy(gswt_wang *w);
 /* WangTile::preload (wangtile.rs:340-347) */
