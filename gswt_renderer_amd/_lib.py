@@ -21,7 +21,7 @@ GSWT_ORDER_REFERENCE = 0
 GSWT_ORDER_DEPTH = 1
 GSWT_OPT_NO_LOD_PREFILTER = 1
 GSWT_OPT_DEBUG_VARYINGS = 2
-GSWT_OPT_TILE_MAP = 3
+GSWT_OPT_SEGMENT = 3
 
 
 class CameraUniforms(C.Structure):

@@ -27,7 +27,8 @@ void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uin
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, uint32_t*, uint32_t*);
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, int, uint32_t*, uint32_t*, uint32_t*);
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, uint2*, uint32_t);
-void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int, int);
+void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int,
+                      uint32_t, uint32_t, uint32_t*, uint32_t*, float4*);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
 }  // namespace gswt
 
@@ -85,6 +86,8 @@ struct gswt_ctx {
     DevBuf<Rec> recs;
     DevBuf<uint32_t> block_sums, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
     DevBuf<uint2> ranges;
+    DevBuf<uint32_t> item_base;
+    DevBuf<float4> partials;
     DevBuf<unsigned long long> counters;   // [0] visible, [1] (u32) total pairs, [2] scratch
     DevBuf<float4> bg_rgba, out_img;
     DevBuf<float> bg_depth;
@@ -92,7 +95,7 @@ struct gswt_ctx {
     // options
     int opt_no_prefilter = 0;
     int opt_debug_varyings = 0;
-    int opt_tile_map = 0;   // measured on MI355X, c3: identity 1.06 ms, XCD bands 2.14 ms, rows round-robin 1.27 ms
+    int opt_segment = 1024;  // pairs per compositor work item (multiple of 256)
     uint32_t last_n_tiles = 0;
     // timing
     hipEvent_t ev[8] = {};
@@ -160,7 +163,7 @@ void gswt_destroy(gswt_ctx* c)
     c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release();
     c->merged_list.release(); c->merged_map.release(); c->rects.release(); c->recs.release(); c->block_sums.release();
     c->scan_ws.release(); c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release();
-    c->ghist.release(); c->ranges.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
+    c->ghist.release(); c->ranges.release(); c->item_base.release(); c->partials.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
     c->bg_depth.release(); c->dbg.release();
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -185,7 +188,9 @@ int gswt_set_option(gswt_ctx* c, int key, int value)
     switch (key) {
     case GSWT_OPT_NO_LOD_PREFILTER: c->opt_no_prefilter = value; c->draws_ready = false; return GSWT_OK;
     case GSWT_OPT_DEBUG_VARYINGS: c->opt_debug_varyings = value; return GSWT_OK;
-    case GSWT_OPT_TILE_MAP: c->opt_tile_map = value; return GSWT_OK;
+    case GSWT_OPT_SEGMENT:
+        if (value < 256 || value % 256) return fail(c, GSWT_ERR_BAD_ARG, "segment must be a positive multiple of 256");
+        c->opt_segment = value; return GSWT_OK;
     default: return fail(c, GSWT_ERR_BAD_ARG, "unknown option %d", key);
     }
 }
@@ -467,7 +472,14 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     launch_ranges(s, keys_sorted, P, c->ranges.p, (uint32_t)n_tiles);
     HIP_TRY(c, hipEventRecord(c->ev[5], s));
     // ---- composite
-    launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows, c->opt_tile_map);
+    {
+        const uint32_t seg = (uint32_t)c->opt_segment;
+        const size_t max_items = (size_t)n_tiles + P / seg + 1;
+        HIP_TRY(c, c->item_base.ensure((size_t)n_tiles + 2));
+        HIP_TRY(c, c->partials.ensure(max_items * 256));
+        launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows, seg, P,
+                         c->item_base.p, c->scan_ws.p, c->partials.p);
+    }
     c->last_n_tiles = (uint32_t)n_tiles;
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     HIP_TRY(c, hipGetLastError());

@@ -59,11 +59,13 @@ struct Frame {
 };
 
 // Projected splat record consumed by the compositor (48 B, three 16-B words).
-//   q0 = (iux, iuy, cxp, alpha)   q1 = (ivx, ivy, cyp, depth)   q2 = (r, g, b, 0)
+//   q0 = (iux, iuy, cxp, alpha)   q1 = (ivx, ivy, cyp, depth)   q2 = (rgba8 bits, hx, hy, 0)
+// iu / iv: rows of the inverse affine map pixel -> quad space (F2); (cxp, cyp): pixel-space centre (F1);
+// (hx, hy): conservative pixel half extents of |p| <= 2.
 struct __attribute__((aligned(16))) Rec {
     float iux, iuy, cxp, alpha;
     float ivx, ivy, cyp, depth;
-    float r, g, b, pad;
+    float rgba8, hx, hy, pad;
 };
 
 // vs_main varyings for the debug/parity hook (48 B, same layout as the oracle's orc_splat)

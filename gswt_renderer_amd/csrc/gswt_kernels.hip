@@ -292,11 +292,7 @@ __global__ __launch_bounds__(256) void k_project(
             visible = true;
             // depth_compare Less against the 1.0 clear when no proxy depth is bound (renderer.rs:182,436)
             if (!f.has_depth && !(depth < 1.0f)) { visible = false; break; }
-            Rec rec;
-            rec.iux = ux / uu; rec.iuy = uy / uu;
-            rec.ivx = wx / ww; rec.ivy = wy / ww;
-            rec.cxp = cxp; rec.cyp = cyp; rec.alpha = ca; rec.depth = depth;
-            rec.r = cr; rec.g = cg; rec.b = cb; rec.pad = 0.0f;
+            const float r_iux = ux / uu, r_iuy = uy / uu, r_ivx = wx / ww, r_ivy = wy / ww;
             float hx = 2.0f * sqrtf(ux * ux + wx * wx) + 1.0f;
             float hy = 2.0f * sqrtf(uy * uy + wy * wy) + 1.0f;
             float fx0 = floorf(cxp - hx), fx1 = ceilf(cxp + hx);
@@ -309,10 +305,12 @@ __global__ __launch_bounds__(256) void k_project(
                 count = (uint32_t)((tx1 - tx0 + 1) * rows);
                 if (count) {
                     rects[slot] = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
+                    // colour stays packed (bytes / 255 is re-evaluated by the compositor's staging lane, same
+                    // correctly rounded division); the two freed words carry the pixel half extents
                     Rec* dst = recs + slot;
-                    reinterpret_cast<float4*>(dst)[0] = make_float4(rec.iux, rec.iuy, rec.cxp, rec.alpha);
-                    reinterpret_cast<float4*>(dst)[1] = make_float4(rec.ivx, rec.ivy, rec.cyp, rec.depth);
-                    reinterpret_cast<float4*>(dst)[2] = make_float4(rec.r, rec.g, rec.b, 0.0f);
+                    reinterpret_cast<float4*>(dst)[0] = make_float4(r_iux, r_iuy, cxp, ca);
+                    reinterpret_cast<float4*>(dst)[1] = make_float4(r_ivx, r_ivy, cyp, depth);
+                    reinterpret_cast<float4*>(dst)[2] = make_float4(__uint_as_float(w1.w), hx, hy, 0.0f);
                 }
             }
         } while (0);
@@ -522,83 +520,130 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 }
 
 // ------------------------------------------------------------------------------------
-// k_composite v1: one workgroup (4 waves) per 16x16 screen tile, one pixel per lane.
-// Batches of 256 pairs are staged through LDS (12 KB), each lane evaluating the canonical
-// per-pixel sequence F3/F4 of DESIGN.md; a wave stops reading when the ballot of
-// "transmittance still above eps" is empty, the workgroup when all four waves have.
+// k_composite: one workgroup (4 wave64) per 16x16 screen tile; wave w owns the 8x8 pixel quadrant
+// (w & 1, w >> 1), one pixel per lane.  Batches of 256 pairs are staged through LDS (16 KB): the
+// staging lane gathers the 48-B record, unpacks the colour and evaluates the per-(splat, tile)
+// constants F3.  Each wave then ballots the batch down to the records whose pixel bounding box
+// touches ITS quadrant and walks only those (scalar bit loop, LDS broadcast reads), evaluating the
+// canonical per-pixel sequence F4.  A wave stops when the ballot of "transmittance >= eps" is
+// empty, the workgroup when all four waves have.
 // ------------------------------------------------------------------------------------
+// Work items: a tile's pair list is cut into segments of `seg` pairs; item = (tile, segment).
+// seg_count[t] = max(1, ceil(len / seg)) so empty tiles still get one item (they write the background).
+__global__ __launch_bounds__(256) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
+                                               uint32_t* __restrict__ seg_count)
+{
+    int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint2 r = ranges[t];
+    uint32_t len = r.y - r.x;
+    seg_count[t] = len == 0 ? 1u : (len + seg - 1u) / seg;
+}
+
 __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
+                                                   const uint32_t* __restrict__ item_base, uint32_t seg,
                                                    const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
                                                    const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
-                                                   float4* __restrict__ out, int n_tiles, int out_rows, int tile_map)
+                                                   float4* __restrict__ out, float4* __restrict__ partials,
+                                                   int n_tiles, int out_rows)
 {
-    __shared__ float4 s_q0[256], s_q1[256], s_q2[256];
-    // workgroup -> screen tile.  Workgroups b, b+8, b+16.. share an XCD (round-robin dispatch).
-    //   0: identity            1: contiguous band of tiles per XCD
-    //   2: tile rows dealt round-robin to XCDs (row r -> XCD r % 8): a row's neighbours share the
-    //      XCD's L2 while the heavy horizon rows spread over all eight XCDs
-    const int nb = (int)gridDim.x;
-    int tile = (int)blockIdx.x;
-    if (tile_map == 1) {
-        const int per_xcd = (nb + 7) / 8;
-        tile = ((int)blockIdx.x % 8) * per_xcd + (int)blockIdx.x / 8;
-    } else if (tile_map == 2) {
-        const int xcd = (int)blockIdx.x % 8, i = (int)blockIdx.x / 8;     // i-th workgroup of this XCD
-        const int rows_local = (n_tiles + f.tiles_x - 1) / f.tiles_x;
-        const int row = (i / f.tiles_x) * 8 + xcd, col = i % f.tiles_x;
-        tile = row < rows_local ? row * f.tiles_x + col : n_tiles;
+    __shared__ float4 s_q0[256], s_q1[256], s_q2[256], s_q3[256];
+    // work item -> (tile, segment): item_base is the exclusive scan of per-tile segment counts
+    // (item_base[n_tiles] = number of items).  Consecutive items are dealt round-robin over the
+    // 8 XCDs by the dispatcher, which balances the skewed tile-list lengths.
+    const uint32_t item = blockIdx.x;
+    if (item >= item_base[n_tiles]) return;
+    int lo = 0, hi = n_tiles;                       // largest t with item_base[t] <= item
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (item_base[mid] <= item) lo = mid; else hi = mid;
     }
-    if (tile >= n_tiles) return;
+    const int tile = lo;
+    const uint32_t seg_idx = item - item_base[tile];
+    const uint32_t n_seg = item_base[tile + 1] - item_base[tile];
     const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
     const int bx = tx * kTile, by = ty * kTile;
-    const int lxi = threadIdx.x & 15, lyi = threadIdx.x >> 4;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const int qx = (int)(wave & 1u) * 8, qy = (int)(wave >> 1) * 8;
+    const int lxi = qx + (int)(lane & 7u), lyi = qy + (int)(lane >> 3);
     const int px = bx + lxi, py = by + lyi;
     const bool inside = px < f.width && py < f.height;
     const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
     const float fbx = (float)bx, fby = (float)by;
-    const uint2 rg = ranges[tile];
+    const float qx0 = (float)qx, qx1 = (float)(qx + 8), qy0 = (float)qy, qy1 = (float)(qy + 8);
+    uint2 rg = ranges[tile];
+    rg.x += seg_idx * seg;
+    rg.y = min(rg.y, rg.x + seg);
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
     float dbuf = 1.0f;
     if (inside && f.has_depth) dbuf = bg_depth[(size_t)py * f.width + px];
     bool done = !inside;
     for (uint32_t base = rg.x; base < rg.y; base += 256u) {
         const uint32_t n = min(256u, rg.y - base);
-        if (threadIdx.x < n) {
-            const uint32_t slot = vals[base + threadIdx.x];
+        if (tid < n) {
+            const uint32_t slot = vals[base + tid];
             const float4* rp = reinterpret_cast<const float4*>(recs + slot);
-            float4 a = rp[0], b = rp[1], c = rp[2];
+            const float4 a = rp[0], b = rp[1], c = rp[2];
             // F3: per-(splat, tile) constants
-            float ox = a.z - fbx, oy = b.z - fby;
-            float nku = -fmaf(a.x, ox, a.y * oy);
-            float nkv = -fmaf(b.x, ox, b.y * oy);
-            s_q0[threadIdx.x] = make_float4(a.x, a.y, nku, a.w);
-            s_q1[threadIdx.x] = make_float4(b.x, b.y, nkv, b.w);
-            s_q2[threadIdx.x] = c;
+            const float ox = a.z - fbx, oy = b.z - fby;
+            const float nku = -fmaf(a.x, ox, a.y * oy);
+            const float nkv = -fmaf(b.x, ox, b.y * oy);
+            const uint32_t cw = __float_as_uint(c.x);
+            s_q0[tid] = make_float4(a.x, a.y, nku, a.w);
+            s_q1[tid] = make_float4(b.x, b.y, nkv, b.w);
+            s_q2[tid] = make_float4((float)(cw & 0xFFu) / 255.0f, (float)((cw >> 8) & 0xFFu) / 255.0f,
+                                    (float)((cw >> 16) & 0xFFu) / 255.0f, 0.0f);
+            s_q3[tid] = make_float4(ox - c.y, ox + c.y, oy - c.z, oy + c.z);     // pixel bbox, tile-local
         }
         __syncthreads();
-        for (uint32_t k = 0; k < n; k++) {
-            const float4 q0 = s_q0[k], q1 = s_q1[k];
-            // F4: per-pixel
-            float pu_y = fmaf(q0.y, ly, q0.z);
-            float pv_y = fmaf(q1.y, ly, q1.z);
-            float ppx = fmaf(q0.x, lx, pu_y);
-            float ppy = fmaf(q1.x, lx, pv_y);
-            float r2 = fmaf(ppy, ppy, ppx * ppx);
-            if (!done && r2 <= 4.0f && q1.w < dbuf) {
-                float Bv = __builtin_amdgcn_exp2f(r2 * -1.4426950408889634f) * q0.w;
-                float wgt = T * Bv;
-                const float4 q2 = s_q2[k];
-                ar = fmaf(wgt, q2.x, ar);
-                ag = fmaf(wgt, q2.y, ag);
-                ab = fmaf(wgt, q2.z, ab);
-                T = T - wgt;
-                done = T < f.t_eps;
+        if (__ballot(!done) != 0ull) {
+            // which staged records can touch this wave's quadrant
+            unsigned long long m[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t idx = (uint32_t)c * 64u + lane;
+                bool hit = false;
+                if (idx < n) {
+                    const float4 bb = s_q3[idx];
+                    hit = bb.y >= qx0 && bb.x <= qx1 && bb.w >= qy0 && bb.z <= qy1;
+                }
+                m[c] = __ballot(hit);
             }
-            if (__ballot(!done) == 0ull) break;   // whole wave saturated
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                unsigned long long mask = m[c];
+                while (mask) {
+                    const uint32_t k = (uint32_t)c * 64u + (uint32_t)__builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    const float4 q0 = s_q0[k], q1 = s_q1[k];
+                    // F4: per-pixel
+                    const float pu_y = fmaf(q0.y, ly, q0.z);
+                    const float pv_y = fmaf(q1.y, ly, q1.z);
+                    const float ppx = fmaf(q0.x, lx, pu_y);
+                    const float ppy = fmaf(q1.x, lx, pv_y);
+                    const float r2 = fmaf(ppy, ppy, ppx * ppx);
+                    if (!done && r2 <= 4.0f && q1.w < dbuf) {
+                        const float Bv = __builtin_amdgcn_exp2f(r2 * -1.4426950408889634f) * q0.w;
+                        const float wgt = T * Bv;
+                        const float4 q2 = s_q2[k];
+                        ar = fmaf(wgt, q2.x, ar);
+                        ag = fmaf(wgt, q2.y, ag);
+                        ab = fmaf(wgt, q2.z, ab);
+                        T = T - wgt;
+                        done = T < f.t_eps;
+                    }
+                    if (__ballot(!done) == 0ull) { mask = 0ull; m[1] = m[2] = m[3] = 0ull; }   // whole wave saturated
+                }
+            }
         }
         if (__syncthreads_and(done ? 1 : 0)) break;
+    }
+    if (n_seg > 1u) {
+        // partial (C, T) of this segment; k_combine folds the segments front to back
+        partials[(size_t)item * 256u + tid] = make_float4(ar, ag, ab, T);
+        return;
     }
     if (inside) {
         float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -611,6 +656,41 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
         const int orow = tyl * kTile + lyi;      // compacted row inside the shard image
         if (orow < out_rows) out[(size_t)orow * f.width + px] = o;
     }
+}
+
+// Folds the per-segment partials of multi-segment tiles: (C1,T1) o (C2,T2) = (C1 + T1*C2, T1*T2).
+// One workgroup per tile, same lane -> pixel mapping as k_composite.
+__global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* __restrict__ item_base,
+                                                 const float4* __restrict__ partials, const float4* __restrict__ bg_rgba,
+                                                 float4* __restrict__ out, int n_tiles, int out_rows)
+{
+    const int tile = blockIdx.x;
+    const uint32_t i0 = item_base[tile], n_seg = item_base[tile + 1] - i0;
+    if (n_seg <= 1u) return;
+    const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
+    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
+    const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const int lxi = (int)(wave & 1u) * 8 + (int)(lane & 7u), lyi = (int)(wave >> 1) * 8 + (int)(lane >> 3);
+    const int px = tx * kTile + lxi, py = ty * kTile + lyi;
+    if (px >= f.width || py >= f.height) return;
+    float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
+        const float4 p = partials[(size_t)(i0 + sidx) * 256u + tid];
+        ar = fmaf(T, p.x, ar);
+        ag = fmaf(T, p.y, ag);
+        ab = fmaf(T, p.z, ab);
+        T = T * p.w;
+    }
+    float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bg_rgba) bg = bg_rgba[(size_t)py * f.width + px];
+    float4 o;
+    o.x = fmaf(T, bg.x, ar);
+    o.y = fmaf(T, bg.y, ag);
+    o.z = fmaf(T, bg.z, ab);
+    o.w = fmaf(T, bg.w, 1.0f - T);
+    const int orow = tyl * kTile + lyi;
+    if (orow < out_rows) out[(size_t)orow * f.width + px] = o;
 }
 
 // Zero-fill helper for shard padding rows / unshard scatter
@@ -692,16 +772,19 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n, uint2* range
     hipLaunchKernelGGL(k_ranges, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, ranges);
 }
 
+// ranges -> per-tile segment counts -> item_base (exclusive scan, item_base[n_tiles] = #items) ->
+// k_composite over an upper bound of items -> k_combine.
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
-                      const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows, int tile_map)
+                      const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
+                      uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint32_t* scan_ws, float4* partials)
 {
     if (n_tiles == 0) return;
-    int grid = ((n_tiles + 7) / 8) * 8;
-    if (tile_map == 2) {
-        const int rows_local = (n_tiles + f.tiles_x - 1) / f.tiles_x;
-        grid = ((rows_local + 7) / 8) * f.tiles_x * 8;
-    }
-    hipLaunchKernelGGL(k_composite, dim3(grid), dim3(256), 0, s, f, ranges, vals, recs, bg_rgba, bg_depth, out, n_tiles, out_rows, tile_map);
+    hipLaunchKernelGGL(k_items, dim3((n_tiles + 255) / 256), dim3(256), 0, s, ranges, n_tiles, seg, item_base);
+    launch_scan(s, item_base, item_base, (size_t)n_tiles, item_base + n_tiles, scan_ws);
+    const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
+    hipLaunchKernelGGL(k_composite, dim3(max_items), dim3(256), 0, s, f, ranges, item_base, seg, vals, recs, bg_rgba, bg_depth,
+                       out, partials, n_tiles, out_rows);
+    hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded)
