@@ -95,7 +95,7 @@ struct gswt_ctx {
     // options
     int opt_no_prefilter = 0;
     int opt_debug_varyings = 0;
-    int opt_segment = 1024;  // pairs per compositor work item (multiple of 256)
+    int opt_segment = 512;   // pairs per compositor work item (multiple of 256); c3 sweep: 512 best
     uint32_t last_n_tiles = 0;
     // timing
     hipEvent_t ev[8] = {};

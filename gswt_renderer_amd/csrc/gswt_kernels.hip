@@ -293,11 +293,13 @@ __global__ __launch_bounds__(256) void k_project(
             // depth_compare Less against the 1.0 clear when no proxy depth is bound (renderer.rs:182,436)
             if (!f.has_depth && !(depth < 1.0f)) { visible = false; break; }
             const float r_iux = ux / uu, r_iuy = uy / uu, r_ivx = wx / ww, r_ivy = wy / ww;
-            float hx = 2.0f * sqrtf(ux * ux + wx * wx) + 1.0f;
-            float hy = 2.0f * sqrtf(uy * uy + wy * wy) + 1.0f;
-            float fx0 = floorf(cxp - hx), fx1 = ceilf(cxp + hx);
-            float fy0 = floorf(cyp - hy), fy1 = ceilf(cyp + hy);
-            if (fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= f.W - 1.0f && fy0 <= f.H - 1.0f) {
+            // half extents of |p| <= 2, inflated by 1e-5 relative + 1e-3 px (conservative under f32 rounding)
+            float hx = 2.0f * sqrtf(ux * ux + wx * wx) * 1.00001f + 0.001f;
+            float hy = 2.0f * sqrtf(uy * uy + wy * wy) * 1.00001f + 0.001f;
+            // pixels whose CENTRE lies inside the box: x in [ceil(c - h - 0.5), floor(c + h - 0.5)]
+            float fx0 = ceilf(cxp - hx - 0.5f), fx1 = floorf(cxp + hx - 0.5f);
+            float fy0 = ceilf(cyp - hy - 0.5f), fy1 = floorf(cyp + hy - 0.5f);
+            if (fx1 >= fx0 && fy1 >= fy0 && fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= f.W - 1.0f && fy0 <= f.H - 1.0f) {
                 int x0 = fx0 < 0.0f ? 0 : (int)fx0, x1 = fx1 > f.W - 1.0f ? f.width - 1 : (int)fx1;
                 int y0 = fy0 < 0.0f ? 0 : (int)fy0, y1 = fy1 > f.H - 1.0f ? f.height - 1 : (int)fy1;
                 int tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
@@ -540,6 +542,10 @@ __global__ __launch_bounds__(256) void k_items(const uint2* __restrict__ ranges,
     seg_count[t] = len == 0 ? 1u : (len + seg - 1u) / seg;
 }
 
+#ifdef GSWT_STATS
+__device__ unsigned long long g_stats[8];
+#endif
+template <bool EARLY, bool DEPTH>
 __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ item_base, uint32_t seg,
                                                    const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
@@ -572,14 +578,19 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
     const bool inside = px < f.width && py < f.height;
     const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
     const float fbx = (float)bx, fby = (float)by;
-    const float qx0 = (float)qx, qx1 = (float)(qx + 8), qy0 = (float)qy, qy1 = (float)(qy + 8);
+    // pixel-centre range of this wave's quadrant (tile-local)
+    const float qx0 = (float)qx + 0.5f, qx1 = (float)qx + 7.5f, qy0 = (float)qy + 0.5f, qy1 = (float)qy + 7.5f;
     uint2 rg = ranges[tile];
     rg.x += seg_idx * seg;
     rg.y = min(rg.y, rg.x + seg);
-    float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    // Transmittance doubles as the "still active" state: a lane is live while T >= t_eps.  Pixels
+    // outside the target start at T = 0 when early-out is on (never live); with t_eps = 0 they just
+    // accumulate and are never stored.
+    float T = (EARLY && !inside) ? 0.0f : 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
     float dbuf = 1.0f;
-    if (inside && f.has_depth) dbuf = bg_depth[(size_t)py * f.width + px];
-    bool done = !inside;
+    if (DEPTH && inside) dbuf = bg_depth[(size_t)py * f.width + px];
+    const float t_eps = f.t_eps;
+    bool wave_live = true;
     for (uint32_t base = rg.x; base < rg.y; base += 256u) {
         const uint32_t n = min(256u, rg.y - base);
         if (tid < n) {
@@ -591,54 +602,68 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
             const float nku = -fmaf(a.x, ox, a.y * oy);
             const float nkv = -fmaf(b.x, ox, b.y * oy);
             const uint32_t cw = __float_as_uint(c.x);
+            const float k255 = 1.0f / 255.0f;      // colour is continuous: x * (1/255) vs x / 255 differs by <= 1 ulp
             s_q0[tid] = make_float4(a.x, a.y, nku, a.w);
             s_q1[tid] = make_float4(b.x, b.y, nkv, b.w);
-            s_q2[tid] = make_float4((float)(cw & 0xFFu) / 255.0f, (float)((cw >> 8) & 0xFFu) / 255.0f,
-                                    (float)((cw >> 16) & 0xFFu) / 255.0f, 0.0f);
+            s_q2[tid] = make_float4((float)(cw & 0xFFu) * k255, (float)((cw >> 8) & 0xFFu) * k255,
+                                    (float)((cw >> 16) & 0xFFu) * k255, 0.0f);
             s_q3[tid] = make_float4(ox - c.y, ox + c.y, oy - c.z, oy + c.z);     // pixel bbox, tile-local
         }
         __syncthreads();
-        if (__ballot(!done) != 0ull) {
-            // which staged records can touch this wave's quadrant
-            unsigned long long m[4];
+        if (wave_live) {
 #pragma unroll
             for (int c = 0; c < 4; c++) {
+                // which staged records of this 64-chunk can touch this wave's quadrant
                 const uint32_t idx = (uint32_t)c * 64u + lane;
                 bool hit = false;
                 if (idx < n) {
                     const float4 bb = s_q3[idx];
                     hit = bb.y >= qx0 && bb.x <= qx1 && bb.w >= qy0 && bb.z <= qy1;
                 }
-                m[c] = __ballot(hit);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                unsigned long long mask = m[c];
-                while (mask) {
-                    const uint32_t k = (uint32_t)c * 64u + (uint32_t)__builtin_ctzll(mask);
-                    mask &= mask - 1ull;
-                    const float4 q0 = s_q0[k], q1 = s_q1[k];
+                const unsigned long long mask = __ballot(hit);
+                if (mask == 0ull) continue;
+                // Compact the hits into a lane-indexed list: lane i of `list` = LDS index of the i-th hit
+                // (the non-hit lanes fill the tail, so every entry is a valid index and the one-ahead
+                // prefetch below never needs a guard).  The scalar unit is shared by the CU's four SIMDs,
+                // so the walk is a plain counted loop: v_readlane for the index, no mask arithmetic.
+                const uint32_t nh = (uint32_t)__popcll(mask);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const uint32_t pos = hit ? below : nh + (lane - below);
+                const int list = __builtin_amdgcn_ds_permute((int)(pos << 2), (int)idx);
+                uint32_t k = (uint32_t)__builtin_amdgcn_readlane(list, 0);
+                float4 q0 = s_q0[k], q1 = s_q1[k], q2 = s_q2[k];
+                for (uint32_t i = 0; i < nh; i++) {
+                    const uint32_t kn = (uint32_t)__builtin_amdgcn_readlane(list, (int)min(i + 1u, 63u));
+                    const float4 n0 = s_q0[kn], n1 = s_q1[kn], n2 = s_q2[kn];      // prefetch hit i+1
                     // F4: per-pixel
                     const float pu_y = fmaf(q0.y, ly, q0.z);
                     const float pv_y = fmaf(q1.y, ly, q1.z);
                     const float ppx = fmaf(q0.x, lx, pu_y);
                     const float ppy = fmaf(q1.x, lx, pv_y);
                     const float r2 = fmaf(ppy, ppy, ppx * ppx);
-                    if (!done && r2 <= 4.0f && q1.w < dbuf) {
-                        const float Bv = __builtin_amdgcn_exp2f(r2 * -1.4426950408889634f) * q0.w;
+                    bool cover = r2 <= 4.0f;
+                    if (DEPTH) cover = cover && q1.w < dbuf;
+                    if (EARLY) cover = cover && T >= t_eps;
+#ifdef GSWT_STATS
+                    { unsigned long long cm = __ballot(cover);
+                      if (lane == 0) { atomicAdd(&g_stats[0], 1ull); atomicAdd(&g_stats[1], (unsigned long long)__popcll(cm)); if (cm == 0ull) atomicAdd(&g_stats[2], 1ull); } }
+#endif
+                    if (__ballot(cover) != 0ull) {          // wave-uniform skip; lanes are predicated, not masked
+                        const float e = __builtin_amdgcn_exp2f(r2 * -1.4426950408889634f) * q0.w;
+                        const float Bv = cover ? e : 0.0f;
                         const float wgt = T * Bv;
-                        const float4 q2 = s_q2[k];
                         ar = fmaf(wgt, q2.x, ar);
                         ag = fmaf(wgt, q2.y, ag);
                         ab = fmaf(wgt, q2.z, ab);
                         T = T - wgt;
-                        done = T < f.t_eps;
                     }
-                    if (__ballot(!done) == 0ull) { mask = 0ull; m[1] = m[2] = m[3] = 0ull; }   // whole wave saturated
+                    q0 = n0; q1 = n1; q2 = n2;
                 }
+                if (EARLY && __ballot(T >= t_eps) == 0ull) { wave_live = false; break; }   // whole wave saturated
             }
         }
-        if (__syncthreads_and(done ? 1 : 0)) break;
+        if (EARLY) { if (__syncthreads_and(wave_live ? 0 : 1)) break; }
+        else __syncthreads();
     }
     if (n_seg > 1u) {
         // partial (C, T) of this segment; k_combine folds the segments front to back
@@ -782,8 +807,15 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     hipLaunchKernelGGL(k_items, dim3((n_tiles + 255) / 256), dim3(256), 0, s, ranges, n_tiles, seg, item_base);
     launch_scan(s, item_base, item_base, (size_t)n_tiles, item_base + n_tiles, scan_ws);
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
-    hipLaunchKernelGGL(k_composite, dim3(max_items), dim3(256), 0, s, f, ranges, item_base, seg, vals, recs, bg_rgba, bg_depth,
-                       out, partials, n_tiles, out_rows);
+    const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0;
+#define GSWT_LAUNCH_COMPOSITE(E, D)                                                                                         \
+    hipLaunchKernelGGL((k_composite<E, D>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, seg, vals, recs, bg_rgba, \
+                       bg_depth, out, partials, n_tiles, out_rows)
+    if (early && depth) GSWT_LAUNCH_COMPOSITE(true, true);
+    else if (early) GSWT_LAUNCH_COMPOSITE(true, false);
+    else if (depth) GSWT_LAUNCH_COMPOSITE(false, true);
+    else GSWT_LAUNCH_COMPOSITE(false, false);
+#undef GSWT_LAUNCH_COMPOSITE
     hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows);
 }
 
@@ -793,3 +825,10 @@ void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int widt
 }
 
 }  // namespace gswt
+#ifdef GSWT_STATS
+extern "C" __attribute__((visibility("default"))) int gswt_debug_stats(unsigned long long* out)
+{
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gswt::g_stats), 64);
+}
+#endif

@@ -157,7 +157,7 @@ GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
  *   are identical (gswt.wgsl:38-42 discards the other LOD), only the entry count differs.
  * DEBUG_VARYINGS: keep vs_main's per-entry outputs for gswt_debug_read_projected. */
 enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
-       GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 1024) */ };
+       GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 512) */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

@@ -526,9 +526,11 @@ static void frag_setup(const orc_splat *sp, float splat_scale, float W, float H,
     if (!fs->ok) return;
     fs->iux = ux / uu; fs->iuy = uy / uu;
     fs->ivx = vx / vv; fs->ivy = vy / vv;
-    /* conservative extent of |p| <= 2 : |dX| <= 2 sqrt(ux^2 + vx^2) */
-    fs->hx = 2.0f * sqrtf(ux * ux + vx * vx) + 1.0f;
-    fs->hy = 2.0f * sqrtf(uy * uy + vy * vy) + 1.0f;
+    /* extent of |p| <= 2 : |dX| <= 2 sqrt(ux^2 + vx^2), inflated by 1e-3 px + 1e-5 relative so the
+     * box is conservative under f32 rounding of F3/F4.  A pixel can be covered only if its CENTRE
+     * lies inside [c - h, c + h]. */
+    fs->hx = 2.0f * sqrtf(ux * ux + vx * vx) * 1.00001f + 0.001f;
+    fs->hy = 2.0f * sqrtf(uy * uy + vy * vy) * 1.00001f + 0.001f;
 }
 
 /* Rasterise one projected splat into rows [y_lo, y_hi) with "over" blending
@@ -536,11 +538,14 @@ static void frag_setup(const orc_splat *sp, float splat_scale, float W, float H,
 static void raster_over(const orc_splat *sp, const orc_frag_setup *fs, int W, int H,
                         int y_lo, int y_hi, const float *bg_depth, float *img)
 {
-    float fx0 = floorf(fs->cxp - fs->hx), fx1 = ceilf(fs->cxp + fs->hx);
-    float fy0 = floorf(fs->cyp - fs->hy), fy1 = ceilf(fs->cyp + fs->hy);
-    if (!(fx1 >= 0.0f) || !(fy1 >= 0.0f) || !(fx0 <= (float)W) || !(fy0 <= (float)H)) return;
+    /* pixels whose centre x + 0.5 lies in [c - h, c + h] */
+    float fx0 = ceilf(fs->cxp - fs->hx - 0.5f), fx1 = floorf(fs->cxp + fs->hx - 0.5f);
+    float fy0 = ceilf(fs->cyp - fs->hy - 0.5f), fy1 = floorf(fs->cyp + fs->hy - 0.5f);
+    if (!(fx1 >= fx0) || !(fy1 >= fy0)) return;
+    if (!(fx1 >= 0.0f) || !(fy1 >= 0.0f) || !(fx0 <= (float)(W - 1)) || !(fy0 <= (float)(H - 1))) return;
     int x0 = fx0 < 0.0f ? 0 : (int)fx0, x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
     int y0 = fy0 < (float)y_lo ? y_lo : (int)fy0, y1 = fy1 > (float)(y_hi - 1) ? y_hi - 1 : (int)fy1;
+    if (y1 < y0) return;
     for (int by = y0 & ~15; by <= y1; by += 16) {
         for (int bx = x0 & ~15; bx <= x1; bx += 16) {
             /* F3: per-block constants */
@@ -580,7 +585,8 @@ static void raster_over(const orc_splat *sp, const orc_frag_setup *fs, int W, in
 typedef struct {
     uint64_t n_instanced;   /* sum of draw counts                */
     uint64_t n_visible;     /* survivors of the vertex stage     */
-    uint64_t n_pairs16;     /* (splat, 16x16 block) bbox pairs   */
+    uint64_t n_pairs16;     /* (splat, 16x16 block) pairs: blocks holding >= 1 pixel centre inside the
+                               splat's axis-aligned bounding box of |p| <= 2 (frag_setup's hx, hy) */
 } orc_stats;
 
 /*
@@ -629,9 +635,9 @@ ORC_API int orc_render(const orc_camera *cam, const orc_scene *scene, const uint
             }
             if (sp[k].visible) {
                 vis_d++;
-                float fx0 = floorf(fs[k].cxp - fs[k].hx), fx1 = ceilf(fs[k].cxp + fs[k].hx);
-                float fy0 = floorf(fs[k].cyp - fs[k].hy), fy1 = ceilf(fs[k].cyp + fs[k].hy);
-                if (fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1)) {
+                float fx0 = ceilf(fs[k].cxp - fs[k].hx - 0.5f), fx1 = floorf(fs[k].cxp + fs[k].hx - 0.5f);
+                float fy0 = ceilf(fs[k].cyp - fs[k].hy - 0.5f), fy1 = floorf(fs[k].cyp + fs[k].hy - 0.5f);
+                if (fx1 >= fx0 && fy1 >= fy0 && fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1)) {
                     int x0 = fx0 < 0 ? 0 : (int)fx0, x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
                     int y0 = fy0 < 0 ? 0 : (int)fy0, y1 = fy1 > (float)(H - 1) ? H - 1 : (int)fy1;
                     pairs_d += (uint64_t)((x1 >> 4) - (x0 >> 4) + 1) * (uint64_t)((y1 >> 4) - (y0 >> 4) + 1);
@@ -690,8 +696,8 @@ ORC_API int orc_render(const orc_camera *cam, const orc_scene *scene, const uint
         }
         for (uint64_t i = 0; i < n_order; i++) {
             uint64_t k = order[i];
-            float fy0 = floorf(fs[k].cyp - fs[k].hy), fy1 = ceilf(fs[k].cyp + fs[k].hy);
-            if (!(fy1 >= 0.0f) || !(fy0 <= (float)H)) continue;
+            float fy0 = ceilf(fs[k].cyp - fs[k].hy - 0.5f), fy1 = floorf(fs[k].cyp + fs[k].hy - 0.5f);
+            if (!(fy1 >= fy0) || !(fy1 >= 0.0f) || !(fy0 <= (float)(H - 1))) continue;
             int b0 = fy0 < 0.0f ? 0 : ((int)fy0) >> 4;
             int b1 = fy1 > (float)(H - 1) ? n_bands - 1 : ((int)fy1) >> 4;
             if (b1 > n_bands - 1) b1 = n_bands - 1;
