@@ -22,6 +22,7 @@ GSWT_ORDER_DEPTH = 1
 GSWT_OPT_NO_LOD_PREFILTER = 1
 GSWT_OPT_DEBUG_VARYINGS = 2
 GSWT_OPT_SEGMENT = 3
+GSWT_OPT_DEBUG_FLAGS = 4
 
 
 class CameraUniforms(C.Structure):
@@ -72,7 +73,7 @@ class Timings(C.Structure):
                 ("ms_sort", C.c_float), ("ms_ranges", C.c_float), ("ms_composite", C.c_float),
                 ("ms_total", C.c_float), ("n_draws", C.c_uint32), ("n_instanced", C.c_uint64),
                 ("n_visible", C.c_uint64), ("n_pairs", C.c_uint64), ("n_tiles", C.c_uint32),
-                ("_pad", C.c_uint32)]
+                ("_pad", C.c_uint32), ("ms_composite_kernel", C.c_float), ("_pad2", C.c_float)]
 
 
 assert C.sizeof(CameraUniforms) == 176 and C.sizeof(SceneUniforms) == 160 and C.sizeof(TileUniforms) == 80

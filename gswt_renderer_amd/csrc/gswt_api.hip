@@ -14,6 +14,7 @@
 #include "../../include/gswt_hip.h"
 #include "gswt_device.h"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -21,14 +22,17 @@
 #include <vector>
 
 namespace gswt {
+void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, const uint32_t*, const uint32_t*,
-                    const uint32_t*, const uint4*, const float*, uint2*, Rec*, uint32_t*, unsigned long long*, Varyings*);
-void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uint32_t*);
-void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, uint32_t*, uint32_t*);
-int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, int, uint32_t*, uint32_t*, uint32_t*);
-void launch_ranges(hipStream_t, const uint32_t*, uint32_t, uint2*, uint32_t);
+                    const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, uint32_t*, uint32_t*,
+                    unsigned long long*, Varyings*);
+void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
+                 uint32_t*, uint32_t*);
+int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*,
+                uint32_t*, uint32_t*);
+void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint32_t*, float4*);
+                      uint32_t, uint32_t, uint32_t*, uint32_t*, float4*, hipEvent_t, hipEvent_t);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
 }  // namespace gswt
 
@@ -84,21 +88,23 @@ struct gswt_ctx {
     // frame
     DevBuf<uint2> rects;
     DevBuf<Rec> recs;
-    DevBuf<uint32_t> block_sums, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
+    DevBuf<uint32_t> block_sums, super_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
+    uint32_t pair_cap = 0;                 // capacity the pair buffers / grids are sized for (grows on overflow)
     DevBuf<uint2> ranges;
     DevBuf<uint32_t> item_base;
     DevBuf<float4> partials;
-    DevBuf<unsigned long long> counters;   // [0] visible, [1] (u32) total pairs, [2] scratch
+    DevBuf<unsigned long long> counters;   // [0] visible splats, [1] pairs, [2] scan scratch, [3] pair-capacity overflow flag
     DevBuf<float4> bg_rgba, out_img;
     DevBuf<float> bg_depth;
     DevBuf<Varyings> dbg;
     // options
     int opt_no_prefilter = 0;
     int opt_debug_varyings = 0;
+    int opt_dbg_flags = 0;
     int opt_segment = 512;   // pairs per compositor work item (multiple of 256); c3 sweep: 512 best
     uint32_t last_n_tiles = 0;
     // timing
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     gswt_timings timings = {};
 };
 
@@ -162,7 +168,7 @@ void gswt_destroy(gswt_ctx* c)
     hipStreamSynchronize(c->stream);
     c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release();
     c->merged_list.release(); c->merged_map.release(); c->rects.release(); c->recs.release(); c->block_sums.release();
-    c->scan_ws.release(); c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release();
+    c->scan_ws.release(); c->super_sums.release(); c->draw_culled.release(); c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release();
     c->ghist.release(); c->ranges.release(); c->item_base.release(); c->partials.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
     c->bg_depth.release(); c->dbg.release();
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
@@ -188,6 +194,7 @@ int gswt_set_option(gswt_ctx* c, int key, int value)
     switch (key) {
     case GSWT_OPT_NO_LOD_PREFILTER: c->opt_no_prefilter = value; c->draws_ready = false; return GSWT_OK;
     case GSWT_OPT_DEBUG_VARYINGS: c->opt_debug_varyings = value; return GSWT_OK;
+    case GSWT_OPT_DEBUG_FLAGS: c->opt_dbg_flags = value; return GSWT_OK;
     case GSWT_OPT_SEGMENT:
         if (value < 256 || value % 256) return fail(c, GSWT_ERR_BAD_ARG, "segment must be a positive multiple of 256");
         c->opt_segment = value; return GSWT_OK;
@@ -345,6 +352,8 @@ int gswt_set_draws(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint3
     HIP_TRY(c, c->rects.ensure(n_slots + 1));
     HIP_TRY(c, c->recs.ensure(n_slots + 1));
     HIP_TRY(c, c->block_sums.ensure((size_t)c->n_chunks + 1));
+    HIP_TRY(c, c->super_sums.ensure(2 * ((size_t)c->n_chunks / 256 + 1) + 2));
+    HIP_TRY(c, c->draw_culled.ensure((size_t)n_draws + 1));
     c->draws_ready = true;
     return GSWT_OK;
 }
@@ -414,6 +423,7 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     f.tiles_x = (width + kTile - 1) / kTile; f.tiles_y = (height + kTile - 1) / kTile;
     f.shard_index = sc > 1 ? cfg->shard_index : 0; f.shard_count = sc;
     f.hm_w = c->hm_w; f.hm_h = c->hm_h;
+    f.dbg_flags = c->opt_dbg_flags;
 
     const int tiles_y_local = sc > 1 ? (f.tiles_y - f.shard_index + sc - 1) / sc : f.tiles_y;
     const int n_tiles = f.tiles_x * (tiles_y_local > 0 ? tiles_y_local : 0);
@@ -434,57 +444,71 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     if (out_on_device) d_out = reinterpret_cast<float4*>(out_rgba);
     else { HIP_TRY(c, c->out_img.ensure(out_px)); d_out = c->out_img.p; }
     HIP_TRY(c, c->ranges.ensure((size_t)n_tiles + 1));
-    HIP_TRY(c, c->scan_ws.ensure((size_t)c->n_chunks / 1024 + 4096));
     const bool dbg = c->opt_debug_varyings != 0;
     if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)c->n_entries + 1));
     if (sc > 1 && out_rows * width > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
 
-    // ---- project
-    HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), s));
-    launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
-                   c->tex.p, c->hmap.p, c->rects.p, c->recs.p, c->block_sums.p, c->counters.p, c->dbg.p);
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    // ---- scan of per-workgroup pair counts; total pairs -> counters[1]
-    launch_scan(s, c->block_sums.p, c->block_sums.p, c->n_chunks, reinterpret_cast<uint32_t*>(c->counters.p + 1), c->scan_ws.p);
-    HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    unsigned long long host_counters[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(host_counters, c->counters.p, sizeof(host_counters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    const uint32_t P = (uint32_t)(host_counters[1] & 0xFFFFFFFFull);
-    // ---- emit
-    HIP_TRY(c, c->keys_a.ensure((size_t)P + 1)); HIP_TRY(c, c->keys_b.ensure((size_t)P + 1));
-    HIP_TRY(c, c->vals_a.ensure((size_t)P + 1)); HIP_TRY(c, c->vals_b.ensure((size_t)P + 1));
-    const uint32_t nblk = (P + 4095) / 4096;
-    HIP_TRY(c, c->ghist.ensure((size_t)256 * nblk + 1));
-    HIP_TRY(c, c->scan_ws.ensure((size_t)256 * nblk / 1024 + 4096));
-    launch_emit(s, f, c->n_chunks, c->rects.p, c->block_sums.p, c->keys_a.p, c->vals_a.p);
-    HIP_TRY(c, hipEventRecord(c->ev[3], s));
-    // ---- stable sort on the tile bits
+    // The pair count P is only known on the device.  Everything downstream of k_project is launched
+    // for a capacity `pair_cap` (blocks past the real P exit), so a frame needs no host round trip
+    // in the middle; the count and an overflow flag are read back with the frame.  If P exceeded the
+    // capacity the buffers grow and the frame is re-run (first frame / sudden scene change only).
     int key_bits = 1;
     while ((1 << key_bits) < n_tiles) key_bits++;
-    int where = launch_sort(s, c->keys_a.p, c->vals_a.p, c->keys_b.p, c->vals_b.p, P, key_bits, c->ghist.p, c->scan_ws.p,
-                            reinterpret_cast<uint32_t*>(c->counters.p + 2));
-    const uint32_t* keys_sorted = where ? c->keys_b.p : c->keys_a.p;
-    const uint32_t* vals_sorted = where ? c->vals_b.p : c->vals_a.p;
-    HIP_TRY(c, hipEventRecord(c->ev[4], s));
-    // ---- ranges
-    launch_ranges(s, keys_sorted, P, c->ranges.p, (uint32_t)n_tiles);
-    HIP_TRY(c, hipEventRecord(c->ev[5], s));
-    // ---- composite
-    {
+    if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_entries / 4, 1u << 20), 0xFFFFFF00ull);
+    unsigned long long host_counters[4] = {0, 0, 0, 0};
+    for (int attempt = 0;; attempt++) {
+        const uint32_t cap = c->pair_cap;
+        HIP_TRY(c, c->keys_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->keys_b.ensure((size_t)cap + 1));
+        HIP_TRY(c, c->vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->vals_b.ensure((size_t)cap + 1));
+        const uint32_t nblk = (cap + 4095) / 4096;
+        HIP_TRY(c, c->ghist.ensure((size_t)256 * nblk + 1));
+        HIP_TRY(c, c->scan_ws.ensure((size_t)256 * nblk / 1024 + (size_t)n_tiles / 1024 + 4096));
         const uint32_t seg = (uint32_t)c->opt_segment;
-        const size_t max_items = (size_t)n_tiles + P / seg + 1;
         HIP_TRY(c, c->item_base.ensure((size_t)n_tiles + 2));
-        HIP_TRY(c, c->partials.ensure(max_items * 256));
-        launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows, seg, P,
-                         c->item_base.p, c->scan_ws.p, c->partials.p);
+        HIP_TRY(c, c->partials.ensure(((size_t)n_tiles + cap / seg + 1) * 256));
+        unsigned long long* const d_P = c->counters.p + 1;
+        // ---- cull + project
+        HIP_TRY(c, hipEventRecord(c->ev[0], s));
+        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), s));
+        HIP_TRY(c, hipMemsetAsync(c->super_sums.p, 0, 2 * ((size_t)c->n_chunks / 256 + 1) * 4, s));
+        launch_cull(s, f, c->draws.p, c->n_draws, c->draw_culled.p);
+        launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
+                       c->tex.p, c->hmap.p, c->draw_culled.p, c->rects.p, c->recs.p, c->block_sums.p, c->super_sums.p,
+                       c->counters.p, c->dbg.p);
+        HIP_TRY(c, hipEventRecord(c->ev[1], s));
+        HIP_TRY(c, hipEventRecord(c->ev[2], s));
+        // ---- emit
+        launch_emit(s, f, c->n_chunks, c->rects.p, c->block_sums.p, c->super_sums.p, cap, c->counters.p, c->keys_a.p, c->vals_a.p);
+        HIP_TRY(c, hipEventRecord(c->ev[3], s));
+        // ---- stable sort on the tile bits
+        int where = launch_sort(s, c->keys_a.p, c->vals_a.p, c->keys_b.p, c->vals_b.p, cap, d_P, key_bits, c->ghist.p, c->scan_ws.p,
+                                reinterpret_cast<uint32_t*>(c->counters.p + 2));
+        const uint32_t* keys_sorted = where ? c->keys_b.p : c->keys_a.p;
+        const uint32_t* vals_sorted = where ? c->vals_b.p : c->vals_a.p;
+        HIP_TRY(c, hipEventRecord(c->ev[4], s));
+        // ---- ranges
+        launch_ranges(s, keys_sorted, cap, d_P, c->ranges.p, (uint32_t)n_tiles);
+        HIP_TRY(c, hipEventRecord(c->ev[5], s));
+        // ---- composite
+        launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows, seg, cap,
+                         c->item_base.p, c->scan_ws.p, c->partials.p, c->ev[7], c->ev[8]);
+        c->last_n_tiles = (uint32_t)n_tiles;
+        HIP_TRY(c, hipEventRecord(c->ev[6], s));
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(host_counters, c->counters.p, sizeof(host_counters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (host_counters[1] >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: %llu pairs exceed 2^32", host_counters[1]);
+        if (host_counters[3] == 0 && host_counters[1] <= cap) break;
+        if (attempt >= 2) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");
+        c->pair_cap = (uint32_t)std::min<uint64_t>(host_counters[1] + host_counters[1] / 4 + 4096, 0xFFFFFF00ull);
     }
-    c->last_n_tiles = (uint32_t)n_tiles;
-    HIP_TRY(c, hipEventRecord(c->ev[6], s));
-    HIP_TRY(c, hipGetLastError());
-    if (!out_on_device) HIP_TRY(c, hipMemcpyAsync(out_rgba, d_out, out_px * 16, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint32_t P = (uint32_t)host_counters[1];
+    // keep ~25 % headroom over the running pair count without shrinking on every small dip
+    if ((uint64_t)P + P / 8 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 4 + 4096, 0xFFFFFF00ull);
+    if (!out_on_device) {
+        HIP_TRY(c, hipMemcpyAsync(out_rgba, d_out, out_px * 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
 
     gswt_timings& t = c->timings;
     memset(&t, 0, sizeof(t));
@@ -495,6 +519,7 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     hipEventElapsedTime(&t.ms_ranges, c->ev[4], c->ev[5]);
     hipEventElapsedTime(&t.ms_composite, c->ev[5], c->ev[6]);
     hipEventElapsedTime(&t.ms_total, c->ev[0], c->ev[6]);
+    hipEventElapsedTime(&t.ms_composite_kernel, c->ev[7], c->ev[8]);
     t.n_draws = c->n_draws; t.n_instanced = c->n_entries; t.n_visible = host_counters[0]; t.n_pairs = P; t.n_tiles = (uint32_t)n_tiles;
     return GSWT_OK;
 }

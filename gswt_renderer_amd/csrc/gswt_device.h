@@ -56,6 +56,7 @@ struct Frame {
     int32_t width, height, tiles_x, tiles_y;
     int32_t shard_index, shard_count;
     int32_t hm_w, hm_h;
+    int32_t dbg_flags;       // profiling ablations (GSWT_OPT_DEBUG_FLAGS); 0 in normal operation
 };
 
 // Projected splat record consumed by the compositor (48 B, three 16-B words).

@@ -60,6 +60,35 @@ __device__ __forceinline__ int owned_rows(int ty0, int ty1, int index, int count
 }
 
 // ------------------------------------------------------------------------------------
+// k_cull: the CPU viewport culling + lod_enable skip of renderer.rs:472-497, one thread per draw.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __restrict__ draws, uint32_t n_draws,
+                                              uint32_t* __restrict__ draw_culled)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_draws) return;
+    const DrawDev& d = draws[i];
+    uint32_t culled = 0;
+    if (d.cull_enable) {
+        float mx = 3.402823466e+38f, my = 3.402823466e+38f, mz = -3.402823466e+38f;
+        for (int ci = 0; ci < 4; ci++) {
+            float px = d.corners[3 * ci], py = d.corners[3 * ci + 1], pz = d.corners[3 * ci + 2];
+            float c4[4];
+            for (int r = 0; r < 4; r++)
+                c4[r] = ((f.VP[r] * px + f.VP[4 + r] * py) + f.VP[8 + r] * pz) + f.VP[12 + r] * 1.0f;
+            float cx = c4[0] / c4[3], cy = c4[1] / c4[3], cz = c4[2] / c4[3];
+            if (fabsf(cx) < mx) mx = fabsf(cx);
+            if (fabsf(cy) < my) my = fabsf(cy);
+            if (cz > mz) mz = cz;
+        }
+        float clip = f.culling_dist;
+        if (mz < -clip || mx > clip || my > clip) culled = 1;
+    }
+    if (!((f.lod_enable_mask >> (d.lod & 31u)) & 1u)) culled = 1;
+    draw_culled[i] = culled;
+}
+
+// ------------------------------------------------------------------------------------
 // k_project
 // One workgroup = one 256-entry chunk of one draw, in composite (front-to-back) order:
 // slot = slot_base + r, r-th entry from the END of the draw's list.
@@ -69,44 +98,26 @@ __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
-    const float* __restrict__ hmap, uint2* __restrict__ rects, Rec* __restrict__ recs,
-    uint32_t* __restrict__ block_sums, unsigned long long* __restrict__ counters,
+    const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, uint2* __restrict__ rects,
+    Rec* __restrict__ recs, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
     Varyings* __restrict__ dbg)
 {
-    __shared__ int s_culled;
     __shared__ uint32_t s_wsum[4], s_wvis[4];
     const uint2 ct = chunk_tab[blockIdx.x];
     const DrawDev& d = draws[ct.x];
     const uint32_t tid = threadIdx.x;
-
-    // CPU viewport culling of renderer.rs:472-497, done once per workgroup
-    if (tid == 0) {
-        int culled = 0;
-        if (d.cull_enable) {
-            float mx = 3.402823466e+38f, my = 3.402823466e+38f, mz = -3.402823466e+38f;
-            for (int ci = 0; ci < 4; ci++) {
-                float px = d.corners[3 * ci], py = d.corners[3 * ci + 1], pz = d.corners[3 * ci + 2];
-                float c4[4];
-                for (int r = 0; r < 4; r++)
-                    c4[r] = ((f.VP[r] * px + f.VP[4 + r] * py) + f.VP[8 + r] * pz) + f.VP[12 + r] * 1.0f;
-                float cx = c4[0] / c4[3], cy = c4[1] / c4[3], cz = c4[2] / c4[3];
-                if (fabsf(cx) < mx) mx = fabsf(cx);
-                if (fabsf(cy) < my) my = fabsf(cy);
-                if (cz > mz) mz = cz;
-            }
-            float clip = f.culling_dist;
-            if (mz < -clip || mx > clip || my > clip) culled = 1;
-        }
-        if (!((f.lod_enable_mask >> (d.lod & 31u)) & 1u)) culled = 1;
-        s_culled = culled;
+    const bool s_culled = draw_culled[ct.x] != 0u;
+    if (s_culled && !DEBUG) {               // nothing to project: the chunk contributes no pairs
+        if (tid == 0) block_sums[blockIdx.x] = 0u;
+        return;
     }
-    __syncthreads();
 
     const uint32_t r = ct.y + tid;
     const uint32_t slot = d.slot_base + r;
     const bool in_list = r < d.count;
     uint32_t count = 0;
     bool visible = false;
+    uint2 my_rect = make_uint2(1u, 0u);     // empty: tx0 = 1 > tx1 = 0
     Varyings vout;
     if (DEBUG) { vout.visible = 0; vout.ndc[0] = vout.ndc[1] = vout.depth = 0.f; vout.major[0] = vout.major[1] = 0.f;
                  vout.minor[0] = vout.minor[1] = 0.f; vout.rgba[0] = vout.rgba[1] = vout.rgba[2] = vout.rgba[3] = 0.f; }
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void k_project(
                 int rows = owned_rows(ty0, ty1, f.shard_index, f.shard_count);
                 count = (uint32_t)((tx1 - tx0 + 1) * rows);
                 if (count) {
-                    rects[slot] = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
+                    my_rect = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
                     // colour stays packed (bytes / 255 is re-evaluated by the compositor's staging lane, same
                     // correctly rounded division); the two freed words carry the pixel half extents
                     Rec* dst = recs + slot;
@@ -317,7 +328,6 @@ __global__ __launch_bounds__(256) void k_project(
             }
         } while (0);
     }
-    if (count == 0) rects[slot] = make_uint2(1u, 0u);  // empty: tx0 = 1 > tx1 = 0
     if (DEBUG && in_list) dbg[d.entry_base + (d.count - 1u - r)] = vout;
 
     // workgroup sums: pairs and visible splats
@@ -328,11 +338,30 @@ __global__ __launch_bounds__(256) void k_project(
     }
     if ((tid & 63u) == 0) { s_wsum[tid >> 6] = wsum; s_wvis[tid >> 6] = wvis; }
     __syncthreads();
+    const uint32_t bsum = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    // k_emit reads the rects of a chunk only when the chunk has pairs
+    if (bsum) rects[slot] = my_rect;
     if (tid == 0) {
-        block_sums[blockIdx.x] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        block_sums[blockIdx.x] = bsum;
+        // two-level sums, spread over n_chunks / 256 addresses (a single hot counter serialises the whole grid);
+        // k_totals folds them into counters[0] (visible splats) and counters[1] (pairs)
+        if (bsum) atomicAdd(&super_sums[blockIdx.x >> 8], bsum);
         uint32_t v = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
-        if (v) atomicAdd(&counters[0], (unsigned long long)v);
+        if (v) atomicAdd(&super_sums[n_super + (blockIdx.x >> 8)], v);
     }
+}
+
+// counters[0] = visible splats, counters[1] = pairs (single workgroup)
+__global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ super_sums, uint32_t n_super,
+                                                unsigned long long* __restrict__ counters)
+{
+    __shared__ unsigned long long s_p[4], s_v[4];
+    unsigned long long p = 0, v = 0;
+    for (uint32_t j = threadIdx.x; j < n_super; j += 256u) { p += super_sums[j]; v += super_sums[n_super + j]; }
+    for (int off = 32; off > 0; off >>= 1) { p += __shfl_down(p, off, 64); v += __shfl_down(v, off, 64); }
+    if ((threadIdx.x & 63u) == 0) { s_p[threadIdx.x >> 6] = p; s_v[threadIdx.x >> 6] = v; }
+    __syncthreads();
+    if (threadIdx.x == 0) { counters[1] = s_p[0] + s_p[1] + s_p[2] + s_p[3]; counters[0] = s_v[0] + s_v[1] + s_v[2] + s_v[3]; }
 }
 
 // ------------------------------------------------------------------------------------
@@ -409,17 +438,33 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 // key = screen tile index local to the shard; val = slot.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __restrict__ rects,
-                                              const uint32_t* __restrict__ block_off,
+                                              const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ super_sums,
+                                              uint32_t pair_cap, unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     __shared__ uint32_t s_w[4];
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (block_sums[c] == 0u) return;
+    // first pair of this chunk = sum of all earlier chunks' pair counts, from the two-level sums
+    // k_project left behind (super_sums[j] = sum over chunks 256 j .. 256 j + 255): no scan kernel
+    uint32_t part = 0;
+    const uint32_t sup = c >> 8;
+    for (uint32_t j = threadIdx.x; j < sup; j += 256u) part += super_sums[j];
+    const uint32_t cj = (sup << 8) + threadIdx.x;
+    if (cj < c) part += block_sums[cj];
+    uint32_t chunk_base;
+    (void)block_excl_scan(part, s_w, &chunk_base);
+    const uint32_t slot = c * 256u + threadIdx.x;
     const uint2 rc = rects[slot];
     const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
     uint32_t count = 0;
     if (tx1 >= tx0) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
     uint32_t tot;
-    uint32_t off = block_off[blockIdx.x] + block_excl_scan(count, s_w, &tot);
+    uint32_t off = chunk_base + block_excl_scan(count, s_w, &tot);
+    if ((unsigned long long)chunk_base + tot > (unsigned long long)pair_cap) {   // pair buffers too small: host re-runs the frame
+        if (threadIdx.x == 0) atomicOr(&counters[3], 1ull);
+        return;
+    }
     if (count == 0) return;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     int ty = ty0;
@@ -439,12 +484,24 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
 // 4096 items per workgroup; each of the 4 waves owns 1024 consecutive items and ranks
 // them 64 at a time with ballot match-any, so in-wave order == memory order.
 // ------------------------------------------------------------------------------------
+// pair count as seen by the kernels downstream of k_emit: never more than the buffers hold
+// (n_ptr = &counters[1]; counters[3] = overflow flag set by k_emit).  On overflow part of the pair buffer is
+// unwritten, so the whole downstream chain processes nothing and the host re-runs the frame with larger buffers.
+__device__ __forceinline__ uint32_t clamped_count(const unsigned long long* n_ptr, uint32_t n_cap)
+{
+    const unsigned long long n = n_ptr[0];
+    if (n_ptr[2] != 0ull || n > (unsigned long long)n_cap) return 0u;
+    return (uint32_t)n;
+}
+
 constexpr int kSortItems = 16;   // per thread
 constexpr int kSortBlock = 256 * kSortItems;
 
-__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift,
-                                                    uint32_t mask, uint32_t* __restrict__ ghist, uint32_t nblk)
+__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
+                                                    uint32_t n_cap, uint32_t shift, uint32_t mask, uint32_t* __restrict__ ghist,
+                                                    uint32_t nblk)
 {
+    const uint32_t n = clamped_count(n_ptr, n_cap);
     __shared__ uint32_t s_h[256];
     s_h[threadIdx.x] = 0;
     __syncthreads();
@@ -460,9 +517,12 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__
 
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                       uint32_t n, uint32_t shift, uint32_t mask, uint32_t nbits,
-                                                       const uint32_t* __restrict__ ghist_scanned, uint32_t nblk)
+                                                       const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
+                                                       uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist_scanned,
+                                                       uint32_t nblk)
 {
+    const uint32_t n = clamped_count(n_ptr, n_cap);
+    if (blockIdx.x * kSortBlock >= n) return;
     __shared__ uint32_t s_h[4][256];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (int k = 0; k < 4; k++) s_h[k][threadIdx.x] = 0;
@@ -512,8 +572,10 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
 // ------------------------------------------------------------------------------------
 // k_ranges: [start, end) of each screen tile in the sorted pair list (ranges pre-zeroed)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ keys, uint32_t n, uint2* __restrict__ ranges)
+__global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
+                                                uint32_t n_cap, uint2* __restrict__ ranges)
 {
+    const uint32_t n = clamped_count(n_ptr, n_cap);
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     uint32_t k = keys[i];
@@ -522,13 +584,17 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 }
 
 // ------------------------------------------------------------------------------------
-// k_composite: one workgroup (4 wave64) per 16x16 screen tile; wave w owns the 8x8 pixel quadrant
-// (w & 1, w >> 1), one pixel per lane.  Batches of 256 pairs are staged through LDS (16 KB): the
-// staging lane gathers the 48-B record, unpacks the colour and evaluates the per-(splat, tile)
-// constants F3.  Each wave then ballots the batch down to the records whose pixel bounding box
-// touches ITS quadrant and walks only those (scalar bit loop, LDS broadcast reads), evaluating the
-// canonical per-pixel sequence F4.  A wave stops when the ballot of "transmittance >= eps" is
-// empty, the workgroup when all four waves have.
+// k_composite: one workgroup (4 wave64) per work item = (16x16 screen tile, segment of its pair list).
+// Wave w owns the 8x8 pixel quadrant (w & 1, w >> 1); inside a wave the four 16-lane groups own the
+// four 4x4 sub-blocks and walk DIFFERENT splats concurrently (the c3 scene averages ~9 covered pixels
+// per pair, so a whole wave per splat would leave most lanes idle).
+//   stage   : 256 pairs per batch -> LDS (16 KB): the staging lane gathers the 48-B record, unpacks the
+//             colour, evaluates the per-(splat, tile) constants F3 and the tile-local pixel-centre box
+//   bin     : every wave ballots the batch against its four sub-blocks and appends the hits, in list
+//             order, to four wave-private index lists in LDS (mbcnt-compacted byte stores)
+//   walk    : counted loop to the longest of the four lists; each group reads its own next index and
+//             record (LDS, four distinct addresses per wave), evaluates the canonical per-pixel
+//             sequence F4 and blends under predication; a wave whose ballot of "T >= eps" is empty stops
 // ------------------------------------------------------------------------------------
 // Work items: a tile's pair list is cut into segments of `seg` pairs; item = (tile, segment).
 // seg_count[t] = max(1, ceil(len / seg)) so empty tiles still get one item (they write the background).
@@ -544,6 +610,10 @@ __global__ __launch_bounds__(256) void k_items(const uint2* __restrict__ ranges,
 
 #ifdef GSWT_STATS
 __device__ unsigned long long g_stats[8];
+#define GSWT_STAT_STEP(C) { unsigned long long cm_ = __ballot(C); if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[0], 1ull); \
+    atomicAdd(&g_stats[1], (unsigned long long)__popcll(cm_)); if (cm_ == 0ull) atomicAdd(&g_stats[2], 1ull); } }
+#else
+#define GSWT_STAT_STEP(C)
 #endif
 template <bool EARLY, bool DEPTH>
 __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
@@ -554,6 +624,7 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
                                                    int n_tiles, int out_rows)
 {
     __shared__ float4 s_q0[256], s_q1[256], s_q2[256], s_q3[256];
+    __shared__ uint8_t s_list[4][4][260];         // [wave][sub-block][i] -> index of the i-th hit in the batch (+4: prefetch overrun)
     // work item -> (tile, segment): item_base is the exclusive scan of per-tile segment counts
     // (item_base[n_tiles] = number of items).  Consecutive items are dealt round-robin over the
     // 8 XCDs by the dispatcher, which balances the skewed tile-list lengths.
@@ -573,13 +644,17 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
     const int bx = tx * kTile, by = ty * kTile;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const int qx = (int)(wave & 1u) * 8, qy = (int)(wave >> 1) * 8;
-    const int lxi = qx + (int)(lane & 7u), lyi = qy + (int)(lane >> 3);
+    const uint32_t grp = lane >> 4, gi = lane & 15u;                 // 16-lane group = 4x4 sub-block
+    const int lxi = qx + (int)(grp & 1u) * 4 + (int)(gi & 3u), lyi = qy + (int)(grp >> 1) * 4 + (int)(gi >> 2);
     const int px = bx + lxi, py = by + lyi;
     const bool inside = px < f.width && py < f.height;
     const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
     const float fbx = (float)bx, fby = (float)by;
-    // pixel-centre range of this wave's quadrant (tile-local)
-    const float qx0 = (float)qx + 0.5f, qx1 = (float)qx + 7.5f, qy0 = (float)qy + 0.5f, qy1 = (float)qy + 7.5f;
+    // pixel-centre ranges (tile-local) of the left/right and top/bottom halves of this wave's quadrant
+    const float xl0 = (float)qx + 0.5f, xl1 = (float)qx + 3.5f, xr0 = (float)qx + 4.5f, xr1 = (float)qx + 7.5f;
+    const float yt0 = (float)qy + 0.5f, yt1 = (float)qy + 3.5f, yb0 = (float)qy + 4.5f, yb1 = (float)qy + 7.5f;
+    uint8_t* const wlist = &s_list[wave][0][0];
+    const uint8_t* const my_list = &s_list[wave][grp][0];
     uint2 rg = ranges[tile];
     rg.x += seg_idx * seg;
     rg.y = min(rg.y, rg.x + seg);
@@ -591,8 +666,15 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
     if (DEPTH && inside) dbuf = bg_depth[(size_t)py * f.width + px];
     const float t_eps = f.t_eps;
     bool wave_live = true;
+    // Masked walk steps (past a sub-block list's end) still read a record through a stale list byte; the
+    // blend is predicated with a zero weight, and 0 * x is only harmless for finite x.  So every LDS record a
+    // stale index can name must hold finite data: zero-fill once (each lane its own entry; staging overwrites).
+    s_q0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_q2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (uint32_t base = rg.x; base < rg.y; base += 256u) {
         const uint32_t n = min(256u, rg.y - base);
+        if (f.dbg_flags & 4) break;                       // ablation: no staging at all
         if (tid < n) {
             const uint32_t slot = vals[base + tid];
             const float4* rp = reinterpret_cast<const float4*>(recs + slot);
@@ -610,57 +692,70 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
             s_q3[tid] = make_float4(ox - c.y, ox + c.y, oy - c.z, oy + c.z);     // pixel bbox, tile-local
         }
         __syncthreads();
-        if (wave_live) {
+        if (wave_live && !(f.dbg_flags & 2)) {             // ablation bit 2: stage only
+            // bin: append this batch's hits to the four sub-block lists (list order preserved)
+            uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                // which staged records of this 64-chunk can touch this wave's quadrant
                 const uint32_t idx = (uint32_t)c * 64u + lane;
-                bool hit = false;
+                bool hl = false, hr = false, ht = false, hb = false;
                 if (idx < n) {
-                    const float4 bb = s_q3[idx];
-                    hit = bb.y >= qx0 && bb.x <= qx1 && bb.w >= qy0 && bb.z <= qy1;
+                    const float4 bb = s_q3[idx];                     // (x_lo, x_hi, y_lo, y_hi) of the pixel-centre box
+                    hl = bb.y >= xl0 && bb.x <= xl1; hr = bb.y >= xr0 && bb.x <= xr1;
+                    ht = bb.w >= yt0 && bb.z <= yt1; hb = bb.w >= yb0 && bb.z <= yb1;
                 }
-                const unsigned long long mask = __ballot(hit);
-                if (mask == 0ull) continue;
-                // Compact the hits into a lane-indexed list: lane i of `list` = LDS index of the i-th hit
-                // (the non-hit lanes fill the tail, so every entry is a valid index and the one-ahead
-                // prefetch below never needs a guard).  The scalar unit is shared by the CU's four SIMDs,
-                // so the walk is a plain counted loop: v_readlane for the index, no mask arithmetic.
-                const uint32_t nh = (uint32_t)__popcll(mask);
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const uint32_t pos = hit ? below : nh + (lane - below);
-                const int list = __builtin_amdgcn_ds_permute((int)(pos << 2), (int)idx);
-                uint32_t k = (uint32_t)__builtin_amdgcn_readlane(list, 0);
-                float4 q0 = s_q0[k], q1 = s_q1[k], q2 = s_q2[k];
-                for (uint32_t i = 0; i < nh; i++) {
-                    const uint32_t kn = (uint32_t)__builtin_amdgcn_readlane(list, (int)min(i + 1u, 63u));
-                    const float4 n0 = s_q0[kn], n1 = s_q1[kn], n2 = s_q2[kn];      // prefetch hit i+1
-                    // F4: per-pixel
-                    const float pu_y = fmaf(q0.y, ly, q0.z);
-                    const float pv_y = fmaf(q1.y, ly, q1.z);
-                    const float ppx = fmaf(q0.x, lx, pu_y);
-                    const float ppy = fmaf(q1.x, lx, pv_y);
-                    const float r2 = fmaf(ppy, ppy, ppx * ppx);
-                    bool cover = r2 <= 4.0f;
-                    if (DEPTH) cover = cover && q1.w < dbuf;
-                    if (EARLY) cover = cover && T >= t_eps;
-#ifdef GSWT_STATS
-                    { unsigned long long cm = __ballot(cover);
-                      if (lane == 0) { atomicAdd(&g_stats[0], 1ull); atomicAdd(&g_stats[1], (unsigned long long)__popcll(cm)); if (cm == 0ull) atomicAdd(&g_stats[2], 1ull); } }
-#endif
-                    if (__ballot(cover) != 0ull) {          // wave-uniform skip; lanes are predicated, not masked
-                        const float e = __builtin_amdgcn_exp2f(r2 * -1.4426950408889634f) * q0.w;
-                        const float Bv = cover ? e : 0.0f;
-                        const float wgt = T * Bv;
-                        ar = fmaf(wgt, q2.x, ar);
-                        ag = fmaf(wgt, q2.y, ag);
-                        ab = fmaf(wgt, q2.z, ab);
-                        T = T - wgt;
-                    }
-                    q0 = n0; q1 = n1; q2 = n2;
+                const bool h0 = hl && ht, h1 = hr && ht, h2 = hl && hb, h3 = hr && hb;
+                const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+#define GSWT_APPEND(H, M, CNT, G)                                                                                         \
+                if (M) {                                                                                                    \
+                    if (H) wlist[(G) * 260u + (CNT) + __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))] = (uint8_t)idx; \
+                    CNT += (uint32_t)__popcll(M);                                                                           \
                 }
-                if (EARLY && __ballot(T >= t_eps) == 0ull) { wave_live = false; break; }   // whole wave saturated
+                GSWT_APPEND(h0, m0, cnt0, 0u) GSWT_APPEND(h1, m1, cnt1, 1u) GSWT_APPEND(h2, m2, cnt2, 2u) GSWT_APPEND(h3, m3, cnt3, 3u)
+#undef GSWT_APPEND
             }
+            const uint32_t n_mine = grp == 0u ? cnt0 : grp == 1u ? cnt1 : grp == 2u ? cnt2 : cnt3;
+            const uint32_t n_max = max(max(cnt0, cnt1), max(cnt2, cnt3));
+            // walk: one splat per 16-lane group per step.  Two-deep software pipeline, unrolled x2 so the
+            // two record register sets (A, B) never need copying: the list byte is fetched two steps
+            // ahead, the record one step ahead (entries past a list's end are stale but in-range; the
+            // step is masked by `i < n_mine`).
+#define GSWT_STEP(Q0, Q1, Q2, I)                                                                        \
+            {                                                                                           \
+                const float pu_y = fmaf(Q0.y, ly, Q0.z);                                                \
+                const float pv_y = fmaf(Q1.y, ly, Q1.z);                                                \
+                const float ppx = fmaf(Q0.x, lx, pu_y);                                                 \
+                const float ppy = fmaf(Q1.x, lx, pv_y);                                                 \
+                const float r2 = fmaf(ppy, ppy, ppx * ppx);                                             \
+                bool cover = ((I) < n_mine) && r2 <= 4.0f;                                              \
+                if (DEPTH) cover = cover && Q1.w < dbuf;                                                \
+                if (EARLY) cover = cover && T >= t_eps;                                                 \
+                GSWT_STAT_STEP(cover)                                                                   \
+                if (__ballot(cover) != 0ull) { /* wave-uniform skip; lanes are predicated, not masked */ \
+                    const float e = __builtin_amdgcn_exp2f(r2 * -1.4426950408889634f) * Q0.w;           \
+                    const float Bv = cover ? e : 0.0f;                                                  \
+                    const float wgt = T * Bv;                                                           \
+                    ar = fmaf(wgt, Q2.x, ar);                                                           \
+                    ag = fmaf(wgt, Q2.y, ag);                                                           \
+                    ab = fmaf(wgt, Q2.z, ab);                                                           \
+                    T = T - wgt;                                                                        \
+                }                                                                                       \
+            }
+            if (!(f.dbg_flags & 1) && n_max) {
+                uint32_t kA = my_list[0], kB = my_list[1];
+                float4 a0 = s_q0[kA], a1 = s_q1[kA], a2 = s_q2[kA];
+                for (uint32_t i = 0; i < n_max; i += 2u) {
+                    const float4 b0 = s_q0[kB], b1 = s_q1[kB], b2 = s_q2[kB];   // record of step i+1
+                    kA = my_list[i + 2u];                                          // index of step i+2
+                    GSWT_STEP(a0, a1, a2, i)
+                    if (i + 1u >= n_max) break;
+                    a0 = s_q0[kA]; a1 = s_q1[kA]; a2 = s_q2[kA];                   // record of step i+2
+                    kB = my_list[i + 3u];                                          // index of step i+3
+                    GSWT_STEP(b0, b1, b2, i + 1u)
+                }
+            }
+#undef GSWT_STEP
+            if (EARLY && __ballot(T >= t_eps) == 0ull) wave_live = false;   // whole wave saturated
         }
         if (EARLY) { if (__syncthreads_and(wave_live ? 0 : 1)) break; }
         else __syncthreads();
@@ -696,7 +791,9 @@ __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* 
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const int lxi = (int)(wave & 1u) * 8 + (int)(lane & 7u), lyi = (int)(wave >> 1) * 8 + (int)(lane >> 3);
+    const uint32_t grp = lane >> 4, gi = lane & 15u;      // same lane -> pixel map as k_composite
+    const int lxi = (int)(wave & 1u) * 8 + (int)(grp & 1u) * 4 + (int)(gi & 3u);
+    const int lyi = (int)(wave >> 1) * 8 + (int)(grp >> 1) * 4 + (int)(gi >> 2);
     const int px = tx * kTile + lxi, py = ty * kTile + lyi;
     if (px >= f.width || py >= f.height) return;
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
@@ -732,17 +829,26 @@ __global__ void k_unshard(const float4* __restrict__ gathered, float4* __restric
 }
 
 // ---- launch wrappers (called from gswt_api.hip) -------------------------------------
+void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled)
+{
+    if (n_draws == 0) return;
+    hipLaunchKernelGGL(k_cull, dim3((n_draws + 255) / 256), dim3(256), 0, s, f, draws, n_draws, draw_culled);
+}
+
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
-                    const float* hmap, uint2* rects, Rec* recs, uint32_t* block_sums, unsigned long long* counters, Varyings* dbg)
+                    const float* hmap, const uint32_t* draw_culled, uint2* rects, Rec* recs, uint32_t* block_sums,
+                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg)
 {
     if (n_chunks == 0) return;
+    const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs x n_super][visible x n_super], zeroed by the caller
     if (debug)
         hipLaunchKernelGGL(k_project<true>, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,
-                           merged_map, tex, hmap, rects, recs, block_sums, counters, dbg);
+                           merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg);
     else
         hipLaunchKernelGGL(k_project<false>, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,
-                           merged_map, tex, hmap, rects, recs, block_sums, counters, dbg);
+                           merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters);
 }
 
 // exclusive scan of `n` u32 in `data` -> `out` (may alias), total -> *total_out.
@@ -762,52 +868,54 @@ void launch_scan(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, uin
     hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)nb1), dim3(256), 0, s, in, out, n, p1);
 }
 
-void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* rects, const uint32_t* block_off,
-                 uint32_t* keys, uint32_t* vals)
+void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* rects, const uint32_t* block_sums,
+                 const uint32_t* super_sums, uint32_t pair_cap, unsigned long long* counters, uint32_t* keys, uint32_t* vals)
 {
     if (n_chunks == 0) return;
-    hipLaunchKernelGGL(k_emit, dim3(n_chunks), dim3(256), 0, s, f, rects, block_off, keys, vals);
+    hipLaunchKernelGGL(k_emit, dim3(n_chunks), dim3(256), 0, s, f, rects, block_sums, super_sums, pair_cap, counters, keys, vals);
 }
 
-// Sorts (keys, vals) by key bits [0, key_bits); result ends in (keys_a, vals_a) or (keys_b, vals_b):
-// returns 0 if in a, 1 if in b.  ghist: 256 * nblk u32 (+ scan workspace after it).
-int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n,
-                int key_bits, uint32_t* ghist, uint32_t* scan_ws, uint32_t* scratch_total)
+// Sorts (keys, vals) by key bits [0, key_bits); the pair count is read on the device (*n_ptr), grids are
+// sized for `n_cap`.  Result ends in (keys_a, vals_a) or (keys_b, vals_b): returns 0 if in a, 1 if in b.
+int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n_cap,
+                const unsigned long long* n_ptr, int key_bits, uint32_t* ghist, uint32_t* scan_ws, uint32_t* scratch_total)
 {
-    if (n == 0) return 0;
-    uint32_t nblk = (n + kSortBlock - 1) / kSortBlock;
+    if (n_cap == 0) return 0;
+    uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock;
     int cur = 0;
     for (int shift = 0; shift < key_bits; shift += 8) {
         uint32_t nbits = (uint32_t)((key_bits - shift) < 8 ? (key_bits - shift) : 8);
         uint32_t mask = (1u << nbits) - 1u;
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, ki, n, (uint32_t)shift, mask, ghist, nblk);
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, ghist, nblk);
         launch_scan(s, ghist, ghist, (size_t)256 * nblk, scratch_total, scan_ws);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, ki, vi, ko, vo, n, (uint32_t)shift, mask, nbits, ghist, nblk);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, nblk);
         cur ^= 1;
     }
     return cur;
 }
 
-void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n, uint2* ranges, uint32_t n_tiles)
+void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const unsigned long long* n_ptr, uint2* ranges, uint32_t n_tiles)
 {
     hipMemsetAsync(ranges, 0, (size_t)n_tiles * sizeof(uint2), s);
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_ranges, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, ranges);
+    if (n_cap == 0) return;
+    hipLaunchKernelGGL(k_ranges, dim3((n_cap + 255) / 256), dim3(256), 0, s, keys, n_ptr, n_cap, ranges);
 }
 
 // ranges -> per-tile segment counts -> item_base (exclusive scan, item_base[n_tiles] = #items) ->
 // k_composite over an upper bound of items -> k_combine.
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
                       const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
-                      uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint32_t* scan_ws, float4* partials)
+                      uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint32_t* scan_ws, float4* partials,
+                      hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     if (n_tiles == 0) return;
     hipLaunchKernelGGL(k_items, dim3((n_tiles + 255) / 256), dim3(256), 0, s, ranges, n_tiles, seg, item_base);
     launch_scan(s, item_base, item_base, (size_t)n_tiles, item_base + n_tiles, scan_ws);
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0;
+    if (ev_begin) hipEventRecord(ev_begin, s);
 #define GSWT_LAUNCH_COMPOSITE(E, D)                                                                                         \
     hipLaunchKernelGGL((k_composite<E, D>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, seg, vals, recs, bg_rgba, \
                        bg_depth, out, partials, n_tiles, out_rows)
@@ -816,6 +924,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     else if (depth) GSWT_LAUNCH_COMPOSITE(false, true);
     else GSWT_LAUNCH_COMPOSITE(false, false);
 #undef GSWT_LAUNCH_COMPOSITE
+    if (ev_end) hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows);
 }
 

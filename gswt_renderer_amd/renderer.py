@@ -156,7 +156,7 @@ class GSWTRenderer:
     def timings(self) -> dict:
         t = L.Timings()
         self._check(self._lib.gswt_last_timings(self._h, C.byref(t)))
-        return {k: getattr(t, k) for k, _ in L.Timings._fields_ if k != "_pad"}
+        return {k: getattr(t, k) for k, _ in L.Timings._fields_ if not k.startswith("_pad")}
 
     VARYINGS_DTYPE = np.dtype([("visible", "<i4"), ("ndc", "<f4", 2), ("depth", "<f4"), ("major", "<f4", 2),
                                ("minor", "<f4", 2), ("rgba", "<f4", 4)])

@@ -140,6 +140,8 @@ typedef struct {
     uint64_t n_pairs;     /* P: (splat, 16x16 screen tile) pairs  */
     uint32_t n_tiles;     /* screen tiles composited by this ctx  */
     uint32_t _pad;
+    float ms_composite_kernel; /* k_composite alone (ms_composite also covers work-item setup + k_combine) */
+    float _pad2;
 } gswt_timings;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
@@ -157,7 +159,8 @@ GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
  *   are identical (gswt.wgsl:38-42 discards the other LOD), only the entry count differs.
  * DEBUG_VARYINGS: keep vs_main's per-entry outputs for gswt_debug_read_projected. */
 enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
-       GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 512) */ };
+       GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 512) */,
+       GSWT_OPT_DEBUG_FLAGS = 4 /* compositor ablation bits for profiling; output is wrong when nonzero */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data
