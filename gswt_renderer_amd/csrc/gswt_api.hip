@@ -22,14 +22,18 @@
 #include <vector>
 
 namespace gswt {
-void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*);
+void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t);
+size_t radix_ws_words(uint32_t, int);
+void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long long*, const uint2*, const Rec*, const uint32_t*,
+                       uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
+                       unsigned long long*, uint32_t*, uint32_t*);
+void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, const uint32_t*, const uint32_t*,
                     const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, uint32_t*, uint32_t*,
                     unsigned long long*, Varyings*);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
                  uint32_t*, uint32_t*);
-int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*,
-                uint32_t*, uint32_t*);
+int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*);
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint32_t*, float4*, hipEvent_t, hipEvent_t);
@@ -92,6 +96,7 @@ struct gswt_ctx {
     uint32_t pair_cap = 0;                 // capacity the pair buffers / grids are sized for (grows on overflow)
     DevBuf<uint2> ranges;
     DevBuf<uint32_t> item_base;
+    DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x n_slots key/val ping-pong + per-block counts
     DevBuf<float4> partials;
     DevBuf<unsigned long long> counters;   // [0] visible splats, [1] pairs, [2] scan scratch, [3] pair-capacity overflow flag
     DevBuf<float4> bg_rgba, out_img;
@@ -169,7 +174,7 @@ void gswt_destroy(gswt_ctx* c)
     c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release();
     c->merged_list.release(); c->merged_map.release(); c->rects.release(); c->recs.release(); c->block_sums.release();
     c->scan_ws.release(); c->super_sums.release(); c->draw_culled.release(); c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release();
-    c->ghist.release(); c->ranges.release(); c->item_base.release(); c->partials.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
+    c->ghist.release(); c->ranges.release(); c->item_base.release(); c->partials.release(); c->depth_ws.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
     c->bg_depth.release(); c->dbg.release();
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -389,7 +394,8 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
         return fail(c, GSWT_ERR_STATE, "gswt_render: surface_type HeightMap without gswt_configure height map");
     if (su->surface_type > 1u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: surface_type %u not supported yet", su->surface_type);
     if (su->draw_mode != 0u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: debug draw modes are not part of the hot path");
-    if (cfg->order_mode != GSWT_ORDER_REFERENCE) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: order mode %d not supported yet", cfg->order_mode);
+    if (cfg->order_mode != GSWT_ORDER_REFERENCE && cfg->order_mode != GSWT_ORDER_DEPTH)
+        return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: unknown order mode %d", cfg->order_mode);
     const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
     if (sc > 1 && (cfg->shard_index < 0 || cfg->shard_index >= sc)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: bad shard index");
     hipSetDevice(c->device);
@@ -460,29 +466,49 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
         const uint32_t cap = c->pair_cap;
         HIP_TRY(c, c->keys_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->keys_b.ensure((size_t)cap + 1));
         HIP_TRY(c, c->vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->vals_b.ensure((size_t)cap + 1));
-        const uint32_t nblk = (cap + 4095) / 4096;
-        HIP_TRY(c, c->ghist.ensure((size_t)256 * nblk + 1));
-        HIP_TRY(c, c->scan_ws.ensure((size_t)256 * nblk / 1024 + (size_t)n_tiles / 1024 + 4096));
+        const size_t n_super2 = 2 * ((size_t)c->n_chunks / 256 + 1);
+        const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
+        const uint32_t n_slots = c->n_chunks * (uint32_t)kChunk;
+        const size_t depth_radix_words = depth_order ? radix_ws_words(n_slots, 32) : 0;
+        const size_t radix_words = radix_ws_words(cap, key_bits) + depth_radix_words;
+        if (depth_order) {
+            HIP_TRY(c, c->depth_ws.ensure(4 * (size_t)n_slots + (size_t)c->n_chunks + 16));
+            HIP_TRY(c, c->scan_ws.ensure((size_t)c->n_chunks / 1024 + 4096));
+        }
+        // one contiguous u32 region cleared by k_cull: [counters: 16][super_sums: n_super2][radix histograms]
+        HIP_TRY(c, c->ghist.ensure(16 + n_super2 + radix_words + 16));
+        uint32_t* const zero_a = c->ghist.p;
+        unsigned long long* const d_counters = reinterpret_cast<unsigned long long*>(zero_a);
+        uint32_t* const d_super = zero_a + 16;
+        uint32_t* const d_radix = d_super + n_super2;
         const uint32_t seg = (uint32_t)c->opt_segment;
         HIP_TRY(c, c->item_base.ensure((size_t)n_tiles + 2));
         HIP_TRY(c, c->partials.ensure(((size_t)n_tiles + cap / seg + 1) * 256));
-        unsigned long long* const d_P = c->counters.p + 1;
-        // ---- cull + project
+        unsigned long long* const d_P = d_counters + 1;
+        // ---- cull (+ clears the frame's accumulators) + project
         HIP_TRY(c, hipEventRecord(c->ev[0], s));
-        HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, 8 * sizeof(unsigned long long), s));
-        HIP_TRY(c, hipMemsetAsync(c->super_sums.p, 0, 2 * ((size_t)c->n_chunks / 256 + 1) * 4, s));
-        launch_cull(s, f, c->draws.p, c->n_draws, c->draw_culled.p);
+        launch_cull(s, f, c->draws.p, c->n_draws, c->draw_culled.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
+                    reinterpret_cast<uint32_t*>(c->ranges.p), (uint32_t)n_tiles * 2u);
         launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
-                       c->tex.p, c->hmap.p, c->draw_culled.p, c->rects.p, c->recs.p, c->block_sums.p, c->super_sums.p,
-                       c->counters.p, c->dbg.p);
+                       c->tex.p, c->hmap.p, c->draw_culled.p, c->rects.p, c->recs.p, c->block_sums.p, d_super,
+                       d_counters, c->dbg.p);
         HIP_TRY(c, hipEventRecord(c->ev[1], s));
         HIP_TRY(c, hipEventRecord(c->ev[2], s));
         // ---- emit
-        launch_emit(s, f, c->n_chunks, c->rects.p, c->block_sums.p, c->super_sums.p, cap, c->counters.p, c->keys_a.p, c->vals_a.p);
+        if (!depth_order) {
+            launch_emit(s, f, c->n_chunks, c->rects.p, c->block_sums.p, d_super, cap, d_counters, c->keys_a.p, c->vals_a.p);
+        } else {
+            // d_counters[4] = n_slots (the radix kernels read their item count from device memory)
+            const unsigned long long ns64 = n_slots;
+            HIP_TRY(c, hipMemcpyAsync(d_counters + 4, &ns64, 8, hipMemcpyHostToDevice, s));
+            uint32_t* dw = c->depth_ws.p;
+            launch_emit_depth(s, f, n_slots, d_counters + 4, c->rects.p, c->recs.p, c->block_sums.p, dw, dw + n_slots, dw + 2 * (size_t)n_slots,
+                              dw + 3 * (size_t)n_slots, d_radix + radix_ws_words(cap, key_bits), dw + 4 * (size_t)n_slots, c->scan_ws.p,
+                              reinterpret_cast<uint32_t*>(d_counters + 2), cap, d_counters, c->keys_a.p, c->vals_a.p);
+        }
         HIP_TRY(c, hipEventRecord(c->ev[3], s));
         // ---- stable sort on the tile bits
-        int where = launch_sort(s, c->keys_a.p, c->vals_a.p, c->keys_b.p, c->vals_b.p, cap, d_P, key_bits, c->ghist.p, c->scan_ws.p,
-                                reinterpret_cast<uint32_t*>(c->counters.p + 2));
+        int where = launch_sort(s, c->keys_a.p, c->vals_a.p, c->keys_b.p, c->vals_b.p, cap, d_P, key_bits, d_radix);
         const uint32_t* keys_sorted = where ? c->keys_b.p : c->keys_a.p;
         const uint32_t* vals_sorted = where ? c->vals_b.p : c->vals_a.p;
         HIP_TRY(c, hipEventRecord(c->ev[4], s));
@@ -491,11 +517,11 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
         HIP_TRY(c, hipEventRecord(c->ev[5], s));
         // ---- composite
         launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows, seg, cap,
-                         c->item_base.p, c->scan_ws.p, c->partials.p, c->ev[7], c->ev[8]);
+                         c->item_base.p, nullptr, c->partials.p, c->ev[7], c->ev[8]);
         c->last_n_tiles = (uint32_t)n_tiles;
         HIP_TRY(c, hipEventRecord(c->ev[6], s));
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(host_counters, c->counters.p, sizeof(host_counters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(host_counters, d_counters, sizeof(host_counters), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         if (host_counters[1] >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: %llu pairs exceed 2^32", host_counters[1]);
         if (host_counters[3] == 0 && host_counters[1] <= cap) break;

@@ -62,10 +62,14 @@ __device__ __forceinline__ int owned_rows(int ty0, int ty1, int index, int count
 // ------------------------------------------------------------------------------------
 // k_cull: the CPU viewport culling + lod_enable skip of renderer.rs:472-497, one thread per draw.
 // ------------------------------------------------------------------------------------
+// Also clears the per-frame accumulators (first kernel of the frame; saves three memset launches).
 __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __restrict__ draws, uint32_t n_draws,
-                                              uint32_t* __restrict__ draw_culled)
+                                              uint32_t* __restrict__ draw_culled, uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
+                                              uint32_t* __restrict__ zero_b, uint32_t n_zero_b)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t j = i; j < n_zero_a; j += gridDim.x * 256u) zero_a[j] = 0u;
+    for (uint32_t j = i; j < n_zero_b; j += gridDim.x * 256u) zero_b[j] = 0u;
     if (i >= n_draws) return;
     const DrawDev& d = draws[i];
     uint32_t culled = 0;
@@ -210,6 +214,7 @@ __global__ __launch_bounds__(256) void k_project(
                 q[rr] = ((f.GP[rr] * cv[0] + f.GP[4 + rr] * cv[1]) + f.GP[8 + rr] * cv[2]) + f.GP[12 + rr] * cv[3];
             float clip = 1.2f * q[3];
             if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) break;
+            if (f.dbg_flags & 16) break;               // ablation: stop after the frustum cull
             // A7 :169-205
             float K[9];
             {
@@ -316,6 +321,7 @@ __global__ __launch_bounds__(256) void k_project(
                 int tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
                 int rows = owned_rows(ty0, ty1, f.shard_index, f.shard_count);
                 count = (uint32_t)((tx1 - tx0 + 1) * rows);
+                if (f.dbg_flags & 8) count = 0;        // ablation: no record / rect stores, no pairs
                 if (count) {
                     my_rect = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
                     // colour stays packed (bytes / 255 is re-evaluated by the compositor's staging lane, same
@@ -497,9 +503,16 @@ __device__ __forceinline__ uint32_t clamped_count(const unsigned long long* n_pt
 constexpr int kSortItems = 16;   // per thread
 constexpr int kSortBlock = 256 * kSortItems;
 
+// Per pass: k_radix_hist leaves, for every digit d, the per-workgroup counts ghist[d][blk], the sums over
+// groups of 32 workgroups gsup[d][blk >> 5] and the digit totals gtot[d] (integer atomics, spread over
+// 256 x nblk/32 addresses).  k_radix_scatter derives its global offsets from those directly -- digit d's
+// base = sum of gtot[< d] + gsup[d][< blk >> 5] + ghist[d][same group, < blk] -- so no scan kernel runs.
+constexpr uint32_t kSupShift = 5;
+
 __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
                                                     uint32_t n_cap, uint32_t shift, uint32_t mask, uint32_t* __restrict__ ghist,
-                                                    uint32_t nblk)
+                                                    uint32_t* __restrict__ gsup, uint32_t* __restrict__ gtot, uint32_t nblk,
+                                                    uint32_t nsup)
 {
     const uint32_t n = clamped_count(n_ptr, n_cap);
     __shared__ uint32_t s_h[256];
@@ -512,18 +525,27 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__
         if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    ghist[threadIdx.x * nblk + blockIdx.x] = s_h[threadIdx.x];
+    const uint32_t cnt = s_h[threadIdx.x];
+    // digit-minor layouts ([blk][256], [group][256]) so that one workgroup's reads and writes are contiguous
+    ghist[blockIdx.x * 256u + threadIdx.x] = cnt;
+    if (cnt) {
+        atomicAdd(&gsup[(blockIdx.x >> kSupShift) * 256u + threadIdx.x], cnt);
+        atomicAdd(&gtot[threadIdx.x], cnt);
+    }
+    (void)nblk; (void)nsup;
 }
 
 __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
-                                                       uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist_scanned,
-                                                       uint32_t nblk)
+                                                       uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist,
+                                                       const uint32_t* __restrict__ gsup, const uint32_t* __restrict__ gtot,
+                                                       uint32_t nblk, uint32_t nsup)
 {
     const uint32_t n = clamped_count(n_ptr, n_cap);
     if (blockIdx.x * kSortBlock >= n) return;
     __shared__ uint32_t s_h[4][256];
+    __shared__ uint32_t s_w[4];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (int k = 0; k < 4; k++) s_h[k][threadIdx.x] = 0;
     __syncthreads();
@@ -538,10 +560,15 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
             atomicAdd(&s_h[w][(key[k] >> shift) & mask], 1u);
         }
     }
-    __syncthreads();
-    {   // digit = threadIdx.x: turn per-wave counts into per-wave global bases
-        uint32_t b = ghist_scanned[threadIdx.x * nblk + blockIdx.x];
-        for (int k = 0; k < 4; k++) { uint32_t c = s_h[k][threadIdx.x]; s_h[k][threadIdx.x] = b; b += c; }
+    {   // digit = threadIdx.x: global base of this workgroup's first item with that digit
+        const uint32_t d = threadIdx.x;
+        uint32_t tot;
+        uint32_t b = block_excl_scan(gtot[d], s_w, &tot);               // items with a smaller digit (includes a barrier)
+        const uint32_t sb = blockIdx.x >> kSupShift;
+        for (uint32_t j = 0; j < sb; j++) b += gsup[j * 256u + d];       // earlier groups of 32 workgroups
+        for (uint32_t j = sb << kSupShift; j < blockIdx.x; j++) b += ghist[j * 256u + d];   // earlier workgroups of this group
+        (void)nblk; (void)nsup;
+        for (int k = 0; k < 4; k++) { uint32_t c = s_h[k][d]; s_h[k][d] = b; b += c; }      // per-wave bases
     }
     __syncthreads();
     volatile uint32_t* h = s_h[w];
@@ -565,6 +592,81 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
             __builtin_amdgcn_wave_barrier();
             keys_out[pos + rank] = key[k];
             vals_out[pos + rank] = val[k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// GSWT_ORDER_DEPTH: true global per-splat depth order.  k_depth_keys builds (depth bits, slot) for every
+// slot (0xFFFFFFFF for slots without pairs), the radix sort above orders them on all 32 bits (stable, so
+// equal depths keep composite order), and k_emit_perm emits the pairs in that order; the tile-bit sort
+// and the compositor are unchanged.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ rects, const Rec* __restrict__ recs,
+                                                    const uint32_t* __restrict__ block_sums, uint32_t n_slots,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot >= n_slots) return;
+    uint32_t key = 0xFFFFFFFFu;
+    if (block_sums[slot >> 8] != 0u) {
+        const uint2 rc = rects[slot];
+        if ((rc.x >> 16) >= (rc.x & 0xFFFFu)) key = __float_as_uint(recs[slot].depth);   // depth in [0, 1]: bit order = value order
+    }
+    keys[slot] = key;
+    vals[slot] = slot;
+}
+
+// pair count of every 256-position block of the depth-ordered slot list
+__global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2* __restrict__ rects, const uint32_t* __restrict__ sorted_keys,
+                                                     const uint32_t* __restrict__ perm, uint32_t n_slots, uint32_t* __restrict__ block_cnt)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    uint32_t count = 0;
+    if (pos < n_slots && sorted_keys[pos] != 0xFFFFFFFFu) {
+        const uint2 rc = rects[perm[pos]];
+        const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
+        count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
+    }
+    uint32_t tot;
+    (void)block_excl_scan(count, s_w, &tot);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* __restrict__ rects, const uint32_t* __restrict__ sorted_keys,
+                                                   const uint32_t* __restrict__ perm, uint32_t n_slots,
+                                                   const uint32_t* __restrict__ block_off, uint32_t pair_cap,
+                                                   unsigned long long* __restrict__ counters, uint32_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    uint32_t count = 0, slot = 0;
+    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
+    if (pos < n_slots && sorted_keys[pos] != 0xFFFFFFFFu) {
+        slot = perm[pos];
+        const uint2 rc = rects[slot];
+        tx0 = rc.x & 0xFFFFu; tx1 = rc.x >> 16; ty0 = rc.y & 0xFFFFu; ty1 = rc.y >> 16;
+        count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
+    }
+    uint32_t tot;
+    const uint32_t chunk_base = block_off[blockIdx.x];
+    uint32_t off = chunk_base + block_excl_scan(count, s_w, &tot);
+    if ((unsigned long long)chunk_base + tot > (unsigned long long)pair_cap) {
+        if (threadIdx.x == 0 && tot) atomicOr(&counters[3], 1ull);
+        return;
+    }
+    if (count == 0) return;
+    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
+    int ty = ty0;
+    if (sc > 1) ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc;
+    for (; ty <= ty1; ty += sc) {
+        const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
+        for (int tx = tx0; tx <= tx1; tx++) {
+            keys[off] = row + (uint32_t)tx;
+            vals[off] = slot;
+            off++;
         }
     }
 }
@@ -598,14 +700,32 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 // ------------------------------------------------------------------------------------
 // Work items: a tile's pair list is cut into segments of `seg` pairs; item = (tile, segment).
 // seg_count[t] = max(1, ceil(len / seg)) so empty tiles still get one item (they write the background).
-__global__ __launch_bounds__(256) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
-                                               uint32_t* __restrict__ seg_count)
+// item_base[t] = exclusive scan of seg_count, item_base[n_tiles] = number of items.  Single workgroup
+// (n_tiles is a few thousand to a few tens of thousands): one launch instead of count + 3 scan launches.
+__global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
+                                                uint32_t* __restrict__ item_base)
 {
-    int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_tiles) return;
-    uint2 r = ranges[t];
-    uint32_t len = r.y - r.x;
-    seg_count[t] = len == 0 ? 1u : (len + seg - 1u) / seg;
+    __shared__ uint32_t s_w[16];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int t = base + (int)threadIdx.x;
+        uint32_t cnt = 0;
+        if (t < n_tiles) {
+            const uint2 r = ranges[t];
+            const uint32_t len = r.y - r.x;
+            cnt = len == 0 ? 1u : (len + seg - 1u) / seg;
+        }
+        uint32_t inc = wave_incl_scan(cnt, lane);
+        if (lane == 63u) s_w[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (uint32_t i = 0; i < 16u; i++) { if (i < w) wbase += s_w[i]; tot += s_w[i]; }
+        if (t < n_tiles) item_base[t] = carry + wbase + inc - cnt;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) item_base[n_tiles] = carry;
 }
 
 #ifdef GSWT_STATS
@@ -829,10 +949,12 @@ __global__ void k_unshard(const float4* __restrict__ gathered, float4* __restric
 }
 
 // ---- launch wrappers (called from gswt_api.hip) -------------------------------------
-void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled)
+void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled,
+                 uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b)
 {
-    if (n_draws == 0) return;
-    hipLaunchKernelGGL(k_cull, dim3((n_draws + 255) / 256), dim3(256), 0, s, f, draws, n_draws, draw_culled);
+    uint32_t grid = (n_draws + 255) / 256;
+    if (grid < 32) grid = 32;
+    hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, zero_a, n_zero_a, zero_b, n_zero_b);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_chunks,
@@ -877,28 +999,58 @@ void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* 
 
 // Sorts (keys, vals) by key bits [0, key_bits); the pair count is read on the device (*n_ptr), grids are
 // sized for `n_cap`.  Result ends in (keys_a, vals_a) or (keys_b, vals_b): returns 0 if in a, 1 if in b.
+// ws: per pass [ghist 256 x nblk][gsup 256 x nsup][gtot 256]; the gsup/gtot parts must be zero on entry
+// (radix_ws_words() u32 in total, zeroed by k_cull each frame).
+size_t radix_ws_words(uint32_t n_cap, int key_bits)
+{
+    const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
+    const int passes = (key_bits + 7) / 8;
+    return (size_t)passes * ((size_t)256 * nblk + (size_t)256 * nsup + 256);
+}
+
 int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n_cap,
-                const unsigned long long* n_ptr, int key_bits, uint32_t* ghist, uint32_t* scan_ws, uint32_t* scratch_total)
+                const unsigned long long* n_ptr, int key_bits, uint32_t* ws)
 {
     if (n_cap == 0) return 0;
-    uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock;
+    const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
     int cur = 0;
     for (int shift = 0; shift < key_bits; shift += 8) {
         uint32_t nbits = (uint32_t)((key_bits - shift) < 8 ? (key_bits - shift) : 8);
         uint32_t mask = (1u << nbits) - 1u;
+        uint32_t* ghist = ws; uint32_t* gsup = ghist + (size_t)256 * nblk; uint32_t* gtot = gsup + (size_t)256 * nsup;
+        ws = gtot + 256;
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, ghist, nblk);
-        launch_scan(s, ghist, ghist, (size_t)256 * nblk, scratch_total, scan_ws);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, nblk);
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, ghist, gsup, gtot, nblk, nsup);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,
+                           ghist, gsup, gtot, nblk, nsup);
         cur ^= 1;
     }
     return cur;
 }
 
+// GSWT_ORDER_DEPTH front end: depth keys -> 32-bit radix sort -> per-block counts -> scan -> emission in depth order.
+// dk_a/dv_a/dk_b/dv_b: n_slots u32 each; ws: radix_ws_words(n_slots, 32) zeroed words; n_slots_dev: device u64 = n_slots.
+void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_slots, const unsigned long long* n_slots_dev, const uint2* rects,
+                       const Rec* recs, const uint32_t* block_sums, uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b,
+                       uint32_t* radix_ws, uint32_t* block_cnt, uint32_t* scan_ws, uint32_t* scratch_total, uint32_t pair_cap,
+                       unsigned long long* counters, uint32_t* keys, uint32_t* vals)
+{
+    if (n_slots == 0) return;
+    const uint32_t nb = (n_slots + 255) / 256;
+    hipLaunchKernelGGL(k_depth_keys, dim3(nb), dim3(256), 0, s, rects, recs, block_sums, n_slots, dk_a, dv_a);
+    const int where = launch_sort(s, dk_a, dv_a, dk_b, dv_b, n_slots, n_slots_dev, 32, radix_ws);
+    const uint32_t* sk = where ? dk_b : dk_a;
+    const uint32_t* perm = where ? dv_b : dv_a;
+    hipLaunchKernelGGL(k_perm_counts, dim3(nb), dim3(256), 0, s, f, rects, sk, perm, n_slots, block_cnt);
+    launch_scan(s, block_cnt, block_cnt, nb, scratch_total, scan_ws);
+    hipLaunchKernelGGL(k_emit_perm, dim3(nb), dim3(256), 0, s, f, rects, sk, perm, n_slots, block_cnt, pair_cap, counters, keys, vals);
+}
+
+// `ranges` must be zero on entry (k_cull clears it each frame)
 void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const unsigned long long* n_ptr, uint2* ranges, uint32_t n_tiles)
 {
-    hipMemsetAsync(ranges, 0, (size_t)n_tiles * sizeof(uint2), s);
+    (void)n_tiles;
     if (n_cap == 0) return;
     hipLaunchKernelGGL(k_ranges, dim3((n_cap + 255) / 256), dim3(256), 0, s, keys, n_ptr, n_cap, ranges);
 }
@@ -911,8 +1063,8 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
                       hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     if (n_tiles == 0) return;
-    hipLaunchKernelGGL(k_items, dim3((n_tiles + 255) / 256), dim3(256), 0, s, ranges, n_tiles, seg, item_base);
-    launch_scan(s, item_base, item_base, (size_t)n_tiles, item_base + n_tiles, scan_ws);
+    (void)scan_ws;
+    hipLaunchKernelGGL(k_items, dim3(1), dim3(1024), 0, s, ranges, n_tiles, seg, item_base);
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0;
     if (ev_begin) hipEventRecord(ev_begin, s);

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0.0, shard=None, culling_dist=1.0):
+def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0.0, shard=None, culling_dist=1.0, order_mode=0):
     verts = synth.make_tileset(n_lod=n_lod, n_tile=16, lod0_count=lod0)
     pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer)
     cu, vp = host.camera_uniforms(cam[0], cam[1], (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
@@ -35,12 +35,14 @@ def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0
         rng = np.random.default_rng(5)
         bg_rgba = rng.uniform(0, 1, size=(Hh, W, 4)).astype(np.float32)
         bg_depth = rng.uniform(0.97, 1.0, size=(Hh, W)).astype(np.float32)
-    ref, st = orc.render(ocam.uniforms(), osu, pp.tex, odraws, W, Hh, height_map=hm, bg_rgba=bg_rgba, bg_depth=bg_depth)
+    ref, st = orc.render(ocam.uniforms(), osu, pp.tex, odraws, W, Hh, height_map=hm, bg_rgba=bg_rgba, bg_depth=bg_depth,
+                         order_mode=order_mode)
     kinds = {"plain": 0, "blend": 0, "merged": 0}
     for d in odraws:
         kinds["merged" if d.tile.single_draw else ("blend" if d.tile.changing else "plain")] += 1
     if shard is None:
-        img = pipe.render(cu, W, Hh, bg_rgba=bg_rgba, bg_depth=bg_depth, transmittance_eps=t_eps, culling_dist=culling_dist)
+        img = pipe.render(cu, W, Hh, bg_rgba=bg_rgba, bg_depth=bg_depth, transmittance_eps=t_eps, culling_dist=culling_dist,
+                          order_mode=order_mode)
         t = renderer.timings()
         assert t["n_visible"] == st["n_visible"]
         assert t["n_pairs"] == st["n_pairs16"]
@@ -49,7 +51,8 @@ def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0
         rows_p = renderer.shard_rows_padded(Hh, n)
         img = np.zeros((Hh, W, 4), dtype=np.float32)
         for r in range(n):
-            part = pipe.render(cu, W, Hh, bg_rgba=bg_rgba, bg_depth=bg_depth, shard=(r, n), culling_dist=culling_dist)
+            part = pipe.render(cu, W, Hh, bg_rgba=bg_rgba, bg_depth=bg_depth, shard=(r, n), culling_dist=culling_dist,
+                               order_mode=order_mode)
             assert part.shape == (rows_p, W, 4)
             for y in range(Hh):
                 ty = y // 16
@@ -120,3 +123,25 @@ def test_moving_camera_sequence(renderer):
         img = pipe.render(cu, W, Hh)
         assert renderer.timings()["n_visible"] == st["n_visible"]
         assert H.max_abs_diff(img, ref) <= TOL, k
+
+
+def test_depth_order_mode(renderer):
+    """GSWT_ORDER_DEPTH (true global per-splat depth sort) against the oracle's depth-order mode, and
+    it really differs from the reference order on interpenetrating tiles."""
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    cam = ((4.2, 1.0, 1.2), (5.0, 3.0, 0.9))
+    img_d, ref_d, _, st = _run_case(renderer, cfg, cam, 320, 240, lod0=2500, order_mode=1)
+    assert st["n_visible"] > 2000
+    assert H.max_abs_diff(img_d, ref_d) <= TOL
+    img_r, ref_r, _, _ = _run_case(renderer, cfg, cam, 320, 240, lod0=2500, order_mode=0)
+    assert H.max_abs_diff(img_r, ref_r) <= TOL
+    assert H.max_abs_diff(ref_d, ref_r) > 1e-3
+
+
+def test_depth_order_sharded_and_background(renderer):
+    cfg = dict(tile_map_half_wh=(2, 2), surface_type=0, lod_max_dist=16.0, tile_sort_type=3, merge_type=2)
+    cam = ((0.5, 0.3, 2.0), (1.0, 3.0, 1.2))
+    full, ref, _, _ = _run_case(renderer, cfg, cam, 200, 150, lod0=1500, order_mode=1, bg=True)
+    assert H.max_abs_diff(full, ref) <= TOL
+    img, _, _, _ = _run_case(renderer, cfg, cam, 200, 150, lod0=1500, order_mode=1, bg=True, shard=3)
+    assert np.array_equal(img, full)
