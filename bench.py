@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--lod0", type=int, default=0, help="override LOD0 splats per tile (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--t-eps", type=float, default=1e-5, help="front-to-back early-out threshold")
+    ap.add_argument("--timing", type=int, default=1, help="hipEvent level: 1 = frame + k_composite (roofline), 2 = every stage")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,42 +113,61 @@ def main():
     r = GSWTRenderer(local_rank)                       # raises when libgswt_hip.so / the GPU is missing
     stream = torch.cuda.Stream(device=dev)
     r.set_stream(stream.cuda_stream)                    # kernels, hipEvents and the all-gather share this stream
+    from gswt_renderer_amd import _lib as L
+    r.set_option(L.GSWT_OPT_TIMING, args.timing)
     wang.upload_to(r)
     r.configure(None)
     r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
     su = wang.scene_uniforms()
     shard = (rank, world) if world > 1 else (0, 1)
     rows = r.shard_rows_padded(H, world) if world > 1 else H
-    out = torch.empty((rows, W, 4), dtype=torch.float32, device=dev)
+    # two frames in flight (gswt_render_async / gswt_render_wait): frame i+1 is queued on the stream while
+    # frame i executes, so the host never idles the GPU between frames; frames alternate output buffers
+    outs = [torch.empty((rows, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    out = outs[0]
     gathered = torch.empty((world * rows, W, 4), dtype=torch.float32, device=dev) if world > 1 else None
-    frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if world > 1 else out
+    frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if world > 1 else None
 
     comp_ms, total_ms, pairs = [], [], []
+    inflight = []
+    last = [None]
 
-    def step():
+    def submit(i):
+        o = outs[i % 2]
         with torch.cuda.stream(stream):
-            r.render(cu, su, W, H, transmittance_eps=args.t_eps, shard=shard, out_device_ptr=out.data_ptr())
+            ticket = r.render_async(cu, su, W, H, o.data_ptr(), transmittance_eps=args.t_eps, shard=shard)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, out)
+                dist.all_gather_into_tensor(gathered, o)
                 r.unshard(gathered.data_ptr(), W, H, world, frame.data_ptr())
+        inflight.append(ticket)
+
+    def collect():
+        r.render_wait(inflight.pop(0))
         t = r.timings()
         comp_ms.append(t["ms_composite_kernel"]); total_ms.append(t["ms_total"]); pairs.append(t["n_pairs"])
-        return t
+        last[0] = t
 
-    for _ in range(args.warmup):
-        step()
+    def run(n):
+        for i in range(n):
+            submit(i)
+            if len(inflight) == 2:
+                collect()
+        while inflight:
+            collect()
+
+    run(args.warmup)
     comp_ms.clear(); total_ms.clear(); pairs.clear()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
+    run(args.steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
+    last = last[0]
+    out = outs[(args.steps - 1) % 2]
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -171,6 +191,7 @@ def main():
                        "transmittance_eps": args.t_eps,
                        "parallelism": f"screen-tile-rows x{world} + RCCL all-gather" if world > 1 else "single GPU"},
             "stage_ms": {k: float(last[k]) for k in ("ms_project", "ms_emit", "ms_sort", "ms_ranges", "ms_composite", "ms_composite_kernel", "ms_total")},
+            "frames_in_flight": 2,
             "roofline": {"bound": "hbm", "kernel": "k_composite", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": comp * 1e3},

@@ -23,6 +23,7 @@ GSWT_OPT_NO_LOD_PREFILTER = 1
 GSWT_OPT_DEBUG_VARYINGS = 2
 GSWT_OPT_SEGMENT = 3
 GSWT_OPT_DEBUG_FLAGS = 4
+GSWT_OPT_TIMING = 5
 
 
 class CameraUniforms(C.Structure):
@@ -90,6 +91,8 @@ SYMBOLS = {
     "gswt_configure": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "gswt_set_draws": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_size_t]),
     "gswt_render": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int]),
+    "gswt_render_async": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
+    "gswt_render_wait": (C.c_int, [_P, C.c_int]),
     "gswt_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "gswt_shard_rows_padded": (C.c_int, [C.c_int, C.c_int]),
     "gswt_unshard": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),

@@ -68,8 +68,32 @@ struct ListRef { uint32_t pair_base, pair_count, self_base, self_count; };
 
 }  // namespace
 
+constexpr int kFrameSlots = 2;
+
+struct FrameArgs {
+    gswt_camera_uniforms cam;
+    gswt_scene_uniforms su;
+    gswt_render_config cfg;
+    int width = 0, height = 0;
+    const float4* d_bg = nullptr;
+    const float* d_bgd = nullptr;
+    float4* d_out = nullptr;
+};
+
+struct FrameSlot {
+    hipEvent_t ev[10] = {};
+    unsigned long long* hc = nullptr;      // pinned host: [0] visible [1] pairs [2] scratch [3] overflow ... [7] staging
+    bool pending = false;
+    FrameArgs args;
+    uint32_t cap = 0;
+    int n_tiles = 0;
+    int timing_level = 0;
+};
+
 struct gswt_ctx {
     int device = 0;
+    FrameSlot slots[kFrameSlots];
+    int next_slot = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
     std::string err;
@@ -106,10 +130,9 @@ struct gswt_ctx {
     int opt_no_prefilter = 0;
     int opt_debug_varyings = 0;
     int opt_dbg_flags = 0;
+    int opt_timing = 2;      // 0: no events, 1: frame + k_composite, 2: every stage
     int opt_segment = 512;   // pairs per compositor work item (multiple of 256); c3 sweep: 512 best
     uint32_t last_n_tiles = 0;
-    // timing
-    hipEvent_t ev[10] = {};
     gswt_timings timings = {};
 };
 
@@ -159,8 +182,12 @@ int gswt_create(int device_id, gswt_ctx** out)
     if (!c) return GSWT_ERR_CAPACITY;
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
-    for (auto& e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+    for (auto& sl : c->slots) {
+        for (auto& e : sl.ev)
+            if (hipEventCreate(&e) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+        if (hipHostMalloc(reinterpret_cast<void**>(&sl.hc), 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+        memset(sl.hc, 0, 8 * sizeof(unsigned long long));
+    }
     if (c->counters.ensure(8) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
     *out = c;
     return GSWT_OK;
@@ -176,7 +203,7 @@ void gswt_destroy(gswt_ctx* c)
     c->scan_ws.release(); c->super_sums.release(); c->draw_culled.release(); c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release();
     c->ghist.release(); c->ranges.release(); c->item_base.release(); c->partials.release(); c->depth_ws.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
     c->bg_depth.release(); c->dbg.release();
-    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    for (auto& sl : c->slots) { for (auto& e : sl.ev) if (e) hipEventDestroy(e); if (sl.hc) hipHostFree(sl.hc); }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -200,6 +227,7 @@ int gswt_set_option(gswt_ctx* c, int key, int value)
     case GSWT_OPT_NO_LOD_PREFILTER: c->opt_no_prefilter = value; c->draws_ready = false; return GSWT_OK;
     case GSWT_OPT_DEBUG_VARYINGS: c->opt_debug_varyings = value; return GSWT_OK;
     case GSWT_OPT_DEBUG_FLAGS: c->opt_dbg_flags = value; return GSWT_OK;
+    case GSWT_OPT_TIMING: c->opt_timing = value; return GSWT_OK;
     case GSWT_OPT_SEGMENT:
         if (value < 256 || value % 256) return fail(c, GSWT_ERR_BAD_ARG, "segment must be a positive multiple of 256");
         c->opt_segment = value; return GSWT_OK;
@@ -379,11 +407,13 @@ int gswt_shard_rows(int height, int shard_index, int shard_count)
     return rows;
 }
 
-int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_uniforms* su, const gswt_render_config* cfg,
-                int width, int height, const float* bg_rgba, const float* bg_depth, int bg_on_device, float* out_rgba,
-                int out_on_device)
+// ---- frame machinery ------------------------------------------------------------------------------
+// A frame is enqueued without any host round trip (enqueue_frame) and collected later (finish_frame).
+// gswt_render = enqueue + finish; gswt_render_async / gswt_render_wait expose the two halves so a caller
+// can queue frame i+1 before collecting frame i (two slots, same stream, executed in order).
+static int validate_frame(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_uniforms* su, const gswt_render_config* cfg,
+                          int width, int height, const void* out_rgba)
 {
-    if (!c) return GSWT_ERR_BAD_ARG;
     if (!cam || !su || !cfg || !out_rgba) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: null argument");
     if (!c->draws_ready) return fail(c, GSWT_ERR_STATE, "gswt_render before gswt_set_draws");
     if (width <= 0 || height <= 0 || width > 65535 * kTile || height > 65535 * kTile)
@@ -398,8 +428,19 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
         return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: unknown order mode %d", cfg->order_mode);
     const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
     if (sc > 1 && (cfg->shard_index < 0 || cfg->shard_index >= sc)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: bad shard index");
-    hipSetDevice(c->device);
+    return GSWT_OK;
+}
+
+// Enqueues every kernel of one frame on the ctx stream.  All pointers in `a` are device pointers.
+static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
+{
+    const FrameArgs& a = sl.args;
+    const gswt_camera_uniforms* cam = &a.cam;
+    const gswt_scene_uniforms* su = &a.su;
+    const gswt_render_config* cfg = &a.cfg;
+    const int width = a.width, height = a.height;
     hipStream_t s = c->stream;
+    const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
 
     Frame f;
     memset(&f, 0, sizeof(f));
@@ -424,7 +465,7 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     memcpy(f.transition_dist, su->transition_dist_vec, 64);
     for (int k = 0; k < 3; k++) { f.height_map_scale[k] = su->height_map_scale[k]; f.scene_scale[k] = su->scene_scale[k]; }
     f.culling_dist = cfg->culling_dist; f.lod_enable_mask = cfg->lod_enable_mask; f.t_eps = cfg->transmittance_eps;
-    f.has_depth = bg_depth ? 1 : 0;
+    f.has_depth = a.d_bgd ? 1 : 0;
     f.width = width; f.height = height;
     f.tiles_x = (width + kTile - 1) / kTile; f.tiles_y = (height + kTile - 1) / kTile;
     f.shard_index = sc > 1 ? cfg->shard_index : 0; f.shard_count = sc;
@@ -435,9 +476,139 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     const int n_tiles = f.tiles_x * (tiles_y_local > 0 ? tiles_y_local : 0);
     const int out_rows = sc > 1 ? gswt_shard_rows_padded(height, sc) : height;
     const size_t out_px = (size_t)out_rows * width;
-    const size_t npx = (size_t)width * height;
+    sl.n_tiles = n_tiles;
+    float4* const d_out = a.d_out;
+    HIP_TRY(c, c->ranges.ensure((size_t)n_tiles + 1));
+    const bool dbg = c->opt_debug_varyings != 0;
+    if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)c->n_entries + 1));
+    if (sc > 1 && out_rows * width > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
 
-    // inputs / outputs
+    // The pair count P is only known on the device.  Everything downstream of k_project is launched
+    // for a capacity `pair_cap` (blocks past the real P do nothing), so a frame needs no host round
+    // trip; the count and an overflow flag travel back with the frame.  If P exceeded the capacity
+    // the buffers grow and the frame is re-run by finish_frame (first frame / sudden scene change only).
+    int key_bits = 1;
+    while ((1 << key_bits) < n_tiles) key_bits++;
+    if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_entries / 4, 1u << 20), 0xFFFFFF00ull);
+    const uint32_t cap = c->pair_cap;
+    sl.cap = cap;
+    HIP_TRY(c, c->keys_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->keys_b.ensure((size_t)cap + 1));
+    HIP_TRY(c, c->vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->vals_b.ensure((size_t)cap + 1));
+    const size_t n_super2 = 2 * ((size_t)c->n_chunks / 256 + 1);
+    const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
+    const uint32_t n_slots = c->n_chunks * (uint32_t)kChunk;
+    const size_t depth_radix_words = depth_order ? radix_ws_words(n_slots, 32) : 0;
+    const size_t radix_words = radix_ws_words(cap, key_bits) + depth_radix_words;
+    if (depth_order) {
+        HIP_TRY(c, c->depth_ws.ensure(4 * (size_t)n_slots + (size_t)c->n_chunks + 16));
+        HIP_TRY(c, c->scan_ws.ensure((size_t)c->n_chunks / 1024 + 4096));
+    }
+    // one contiguous u32 region cleared by k_cull: [counters: 16][super_sums: n_super2][radix histograms]
+    HIP_TRY(c, c->ghist.ensure(16 + n_super2 + radix_words + 16));
+    uint32_t* const zero_a = c->ghist.p;
+    unsigned long long* const d_counters = reinterpret_cast<unsigned long long*>(zero_a);
+    uint32_t* const d_super = zero_a + 16;
+    uint32_t* const d_radix = d_super + n_super2;
+    const uint32_t seg = (uint32_t)c->opt_segment;
+    HIP_TRY(c, c->item_base.ensure((size_t)n_tiles + 2));
+    HIP_TRY(c, c->partials.ensure(((size_t)n_tiles + cap / seg + 1) * 256));
+    unsigned long long* const d_P = d_counters + 1;
+    hipEvent_t* ev = sl.ev;
+    // ---- cull (+ clears the frame's accumulators) + project
+    if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
+    launch_cull(s, f, c->draws.p, c->n_draws, c->draw_culled.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
+                reinterpret_cast<uint32_t*>(c->ranges.p), (uint32_t)n_tiles * 2u);
+    launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
+                   c->tex.p, c->hmap.p, c->draw_culled.p, c->rects.p, c->recs.p, c->block_sums.p, d_super,
+                   d_counters, c->dbg.p);
+    if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
+    // ---- emit
+    if (!depth_order) {
+        launch_emit(s, f, c->n_chunks, c->rects.p, c->block_sums.p, d_super, cap, d_counters, c->keys_a.p, c->vals_a.p);
+    } else {
+        // d_counters[4] = n_slots (the radix kernels read their item count from device memory)
+        sl.hc[7] = n_slots;
+        HIP_TRY(c, hipMemcpyAsync(d_counters + 4, &sl.hc[7], 8, hipMemcpyHostToDevice, s));
+        uint32_t* dw = c->depth_ws.p;
+        launch_emit_depth(s, f, n_slots, d_counters + 4, c->rects.p, c->recs.p, c->block_sums.p, dw, dw + n_slots, dw + 2 * (size_t)n_slots,
+                          dw + 3 * (size_t)n_slots, d_radix + radix_ws_words(cap, key_bits), dw + 4 * (size_t)n_slots, c->scan_ws.p,
+                          reinterpret_cast<uint32_t*>(d_counters + 2), cap, d_counters, c->keys_a.p, c->vals_a.p);
+    }
+    if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
+    // ---- stable sort on the tile bits
+    int where = launch_sort(s, c->keys_a.p, c->vals_a.p, c->keys_b.p, c->vals_b.p, cap, d_P, key_bits, d_radix);
+    const uint32_t* keys_sorted = where ? c->keys_b.p : c->keys_a.p;
+    const uint32_t* vals_sorted = where ? c->vals_b.p : c->vals_a.p;
+    if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[4], s));
+    // ---- ranges
+    launch_ranges(s, keys_sorted, cap, d_P, c->ranges.p, (uint32_t)n_tiles);
+    if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[5], s));
+    // ---- composite
+    launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
+                     c->item_base.p, nullptr, c->partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr);
+    c->last_n_tiles = (uint32_t)n_tiles;
+    if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(sl.hc, d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(ev[9], s));
+    sl.timing_level = c->opt_timing;
+    return GSWT_OK;
+}
+
+// Waits for the slot's frame; re-runs it with larger pair buffers if it overflowed; fills c->timings.
+static int finish_frame(gswt_ctx* c, FrameSlot& sl)
+{
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(c, hipEventSynchronize(sl.ev[9]));
+        const unsigned long long P64 = sl.hc[1];
+        if (P64 >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: %llu pairs exceed 2^32", P64);
+        if (sl.hc[3] == 0 && P64 <= sl.cap) break;
+        if (attempt >= 2) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");
+        c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 4 + 4096, 0xFFFFFF00ull));
+        int rc = enqueue_frame(c, sl);
+        if (rc != GSWT_OK) return rc;
+    }
+    const uint32_t P = (uint32_t)sl.hc[1];
+    // keep ~25 % headroom over the running pair count without shrinking on every small dip
+    if ((uint64_t)P + P / 8 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 4 + 4096, 0xFFFFFF00ull);
+    gswt_timings& t = c->timings;
+    memset(&t, 0, sizeof(t));
+    hipEvent_t* ev = sl.ev;
+    if (sl.timing_level >= 2) {
+        hipEventElapsedTime(&t.ms_project, ev[0], ev[1]);
+        hipEventElapsedTime(&t.ms_emit, ev[1], ev[3]);
+        hipEventElapsedTime(&t.ms_sort, ev[3], ev[4]);
+        hipEventElapsedTime(&t.ms_ranges, ev[4], ev[5]);
+        hipEventElapsedTime(&t.ms_composite, ev[5], ev[6]);
+    }
+    if (sl.timing_level >= 1) {
+        hipEventElapsedTime(&t.ms_total, ev[0], ev[6]);
+        hipEventElapsedTime(&t.ms_composite_kernel, ev[7], ev[8]);
+    }
+    t.n_draws = c->n_draws; t.n_instanced = c->n_entries; t.n_visible = sl.hc[0]; t.n_pairs = P; t.n_tiles = (uint32_t)sl.n_tiles;
+    return GSWT_OK;
+}
+
+static void fill_args(FrameArgs& a, const gswt_camera_uniforms* cam, const gswt_scene_uniforms* su, const gswt_render_config* cfg,
+                      int width, int height, const float4* d_bg, const float* d_bgd, float4* d_out)
+{
+    a.cam = *cam; a.su = *su; a.cfg = *cfg; a.width = width; a.height = height; a.d_bg = d_bg; a.d_bgd = d_bgd; a.d_out = d_out;
+}
+
+int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_uniforms* su, const gswt_render_config* cfg,
+                int width, int height, const float* bg_rgba, const float* bg_depth, int bg_on_device, float* out_rgba,
+                int out_on_device)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    int rc = validate_frame(c, cam, su, cfg, width, height, out_rgba);
+    if (rc != GSWT_OK) return rc;
+    hipSetDevice(c->device);
+    hipStream_t s = c->stream;
+    for (auto& sl : c->slots)                      // collect anything still in flight from the async API
+        if (sl.pending) { sl.pending = false; rc = finish_frame(c, sl); if (rc != GSWT_OK) return rc; }
+    const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
+    const int out_rows = sc > 1 ? gswt_shard_rows_padded(height, sc) : height;
+    const size_t out_px = (size_t)out_rows * width, npx = (size_t)width * height;
     const float4* d_bg = nullptr; const float* d_bgd = nullptr; float4* d_out = nullptr;
     if (bg_rgba) {
         if (bg_on_device) d_bg = reinterpret_cast<const float4*>(bg_rgba);
@@ -449,105 +620,47 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     }
     if (out_on_device) d_out = reinterpret_cast<float4*>(out_rgba);
     else { HIP_TRY(c, c->out_img.ensure(out_px)); d_out = c->out_img.p; }
-    HIP_TRY(c, c->ranges.ensure((size_t)n_tiles + 1));
-    const bool dbg = c->opt_debug_varyings != 0;
-    if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)c->n_entries + 1));
-    if (sc > 1 && out_rows * width > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
-
-    // The pair count P is only known on the device.  Everything downstream of k_project is launched
-    // for a capacity `pair_cap` (blocks past the real P exit), so a frame needs no host round trip
-    // in the middle; the count and an overflow flag are read back with the frame.  If P exceeded the
-    // capacity the buffers grow and the frame is re-run (first frame / sudden scene change only).
-    int key_bits = 1;
-    while ((1 << key_bits) < n_tiles) key_bits++;
-    if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_entries / 4, 1u << 20), 0xFFFFFF00ull);
-    unsigned long long host_counters[4] = {0, 0, 0, 0};
-    for (int attempt = 0;; attempt++) {
-        const uint32_t cap = c->pair_cap;
-        HIP_TRY(c, c->keys_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->keys_b.ensure((size_t)cap + 1));
-        HIP_TRY(c, c->vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->vals_b.ensure((size_t)cap + 1));
-        const size_t n_super2 = 2 * ((size_t)c->n_chunks / 256 + 1);
-        const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
-        const uint32_t n_slots = c->n_chunks * (uint32_t)kChunk;
-        const size_t depth_radix_words = depth_order ? radix_ws_words(n_slots, 32) : 0;
-        const size_t radix_words = radix_ws_words(cap, key_bits) + depth_radix_words;
-        if (depth_order) {
-            HIP_TRY(c, c->depth_ws.ensure(4 * (size_t)n_slots + (size_t)c->n_chunks + 16));
-            HIP_TRY(c, c->scan_ws.ensure((size_t)c->n_chunks / 1024 + 4096));
-        }
-        // one contiguous u32 region cleared by k_cull: [counters: 16][super_sums: n_super2][radix histograms]
-        HIP_TRY(c, c->ghist.ensure(16 + n_super2 + radix_words + 16));
-        uint32_t* const zero_a = c->ghist.p;
-        unsigned long long* const d_counters = reinterpret_cast<unsigned long long*>(zero_a);
-        uint32_t* const d_super = zero_a + 16;
-        uint32_t* const d_radix = d_super + n_super2;
-        const uint32_t seg = (uint32_t)c->opt_segment;
-        HIP_TRY(c, c->item_base.ensure((size_t)n_tiles + 2));
-        HIP_TRY(c, c->partials.ensure(((size_t)n_tiles + cap / seg + 1) * 256));
-        unsigned long long* const d_P = d_counters + 1;
-        // ---- cull (+ clears the frame's accumulators) + project
-        HIP_TRY(c, hipEventRecord(c->ev[0], s));
-        launch_cull(s, f, c->draws.p, c->n_draws, c->draw_culled.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
-                    reinterpret_cast<uint32_t*>(c->ranges.p), (uint32_t)n_tiles * 2u);
-        launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
-                       c->tex.p, c->hmap.p, c->draw_culled.p, c->rects.p, c->recs.p, c->block_sums.p, d_super,
-                       d_counters, c->dbg.p);
-        HIP_TRY(c, hipEventRecord(c->ev[1], s));
-        HIP_TRY(c, hipEventRecord(c->ev[2], s));
-        // ---- emit
-        if (!depth_order) {
-            launch_emit(s, f, c->n_chunks, c->rects.p, c->block_sums.p, d_super, cap, d_counters, c->keys_a.p, c->vals_a.p);
-        } else {
-            // d_counters[4] = n_slots (the radix kernels read their item count from device memory)
-            const unsigned long long ns64 = n_slots;
-            HIP_TRY(c, hipMemcpyAsync(d_counters + 4, &ns64, 8, hipMemcpyHostToDevice, s));
-            uint32_t* dw = c->depth_ws.p;
-            launch_emit_depth(s, f, n_slots, d_counters + 4, c->rects.p, c->recs.p, c->block_sums.p, dw, dw + n_slots, dw + 2 * (size_t)n_slots,
-                              dw + 3 * (size_t)n_slots, d_radix + radix_ws_words(cap, key_bits), dw + 4 * (size_t)n_slots, c->scan_ws.p,
-                              reinterpret_cast<uint32_t*>(d_counters + 2), cap, d_counters, c->keys_a.p, c->vals_a.p);
-        }
-        HIP_TRY(c, hipEventRecord(c->ev[3], s));
-        // ---- stable sort on the tile bits
-        int where = launch_sort(s, c->keys_a.p, c->vals_a.p, c->keys_b.p, c->vals_b.p, cap, d_P, key_bits, d_radix);
-        const uint32_t* keys_sorted = where ? c->keys_b.p : c->keys_a.p;
-        const uint32_t* vals_sorted = where ? c->vals_b.p : c->vals_a.p;
-        HIP_TRY(c, hipEventRecord(c->ev[4], s));
-        // ---- ranges
-        launch_ranges(s, keys_sorted, cap, d_P, c->ranges.p, (uint32_t)n_tiles);
-        HIP_TRY(c, hipEventRecord(c->ev[5], s));
-        // ---- composite
-        launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, d_bg, d_bgd, d_out, n_tiles, out_rows, seg, cap,
-                         c->item_base.p, nullptr, c->partials.p, c->ev[7], c->ev[8]);
-        c->last_n_tiles = (uint32_t)n_tiles;
-        HIP_TRY(c, hipEventRecord(c->ev[6], s));
-        HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipMemcpyAsync(host_counters, d_counters, sizeof(host_counters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        if (host_counters[1] >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: %llu pairs exceed 2^32", host_counters[1]);
-        if (host_counters[3] == 0 && host_counters[1] <= cap) break;
-        if (attempt >= 2) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");
-        c->pair_cap = (uint32_t)std::min<uint64_t>(host_counters[1] + host_counters[1] / 4 + 4096, 0xFFFFFF00ull);
-    }
-    const uint32_t P = (uint32_t)host_counters[1];
-    // keep ~25 % headroom over the running pair count without shrinking on every small dip
-    if ((uint64_t)P + P / 8 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 4 + 4096, 0xFFFFFF00ull);
+    FrameSlot& sl = c->slots[0];
+    fill_args(sl.args, cam, su, cfg, width, height, d_bg, d_bgd, d_out);
+    rc = enqueue_frame(c, sl);
+    if (rc != GSWT_OK) return rc;
+    rc = finish_frame(c, sl);
+    if (rc != GSWT_OK) return rc;
     if (!out_on_device) {
         HIP_TRY(c, hipMemcpyAsync(out_rgba, d_out, out_px * 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
     }
-
-    gswt_timings& t = c->timings;
-    memset(&t, 0, sizeof(t));
-    hipEventElapsedTime(&t.ms_project, c->ev[0], c->ev[1]);
-    hipEventElapsedTime(&t.ms_scan, c->ev[1], c->ev[2]);
-    hipEventElapsedTime(&t.ms_emit, c->ev[2], c->ev[3]);
-    hipEventElapsedTime(&t.ms_sort, c->ev[3], c->ev[4]);
-    hipEventElapsedTime(&t.ms_ranges, c->ev[4], c->ev[5]);
-    hipEventElapsedTime(&t.ms_composite, c->ev[5], c->ev[6]);
-    hipEventElapsedTime(&t.ms_total, c->ev[0], c->ev[6]);
-    hipEventElapsedTime(&t.ms_composite_kernel, c->ev[7], c->ev[8]);
-    t.n_draws = c->n_draws; t.n_instanced = c->n_entries; t.n_visible = host_counters[0]; t.n_pairs = P; t.n_tiles = (uint32_t)n_tiles;
     return GSWT_OK;
+}
+
+int gswt_render_async(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_uniforms* su, const gswt_render_config* cfg,
+                      int width, int height, const float* bg_rgba_dev, const float* bg_depth_dev, float* out_rgba_dev, int* ticket)
+{
+    if (!c || !ticket) return GSWT_ERR_BAD_ARG;
+    int rc = validate_frame(c, cam, su, cfg, width, height, out_rgba_dev);
+    if (rc != GSWT_OK) return rc;
+    hipSetDevice(c->device);
+    const int si = c->next_slot;
+    FrameSlot& sl = c->slots[si];
+    if (sl.pending) { sl.pending = false; rc = finish_frame(c, sl); if (rc != GSWT_OK) return rc; }
+    fill_args(sl.args, cam, su, cfg, width, height, reinterpret_cast<const float4*>(bg_rgba_dev), bg_depth_dev,
+              reinterpret_cast<float4*>(out_rgba_dev));
+    rc = enqueue_frame(c, sl);
+    if (rc != GSWT_OK) return rc;
+    sl.pending = true;
+    c->next_slot = (si + 1) % kFrameSlots;
+    *ticket = si;
+    return GSWT_OK;
+}
+
+int gswt_render_wait(gswt_ctx* c, int ticket)
+{
+    if (!c || ticket < 0 || ticket >= kFrameSlots) return GSWT_ERR_BAD_ARG;
+    FrameSlot& sl = c->slots[ticket];
+    if (!sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render_wait: ticket %d is not in flight", ticket);
+    hipSetDevice(c->device);
+    sl.pending = false;
+    return finish_frame(c, sl);
 }
 
 int gswt_unshard(gswt_ctx* c, const float* gathered, int width, int height, int shard_count, float* out_rgba)

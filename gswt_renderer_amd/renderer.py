@@ -143,6 +143,26 @@ class GSWTRenderer:
                                           1 if bg_on_device else 0, _ptr(out), 0))
         return out
 
+    def render_async(self, camera, scene, width: int, height: int, out_device_ptr: int, *, culling_dist: float = 1.0,
+                     lod_enable_mask: int = 0xFFFFFFFF, order_mode: int = L.GSWT_ORDER_REFERENCE,
+                     transmittance_eps: float = 0.0, shard=(0, 1), bg_rgba_ptr: int = 0, bg_depth_ptr: int = 0) -> int:
+        """Queues a frame (device pointers only) and returns a ticket for render_wait."""
+        cam = (C.c_char * 176).from_buffer_copy(bytes(camera))
+        sc = (C.c_char * 160).from_buffer_copy(bytes(scene))
+        cfg = L.RenderConfig()
+        cfg.culling_dist, cfg.lod_enable_mask, cfg.order_mode = culling_dist, lod_enable_mask & 0xFFFFFFFF, order_mode
+        cfg.transmittance_eps = transmittance_eps
+        cfg.shard_index, cfg.shard_count = int(shard[0]), int(shard[1])
+        ticket = C.c_int(-1)
+        self._check(self._lib.gswt_render_async(self._h, cam, sc, C.byref(cfg), width, height,
+                                                C.c_void_p(bg_rgba_ptr) if bg_rgba_ptr else None,
+                                                C.c_void_p(bg_depth_ptr) if bg_depth_ptr else None,
+                                                C.c_void_p(out_device_ptr), C.byref(ticket)))
+        return ticket.value
+
+    def render_wait(self, ticket: int):
+        self._check(self._lib.gswt_render_wait(self._h, ticket))
+
     def shard_rows_padded(self, height: int, shard_count: int) -> int:
         return int(self._lib.gswt_shard_rows_padded(height, shard_count))
 

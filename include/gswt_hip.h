@@ -160,7 +160,8 @@ GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
  * DEBUG_VARYINGS: keep vs_main's per-entry outputs for gswt_debug_read_projected. */
 enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
        GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 512) */,
-       GSWT_OPT_DEBUG_FLAGS = 4 /* compositor ablation bits for profiling; output is wrong when nonzero */ };
+       GSWT_OPT_DEBUG_FLAGS = 4 /* ablation bits for profiling; output is wrong when nonzero */,
+       GSWT_OPT_TIMING = 5 /* hipEvent timing: 0 none, 1 frame + k_composite, 2 every stage (default) */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data
@@ -192,6 +193,19 @@ GSWT_API int gswt_render(gswt_ctx *ctx, const gswt_camera_uniforms *camera,
                          int width, int height,
                          const float *bg_rgba, const float *bg_depth, int bg_on_device,
                          float *out_rgba, int out_on_device);
+
+/* Asynchronous form of gswt_render for pipelining consecutive frames (State::render is called once per
+ * display refresh; with the device library the next frame can be queued while the previous one is still
+ * executing).  All pointers are DEVICE pointers.  gswt_render_async enqueues the frame and returns a
+ * ticket; gswt_render_wait(ticket) blocks until it finished, re-runs it if the pair buffers had to grow,
+ * and makes gswt_last_timings refer to it.  At most two frames may be in flight (enqueuing a third waits
+ * for the oldest); frames execute in submission order on the ctx stream, so frames in flight together
+ * should write different output buffers. */
+GSWT_API int gswt_render_async(gswt_ctx *ctx, const gswt_camera_uniforms *camera,
+                               const gswt_scene_uniforms *scene, const gswt_render_config *cfg,
+                               int width, int height, const float *bg_rgba_dev, const float *bg_depth_dev,
+                               float *out_rgba_dev, int *ticket);
+GSWT_API int gswt_render_wait(gswt_ctx *ctx, int ticket);
 
 /* Number of pixel rows the shard (index, count) owns for a frame of `height` rows. */
 GSWT_API int gswt_shard_rows(int height, int shard_index, int shard_count);

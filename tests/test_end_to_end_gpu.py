@@ -145,3 +145,29 @@ def test_depth_order_sharded_and_background(renderer):
     assert H.max_abs_diff(full, ref) <= TOL
     img, _, _, _ = _run_case(renderer, cfg, cam, 200, 150, lod0=1500, order_mode=1, bg=True, shard=3)
     assert np.array_equal(img, full)
+
+
+def test_async_pipelined_frames_match_sync(renderer):
+    """gswt_render_async / gswt_render_wait: three frames queued back to back (two in flight) give exactly
+    the images of the synchronous call, including a frame that forces the pair buffers to grow."""
+    import torch
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=800)
+    pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer)
+    W, Hh = 256, 160
+    pos = (4.2, 1.0, 2.0)
+    cams = [host.camera_uniforms(pos, t, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh) for t in ((5.0, 3.0, 1.5), (3.0, 4.0, 1.0), (6.0, 1.5, 1.8))]
+    pipe.update(pos, cams[0][1])
+    su = pipe.wang.scene_uniforms()
+    want = [renderer.render(cu, su, W, Hh) for cu, _ in cams]
+    outs = [torch.zeros((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+    tickets = []
+    for (cu, _), o in zip(cams, outs):
+        tickets.append(renderer.render_async(cu, su, W, Hh, o.data_ptr()))
+        if len(tickets) == 2:
+            renderer.render_wait(tickets.pop(0))
+    while tickets:
+        renderer.render_wait(tickets.pop(0))
+    for o, wimg in zip(outs, want):
+        assert np.array_equal(o.cpu().numpy(), wimg)
+    assert renderer.timings()["n_pairs"] > 0
