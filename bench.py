@@ -73,10 +73,12 @@ def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0):
             draws.append(orc.Draw(tu, gi[d.base_lod][d.base_tile][d.base_view], None, li[d.base_lod][d.base_tile][d.base_view]))
     ocu = orc.Camera176.from_buffer_copy(bytes(cu))
     osu = orc.Scene160.from_buffer_copy(bytes(su))
+    # the GPU box gives one GPU's job a 16-core CPU share; the oracle's OpenMP team is sized to that
+    n_threads = int(os.environ.get("GSWT_CPU_BASELINE_THREADS", str(min(16, os.cpu_count() or 1))))
     t0 = time.perf_counter()
-    img, st = orc.render(ocu, osu, tex, draws, W, H)
+    img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads)
     dt = time.perf_counter() - t0
-    return img, st, dt, orc.num_threads()
+    return img, st, dt, n_threads
 
 
 def main():
@@ -92,14 +94,17 @@ def main():
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    force_dist = os.environ.get("GSWT_BENCH_FORCE_DIST") == "1"      # exercise the all-gather plumbing with one rank
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
     import torch
     dist = None
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     elif n_gpus > 1:
@@ -119,14 +124,15 @@ def main():
     r.configure(None)
     r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
     su = wang.scene_uniforms()
+    use_dist = world > 1 or force_dist
     shard = (rank, world) if world > 1 else (0, 1)
     rows = r.shard_rows_padded(H, world) if world > 1 else H
     # two frames in flight (gswt_render_async / gswt_render_wait): frame i+1 is queued on the stream while
     # frame i executes, so the host never idles the GPU between frames; frames alternate output buffers
     outs = [torch.empty((rows, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
     out = outs[0]
-    gathered = torch.empty((world * rows, W, 4), dtype=torch.float32, device=dev) if world > 1 else None
-    frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * rows, W, 4), dtype=torch.float32, device=dev) if use_dist else None
+    frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if use_dist else None
 
     comp_ms, total_ms, pairs = [], [], []
     inflight = []
@@ -136,7 +142,7 @@ def main():
         o = outs[i % 2]
         with torch.cuda.stream(stream):
             ticket = r.render_async(cu, su, W, H, o.data_ptr(), transmittance_eps=args.t_eps, shard=shard)
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered, o)
                 r.unshard(gathered.data_ptr(), W, H, world, frame.data_ptr())
         inflight.append(ticket)
@@ -196,6 +202,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": comp * 1e3},
         }
+        if use_dist:
+            res["dist_check_max_abs_diff"] = float((frame - (out if world == 1 else frame)).abs().max().item())
         if world == 1 and not args.no_cpu_baseline:
             img_cpu, st, cdt, nthr = cpu_baseline(wang, sort, cu, vp, su, W, H)
             gpu_img = out.cpu().numpy()
