@@ -60,7 +60,15 @@ class Draw(C.Structure):
     _fields_ = [("tile", TileUniforms), ("merged", C.c_uint32), ("base_lod", C.c_uint32),
                 ("base_tile", C.c_uint32), ("base_view", C.c_uint32), ("merged_offset", C.c_uint32),
                 ("merged_count", C.c_uint32), ("merged_has_lod", C.c_uint32), ("cull_enable", C.c_uint32),
-                ("corners", C.c_float * 12), ("lod", C.c_uint32), ("_pad", C.c_uint32 * 3)]
+                ("corners", C.c_float * 12), ("lod", C.c_uint32), ("merged_group", C.c_uint32), ("_pad", C.c_uint32 * 2)]
+
+
+class MergeGroup(C.Structure):
+    _fields_ = [("view_id", C.c_uint32), ("first_member", C.c_uint32), ("n_members", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class MergeMember(C.Structure):
+    _fields_ = [("map_index", C.c_uint32), ("lod", C.c_uint32), ("tile", C.c_uint32), ("other_lod", C.c_int32)]
 
 
 class RenderConfig(C.Structure):
@@ -90,6 +98,9 @@ SYMBOLS = {
     "gswt_upload_scene": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_int, C.c_int, C.c_int]),
     "gswt_configure": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "gswt_set_draws": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_size_t]),
+    "gswt_upload_raw_depth": (C.c_int, [_P, _P, _P, _P]),
+    "gswt_set_draws_merge_groups": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, C.c_int]),
+    "gswt_debug_read_merged": (C.c_int, [_P, _P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gswt_render": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int]),
     "gswt_render_async": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
     "gswt_render_wait": (C.c_int, [_P, C.c_int]),

@@ -28,6 +28,8 @@ void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long 
                        uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                        unsigned long long*, uint32_t*, uint32_t*);
 void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uint32_t*);
+void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
+                        uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, const uint32_t*, const uint32_t*,
                     const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, uint32_t*, uint32_t*,
                     unsigned long long*, Varyings*);
@@ -110,6 +112,14 @@ struct gswt_ctx {
     DevBuf<DrawDev> draws;
     DevBuf<uint2> chunk_tab;
     DevBuf<uint32_t> merged_list, merged_map;
+    size_t n_merged = 0;
+    // on-device merged lists
+    DevBuf<int32_t> raw_depth;
+    std::vector<uint32_t> raw_off;          // [(lod*n_tile + tile)*n_view + view] -> offset in raw_depth
+    std::vector<uint32_t> raw_cnt, raw_merge_offset;   // [lod*n_tile + tile]
+    DevBuf<MergeSeg> mg_segs;
+    DevBuf<MergeGroup> mg_groups;
+    DevBuf<uint32_t> mg_ws;
     uint32_t n_draws = 0, n_chunks = 0;
     uint64_t n_entries = 0;
     bool draws_ready = false;
@@ -199,7 +209,7 @@ void gswt_destroy(gswt_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release();
-    c->merged_list.release(); c->merged_map.release(); c->rects.release(); c->recs.release(); c->block_sums.release();
+    c->merged_list.release(); c->merged_map.release(); c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release(); c->mg_ws.release(); c->rects.release(); c->recs.release(); c->block_sums.release();
     c->scan_ws.release(); c->super_sums.release(); c->draw_culled.release(); c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release();
     c->ghist.release(); c->ranges.release(); c->item_base.release(); c->partials.release(); c->depth_ws.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
     c->bg_depth.release(); c->dbg.release();
@@ -293,13 +303,15 @@ int gswt_configure(gswt_ctx* c, const float* height_map, int hm_w, int hm_h)
     return GSWT_OK;
 }
 
-int gswt_set_draws(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint32_t* merged_gs_index,
-                   const uint32_t* merged_map_id, const uint32_t* merged_lod_id, size_t n_merged)
+// Shared by gswt_set_draws (merged arrays from the host) and gswt_set_draws_merge_groups (built on the device:
+// merged_gs_index == nullptr && device_merge).
+static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint32_t* merged_gs_index,
+                          const uint32_t* merged_map_id, const uint32_t* merged_lod_id, size_t n_merged, bool device_merge)
 {
     if (!c) return GSWT_ERR_BAD_ARG;
     if (!c->scene_ready) return fail(c, GSWT_ERR_STATE, "gswt_set_draws before gswt_upload_scene");
     if (n_draws < 0 || (n_draws > 0 && !draws)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: bad draw list");
-    if (n_merged && (!merged_gs_index || !merged_map_id)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged arrays missing");
+    if (!device_merge && n_merged && (!merged_gs_index || !merged_map_id)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged arrays missing");
     if (n_merged >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: merged lists exceed 2^32 entries");
     hipSetDevice(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -322,7 +334,7 @@ int gswt_set_draws(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint3
         if (g.merged) {
             if ((size_t)g.merged_offset + g.merged_count > n_merged)
                 return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: draw %d merged range out of bounds", i);
-            if (g.merged_has_lod && !merged_lod_id)
+            if (g.merged_has_lod && !merged_lod_id && !device_merge)
                 return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: draw %d needs merged_lod_id", i);
             if (g.tile.single_draw != 1u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged draw %d without single_draw", i);
             d.merged = 1; d.list_base = g.merged_offset; d.count = g.merged_count;
@@ -359,7 +371,8 @@ int gswt_set_draws(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint3
     // merged arrays: pack gs_index | lod << 28
     HIP_TRY(c, c->merged_list.ensure(n_merged + 1));
     HIP_TRY(c, c->merged_map.ensure(n_merged + 1));
-    if (n_merged) {
+    c->n_merged = n_merged;
+    if (n_merged && !device_merge) {
         std::vector<uint32_t> packed(n_merged);
         for (size_t k = 0; k < n_merged; k++) {
             if (merged_gs_index[k] >= c->n_splats) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged gs_index[%zu] out of range", k);
@@ -388,6 +401,121 @@ int gswt_set_draws(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint3
     HIP_TRY(c, c->super_sums.ensure(2 * ((size_t)c->n_chunks / 256 + 1) + 2));
     HIP_TRY(c, c->draw_culled.ensure((size_t)n_draws + 1));
     c->draws_ready = true;
+    return GSWT_OK;
+}
+
+int gswt_set_draws(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint32_t* merged_gs_index,
+                   const uint32_t* merged_map_id, const uint32_t* merged_lod_id, size_t n_merged)
+{
+    return set_draws_impl(c, draws, n_draws, merged_gs_index, merged_map_id, merged_lod_id, n_merged, false);
+}
+
+int gswt_upload_raw_depth(gswt_ctx* c, const int32_t* const* raw_depth, const uint32_t* counts, const uint32_t* merge_offset)
+{
+    if (!c || !raw_depth || !counts || !merge_offset) return GSWT_ERR_BAD_ARG;
+    if (!c->scene_ready) return fail(c, GSWT_ERR_STATE, "gswt_upload_raw_depth before gswt_upload_scene");
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t nlt = (size_t)c->n_lod * c->n_tile, nv = (size_t)c->n_view;
+    c->raw_cnt.assign(counts, counts + nlt);
+    c->raw_merge_offset.assign(merge_offset, merge_offset + nlt);
+    c->raw_off.assign(nlt * nv, 0);
+    size_t total = 0;
+    for (size_t i = 0; i < nlt; i++) for (size_t v = 0; v < nv; v++) { c->raw_off[i * nv + v] = (uint32_t)total; total += counts[i]; }
+    if (total >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_upload_raw_depth: raw depth arena exceeds 2^32");
+    std::vector<int32_t> arena(total);
+    for (size_t i = 0; i < nlt; i++)
+        for (size_t v = 0; v < nv; v++) {
+            if (counts[i] && !raw_depth[i * nv + v]) return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_raw_depth: null array");
+            if (counts[i]) memcpy(arena.data() + c->raw_off[i * nv + v], raw_depth[i * nv + v], (size_t)counts[i] * 4);
+        }
+    HIP_TRY(c, c->raw_depth.ensure(total + 1));
+    if (total) HIP_TRY(c, hipMemcpy(c->raw_depth.p, arena.data(), total * 4, hipMemcpyHostToDevice));
+    return GSWT_OK;
+}
+
+int gswt_set_draws_merge_groups(gswt_ctx* c, const gswt_draw* draws, int n_draws, const gswt_merge_group* groups, int n_groups,
+                                const gswt_merge_member* members, int n_members)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    if (n_groups < 0 || n_members < 0 || (n_groups && (!groups || !members))) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: bad groups");
+    if (n_groups && c->raw_cnt.empty()) return fail(c, GSWT_ERR_STATE, "gswt_set_draws_merge_groups before gswt_upload_raw_depth");
+    if (n_groups > 32768) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws_merge_groups: more than 32768 merged groups");
+    // segments and group ranges (the concatenation order IS the merged-arena order)
+    std::vector<MergeSeg> segs;
+    std::vector<MergeGroup> grp((size_t)n_groups);
+    uint64_t total = 0;
+    const size_t nv = (size_t)c->n_view;
+    for (int g = 0; g < n_groups; g++) {
+        const gswt_merge_group& G = groups[g];
+        if ((uint64_t)G.first_member + G.n_members > (uint64_t)n_members || (int)G.view_id >= c->n_view)
+            return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: group %d out of range", g);
+        grp[g].base = (uint32_t)total; grp[g].mn = 0; grp[g].mx = 0;
+        for (uint32_t m = 0; m < G.n_members; m++) {
+            const gswt_merge_member& M = members[G.first_member + m];
+            const int lods[2] = {(int)M.lod, M.other_lod};
+            for (int k = 0; k < 2; k++) {
+                if (lods[k] < 0) continue;
+                if (lods[k] >= c->n_lod || (int)M.tile >= c->n_tile) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: member tid out of range");
+                const size_t lt = (size_t)lods[k] * c->n_tile + M.tile;
+                MergeSeg sg;
+                sg.group = (uint32_t)g; sg.src = c->raw_off[lt * nv + G.view_id]; sg.len = c->raw_cnt[lt]; sg.start = (uint32_t)total;
+                sg.gs_offset = c->raw_merge_offset[lt]; sg.map_index = M.map_index; sg.lod = (uint32_t)lods[k]; sg._pad = 0;
+                if (sg.len) segs.push_back(sg);
+                total += sg.len;
+            }
+        }
+        grp[g].len = (uint32_t)(total - grp[g].base);
+    }
+    if (total >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws_merge_groups: merged lists exceed 2^32 entries");
+    for (int i = 0; i < n_draws; i++)
+        if (draws[i].merged) {
+            const uint32_t g = draws[i].merged_group;
+            if ((int)g >= n_groups || draws[i].merged_offset != grp[g].base || draws[i].merged_count != grp[g].len)
+                return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: draw %d does not match group %u (offset %u/%u count %u/%u)", i, g,
+                            draws[i].merged_offset, (int)g < n_groups ? grp[g].base : 0u, draws[i].merged_count, (int)g < n_groups ? grp[g].len : 0u);
+        }
+    int rc = set_draws_impl(c, draws, n_draws, nullptr, nullptr, nullptr, (size_t)total, true);
+    if (rc != GSWT_OK) return rc;
+    if (total == 0) return GSWT_OK;
+    c->draws_ready = false;
+    hipStream_t s = c->stream;
+    const uint32_t n_total = (uint32_t)total;
+    int gbits = 1;
+    while ((1 << gbits) < n_groups) gbits++;
+    HIP_TRY(c, c->mg_segs.ensure(segs.size() + 1));
+    HIP_TRY(c, c->mg_groups.ensure(grp.size() + 1));
+    const size_t radix_words = radix_ws_words(n_total, 16 + gbits);
+    HIP_TRY(c, c->mg_ws.ensure(4 * (size_t)n_total + radix_words + 16));
+    HIP_TRY(c, hipMemcpyAsync(c->mg_segs.p, segs.data(), segs.size() * sizeof(MergeSeg), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->mg_groups.p, grp.data(), grp.size() * sizeof(MergeGroup), hipMemcpyHostToDevice, s));
+    uint32_t* w = c->mg_ws.p;
+    uint32_t* radix = w + 4 * (size_t)n_total;
+    HIP_TRY(c, hipMemsetAsync(radix, 0, (radix_words + 16) * 4, s));
+    unsigned long long* n_dev = reinterpret_cast<unsigned long long*>(radix + radix_words + (radix_words & 1));   // 8-byte aligned, followed by zeros
+    const unsigned long long n64 = n_total;
+    HIP_TRY(c, hipMemcpyAsync(n_dev, &n64, 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));                 // n64 / segs / grp are host locals
+    launch_merge_build(s, c->mg_segs.p, (uint32_t)segs.size(), c->mg_groups.p, (uint32_t)n_groups, c->raw_depth.p, n_total, n_dev,
+                       w, w + n_total, w + 2 * (size_t)n_total, w + 3 * (size_t)n_total, radix, gbits, c->merged_list.p, c->merged_map.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->draws_ready = true;
+    return GSWT_OK;
+}
+
+int gswt_debug_read_merged(gswt_ctx* c, uint32_t* packed_list, uint32_t* map_id, size_t capacity, size_t* n)
+{
+    if (!c || !n) return GSWT_ERR_BAD_ARG;
+    *n = c->n_merged;
+    if (!packed_list || !map_id) return GSWT_OK;
+    if (capacity < c->n_merged) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu entries, need %zu", capacity, c->n_merged);
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->n_merged) {
+        HIP_TRY(c, hipMemcpy(packed_list, c->merged_list.p, c->n_merged * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(map_id, c->merged_map.p, c->n_merged * 4, hipMemcpyDeviceToHost));
+    }
     return GSWT_OK;
 }
 

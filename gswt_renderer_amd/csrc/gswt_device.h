@@ -69,6 +69,15 @@ struct __attribute__((aligned(16))) Rec {
     float rgba8, hx, hy, pad;
 };
 
+// Device-side merged-list building (see k_mg_* in gswt_kernels.hip)
+struct MergeSeg {
+    uint32_t group, src, len, start, gs_offset, map_index, lod, _pad;
+};
+struct MergeGroup {
+    uint32_t base, len;
+    int32_t mn, mx;
+};
+
 // vs_main varyings for the debug/parity hook (48 B, same layout as the oracle's orc_splat)
 struct Varyings {
     int32_t visible;

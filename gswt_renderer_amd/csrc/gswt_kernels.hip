@@ -672,6 +672,92 @@ __global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* _
 }
 
 // ------------------------------------------------------------------------------------
+// Merged-group lists on the device (Scene::sort_raw_depth_vec for every MergedFrom group of a sort event,
+// wangtile.rs:595-670 + scene.rs:655-698, in one segmented sort).
+//   segment  = one member's raw-depth array (plus the other LOD's when the member is Changing)
+//   k_mg_minmax : per group min / max of the concatenated raw depths
+//   k_mg_keys   : key = group << 16 | bucket, bucket = clamp(floor((d - min) as f32 * (65535 / (max - min)))),
+//                 NaN -> 0 as in Rust's `as i32`; val = position in the concatenation
+//   radix sort  : stable on 16 + log2(groups) bits  == the CPU's stable scatter by bucket
+//   k_mg_final  : reverse inside each group (`depth_index.reverse()`), map concat position -> gs_index / map id / lod
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mg_find_seg(const MergeSeg* __restrict__ segs, uint32_t n_segs, uint32_t e)
+{
+    uint32_t lo = 0, hi = n_segs;                     // largest s with segs[s].start <= e
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (segs[mid].start <= e) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_mg_init(MergeGroup* __restrict__ groups, uint32_t n_groups)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g < n_groups) { groups[g].mn = 2147483647; groups[g].mx = -2147483647 - 1; }
+}
+
+__global__ __launch_bounds__(256) void k_mg_minmax(const MergeSeg* __restrict__ segs, uint32_t n_segs, const int32_t* __restrict__ raw,
+                                                   uint32_t n_total, MergeGroup* __restrict__ groups)
+{
+    // each lane folds up to four entries (they may straddle groups), then the lanes that share the wave's
+    // first group reduce with shuffles -> about one atomic pair per wave
+    const uint32_t e0 = blockIdx.x * 1024u;
+    int32_t mn = 2147483647, mx = -2147483647 - 1;
+    uint32_t cur_group = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t e = e0 + k * 256u + threadIdx.x;
+        if (e >= n_total) break;
+        const MergeSeg sg = segs[mg_find_seg(segs, n_segs, e)];
+        const int32_t d = raw[sg.src + (e - sg.start)];
+        if (sg.group != cur_group) {
+            if (cur_group != 0xFFFFFFFFu) { atomicMin(&groups[cur_group].mn, mn); atomicMax(&groups[cur_group].mx, mx); }
+            cur_group = sg.group; mn = d; mx = d;
+        } else { mn = min(mn, d); mx = max(mx, d); }
+    }
+    const uint32_t wg = __shfl(cur_group, 0, 64);
+    const bool same = cur_group == wg && cur_group != 0xFFFFFFFFu;
+    int32_t rmn = same ? mn : 2147483647, rmx = same ? mx : (-2147483647 - 1);
+    for (int off = 32; off > 0; off >>= 1) { rmn = min(rmn, __shfl_down(rmn, off, 64)); rmx = max(rmx, __shfl_down(rmx, off, 64)); }
+    if ((threadIdx.x & 63u) == 0 && wg != 0xFFFFFFFFu) { atomicMin(&groups[wg].mn, rmn); atomicMax(&groups[wg].mx, rmx); }
+    if (!same && cur_group != 0xFFFFFFFFu) { atomicMin(&groups[cur_group].mn, mn); atomicMax(&groups[cur_group].mx, mx); }
+}
+
+__global__ __launch_bounds__(256) void k_mg_keys(const MergeSeg* __restrict__ segs, uint32_t n_segs, const int32_t* __restrict__ raw,
+                                                 uint32_t n_total, const MergeGroup* __restrict__ groups, uint32_t* __restrict__ keys,
+                                                 uint32_t* __restrict__ vals)
+{
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= n_total) return;
+    const MergeSeg sg = segs[mg_find_seg(segs, n_segs, e)];
+    const MergeGroup g = groups[sg.group];
+    const int32_t d = raw[sg.src + (e - sg.start)];
+    // scene.rs:669-676: depth_inv = 65535 / (max - min) (f32), bucket = floor((d - min) as f32 * depth_inv) as i32, clamped
+    const float depth_inv = 65535.0f / (float)(int32_t)(g.mx - g.mn);
+    const float v = floorf((float)(int32_t)(d - g.mn) * depth_inv);
+    int32_t b;
+    if (v != v) b = 0;                                   // NaN (max == min: 0 * inf) -> 0
+    else if (v >= 2147483648.0f) b = 2147483647;
+    else if (v <= -2147483648.0f) b = -2147483647 - 1;
+    else b = (int32_t)v;
+    b = min(max(b, 0), 65535);
+    keys[e] = (sg.group << 16) | (uint32_t)b;
+    vals[e] = e;
+}
+
+__global__ __launch_bounds__(256) void k_mg_final(const MergeSeg* __restrict__ segs, uint32_t n_segs, const MergeGroup* __restrict__ groups,
+                                                  const uint32_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_vals,
+                                                  uint32_t n_total, uint32_t* __restrict__ merged_list, uint32_t* __restrict__ merged_map)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n_total) return;
+    const uint32_t g = sorted_keys[p] >> 16;
+    const MergeGroup gr = groups[g];
+    const uint32_t out = gr.base + (gr.len - 1u - (p - gr.base));          // depth_index.reverse()
+    const uint32_t e = sorted_vals[p];
+    const MergeSeg sg = segs[mg_find_seg(segs, n_segs, e)];
+    merged_list[out] = ((e - sg.start) + sg.gs_offset) | (sg.lod << kLodShift);
+    merged_map[out] = sg.map_index;
+}
+
+// ------------------------------------------------------------------------------------
 // k_ranges: [start, end) of each screen tile in the sorted pair list (ranges pre-zeroed)
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
@@ -1045,6 +1131,21 @@ void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_slots, const un
     hipLaunchKernelGGL(k_perm_counts, dim3(nb), dim3(256), 0, s, f, rects, sk, perm, n_slots, block_cnt);
     launch_scan(s, block_cnt, block_cnt, nb, scratch_total, scan_ws);
     hipLaunchKernelGGL(k_emit_perm, dim3(nb), dim3(256), 0, s, f, rects, sk, perm, n_slots, block_cnt, pair_cap, counters, keys, vals);
+}
+
+// Builds every merged group's (gs_index | lod, map_id) list on the device.  keys/vals a,b: n_total u32 each;
+// ws: radix_ws_words(n_total, 16 + group_bits) zeroed words; n_total_dev: device u64 = n_total (+ two zero words after it).
+void launch_merge_build(hipStream_t s, const MergeSeg* segs, uint32_t n_segs, MergeGroup* groups, uint32_t n_groups,
+                        const int32_t* raw, uint32_t n_total, const unsigned long long* n_total_dev, uint32_t* ka, uint32_t* va,
+                        uint32_t* kb, uint32_t* vb, uint32_t* radix_ws, int group_bits, uint32_t* merged_list, uint32_t* merged_map)
+{
+    if (n_total == 0 || n_groups == 0) return;
+    hipLaunchKernelGGL(k_mg_init, dim3((n_groups + 255) / 256), dim3(256), 0, s, groups, n_groups);
+    hipLaunchKernelGGL(k_mg_minmax, dim3((n_total + 1023) / 1024), dim3(256), 0, s, segs, n_segs, raw, n_total, groups);
+    hipLaunchKernelGGL(k_mg_keys, dim3((n_total + 255) / 256), dim3(256), 0, s, segs, n_segs, raw, n_total, groups, ka, va);
+    const int where = launch_sort(s, ka, va, kb, vb, n_total, n_total_dev, 16 + group_bits, radix_ws);
+    hipLaunchKernelGGL(k_mg_final, dim3((n_total + 255) / 256), dim3(256), 0, s, segs, n_segs, groups, where ? kb : ka, where ? vb : va,
+                       n_total, merged_list, merged_map);
 }
 
 // `ranges` must be zero on entry (k_cull clears it each frame)

@@ -511,6 +511,11 @@ struct gswt_wang {
     // last sort result
     std::vector<gswt_sorted_tile> sorted;
     std::vector<uint32_t> m_gs, m_map, m_lod;
+    std::vector<gswt_merge_group> m_groups;
+    std::vector<gswt_merge_member> m_members;
+    bool device_merge = false;
+    std::vector<const int32_t*> rd_ptrs;
+    std::vector<uint32_t> rd_counts, rd_offsets;
 
     TileBaseData& tb(size_t l, size_t t, size_t v) { return base[(l * n_tile + t) * n_view + v]; }
     const TileBaseData& tb(size_t l, size_t t, size_t v) const { return base[(l * n_tile + t) * n_view + v]; }
@@ -1541,6 +1546,27 @@ int gswt_wang_build_tiles(gswt_wang* w, const float cam_pos[3], gswt_scene_data*
     return GSWT_OK;
 }
 
+int gswt_wang_set_device_merge(gswt_wang* w, int enable)
+{
+    if (!w) return GSWT_ERR_BAD_ARG;
+    w->device_merge = enable != 0;
+    return GSWT_OK;
+}
+
+int gswt_wang_raw_depth_tables(gswt_wang* w, const int32_t* const** ptrs, const uint32_t** counts, const uint32_t** merge_offset)
+{
+    if (!w || !ptrs || !counts || !merge_offset) return GSWT_ERR_BAD_ARG;
+    w->rd_ptrs.clear(); w->rd_counts.clear(); w->rd_offsets.clear();
+    for (size_t l = 0; l < w->n_lod; l++)
+        for (size_t t = 0; t < w->n_tile; t++) {
+            w->rd_counts.push_back((uint32_t)w->tiles[l][t].splat_count);
+            w->rd_offsets.push_back(w->merge_offset[l][t]);
+            for (size_t v = 0; v < w->n_view; v++) w->rd_ptrs.push_back(w->tb(l, t, v).raw_depth.data());
+        }
+    *ptrs = w->rd_ptrs.data(); *counts = w->rd_counts.data(); *merge_offset = w->rd_offsets.data();
+    return GSWT_OK;
+}
+
 int gswt_wang_get_tile_ids(const gswt_wang* w, uint32_t* ids, size_t cap)
 {
     if (!w || !ids) return GSWT_ERR_BAD_ARG;
@@ -1593,6 +1619,8 @@ int gswt_wang_sort_tiles(gswt_wang* w, const float cam_pos[3], const float vp[16
     }
     w->sorted.clear();
     w->m_gs.clear(); w->m_map.clear(); w->m_lod.clear();
+    w->m_groups.clear(); w->m_members.clear();
+    size_t merged_total = 0;
     for (size_t mi : order) {
         const TileInstance* ti = w->tile_map[mi].get();
         size_t view_id;
@@ -1638,6 +1666,30 @@ int gswt_wang_sort_tiles(gswt_wang* w, const float cam_pos[3], const float vp[16
         st.key_len = (uint32_t)tids.size();
         st.single_lod_id = -1;
         if (ti->merge == MS_FROM) {
+            // group description (what gswt_set_draws_merge_groups consumes)
+            gswt_merge_group grp;
+            grp.view_id = (uint32_t)view_id; grp.first_member = (uint32_t)w->m_members.size(); grp.n_members = (uint32_t)ti->merged_from.size(); grp._pad = 0;
+            size_t group_len = 0;
+            bool do_transition = false;
+            for (size_t m_mi : ti->merged_from) {
+                const TileInstance* mt = w->tile_map[m_mi].get();
+                gswt_merge_member mm;
+                mm.map_index = (uint32_t)m_mi; mm.lod = (uint32_t)mt->lod; mm.tile = (uint32_t)mt->tile; mm.other_lod = -1;
+                if (mt->transition == TR_CHANGING_LOWER) mm.other_lod = (int32_t)mt->lod + 1;
+                else if (mt->transition == TR_CHANGING_HIGHER) mm.other_lod = (int32_t)mt->lod - 1;
+                if (mt->transition != TR_NONE) do_transition = true;
+                group_len += w->tb(mt->lod, mt->tile, view_id).raw_depth.size();
+                if (mm.other_lod >= 0) group_len += w->tb((size_t)mm.other_lod, mt->tile, view_id).raw_depth.size();
+                w->m_members.push_back(mm);
+            }
+            st.merged = 1;
+            st.merged_group = (uint32_t)w->m_groups.size();
+            st.merged_offset = (uint32_t)merged_total;
+            st.merged_count = (uint32_t)group_len;
+            st.single_lod_id = do_transition ? -1 : (int32_t)ti->lod;
+            w->m_groups.push_back(grp);
+            merged_total += group_len;
+            if (!w->device_merge) {
             std::string key = cache_key(view_id, tids, sts);
             const RenderDataValue* val = nullptr;
             RenderDataValue fresh;
@@ -1666,24 +1718,25 @@ int gswt_wang_sort_tiles(gswt_wang* w, const float cam_pos[3], const float vp[16
                 val = &fresh;
                 remapped = fresh.gs_map_id;
             }
-            st.merged = 1;
-            st.merged_offset = (uint32_t)w->m_gs.size();
             st.merged_count = (uint32_t)val->splat_count;
             st.single_lod_id = val->single_lod_id;
             w->m_gs.insert(w->m_gs.end(), val->gs_index.begin(), val->gs_index.end());
             w->m_map.insert(w->m_map.end(), remapped.begin(), remapped.end());
             if (val->has_lod) w->m_lod.insert(w->m_lod.end(), val->gs_lod_id.begin(), val->gs_lod_id.end());
             else w->m_lod.insert(w->m_lod.end(), val->splat_count, 0u);
+            }
         }
         w->sorted.push_back(st);
     }
     out->scene_id = 0;
     out->n_tiles = (uint32_t)w->sorted.size();
     out->tiles = w->sorted.data();
-    out->n_merged = w->m_gs.size();
-    out->merged_gs_index = w->m_gs.data();
-    out->merged_map_id = w->m_map.data();
-    out->merged_lod_id = w->m_lod.data();
+    out->n_merged = merged_total;
+    out->merged_gs_index = w->device_merge ? nullptr : w->m_gs.data();
+    out->merged_map_id = w->device_merge ? nullptr : w->m_map.data();
+    out->merged_lod_id = w->device_merge ? nullptr : w->m_lod.data();
+    out->n_groups = (uint32_t)w->m_groups.size(); out->n_members = (uint32_t)w->m_members.size();
+    out->groups = w->m_groups.data(); out->members = w->m_members.data();
     return GSWT_OK;
 }
 
@@ -1705,7 +1758,7 @@ int gswt_renderer_build_draws(const gswt_sort_data* sort, gswt_draw* draws_out)
             u.single_draw = 1;
             u.single_lod_id = t.single_lod_id;
             u.changing = t.single_lod_id == -1 ? 1u : 0u;
-            d.merged = 1; d.merged_offset = t.merged_offset; d.merged_count = t.merged_count;
+            d.merged = 1; d.merged_offset = t.merged_offset; d.merged_count = t.merged_count; d.merged_group = t.merged_group;
             d.merged_has_lod = t.single_lod_id == -1 ? 1u : 0u;
         } else {
             d.base_lod = t.lod;

@@ -89,13 +89,14 @@ class SortedTile(C.Structure):
                 ("transition", C.c_int32), ("spawning_factor", C.c_float), ("has_corners", C.c_uint32),
                 ("corners", C.c_float * 12), ("key_len", C.c_uint32), ("merged", C.c_uint32),
                 ("merged_offset", C.c_uint32), ("merged_count", C.c_uint32), ("single_lod_id", C.c_int32),
-                ("cache_hit", C.c_uint32)]
+                ("cache_hit", C.c_uint32), ("merged_group", C.c_uint32)]
 
 
 class SortDataC(C.Structure):
     _fields_ = [("scene_id", C.c_uint32), ("n_tiles", C.c_uint32), ("tiles", C.POINTER(SortedTile)),
                 ("n_merged", C.c_size_t), ("merged_gs_index", C.c_void_p), ("merged_map_id", C.c_void_p),
-                ("merged_lod_id", C.c_void_p)]
+                ("merged_lod_id", C.c_void_p), ("n_groups", C.c_uint32), ("n_members", C.c_uint32),
+                ("groups", C.c_void_p), ("members", C.c_void_p)]
 
 
 class Preload(C.Structure):
@@ -131,6 +132,8 @@ HOST_SYMBOLS = {
     "gswt_wang_check_update": (C.c_int, [_P, _P]),
     "gswt_wang_build_tiles": (C.c_int, [_P, _P, _P]),
     "gswt_wang_sort_tiles": (C.c_int, [_P, _P, _P, _P]),
+    "gswt_wang_set_device_merge": (C.c_int, [_P, C.c_int]),
+    "gswt_wang_raw_depth_tables": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "gswt_wang_get_tile_ids": (C.c_int, [_P, _P, C.c_size_t]),
     "gswt_wang_set_tile_ids": (C.c_int, [_P, _P, C.c_size_t]),
     "gswt_renderer_build_draws": (C.c_int, [_P, _P]),
@@ -262,6 +265,8 @@ class SortData:
     merged_map_id: np.ndarray
     merged_lod_id: np.ndarray
     draws: list            # list[L.Draw] built by gswt_renderer_build_draws
+    groups: list = None    # list[L.MergeGroup] (copies)
+    members: list = None   # list[L.MergeMember] (copies)
 
 
 class WangTile:
@@ -312,6 +317,16 @@ class WangTile:
                     gi[l][t].append(np.ctypeslib.as_array(C.cast(b.gs_index, C.POINTER(C.c_uint32)), shape=(n,)))
                     li[l][t].append(np.ctypeslib.as_array(C.cast(b.gs_lod_id, C.POINTER(C.c_uint32)), shape=(n,)))
         return tex, gi, li
+
+    def set_device_merge(self, enable: bool):
+        """sort_tiles then only describes merged groups; libgswt_hip builds their lists (gswt_set_draws_merge_groups)."""
+        _check(self._lib.gswt_wang_set_device_merge(self._h, 1 if enable else 0))
+
+    def upload_raw_depth_to(self, renderer):
+        """gswt_upload_raw_depth with this WangTile's raw-depth tables (needed for device-side merged lists)."""
+        ptrs, cnts, offs = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(self._lib.gswt_wang_raw_depth_tables(self._h, C.byref(ptrs), C.byref(cnts), C.byref(offs)))
+        renderer._check(renderer._lib.gswt_upload_raw_depth(renderer._h, ptrs, cnts, offs))
 
     def upload_to(self, renderer):
         """GSWTRenderer::new(preload_data): hand the PreloadData pointers straight to libgswt_hip."""
@@ -390,8 +405,17 @@ class WangTile:
             if sd.n_merged == 0:
                 return np.zeros(0, dtype=np.uint32)
             return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(sd.n_merged,)).copy()
+        groups = [L.MergeGroup.from_buffer_copy(C.string_at(sd.groups + i * C.sizeof(L.MergeGroup), C.sizeof(L.MergeGroup)))
+                  for i in range(sd.n_groups)]
+        members = [L.MergeMember.from_buffer_copy(C.string_at(sd.members + i * C.sizeof(L.MergeMember), C.sizeof(L.MergeMember)))
+                   for i in range(sd.n_members)]
+
+        def arr(p):
+            if sd.n_merged == 0 or not p:
+                return np.zeros(0, dtype=np.uint32)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(sd.n_merged,)).copy()
         return SortData(tiles, arr(sd.merged_gs_index), arr(sd.merged_map_id), arr(sd.merged_lod_id),
-                        [draws[i] for i in range(sd.n_tiles)])
+                        [draws[i] for i in range(sd.n_tiles)], groups, members)
 
     def scene_uniforms(self, *, splat_scale=1.0, scene_scale=(1.0, 1.0, 1.0), height_map_scale_v=1.0) -> L.SceneUniforms:
         """SceneUniforms::from_data, renderer.rs:631-672"""

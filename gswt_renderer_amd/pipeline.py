@@ -12,7 +12,8 @@ from .renderer import GSWTRenderer
 
 
 class GSWTPipeline:
-    def __init__(self, verts_or_zip, user: host.UserData, device_id: int = 0, renderer: GSWTRenderer | None = None):
+    def __init__(self, verts_or_zip, user: host.UserData, device_id: int = 0, renderer: GSWTRenderer | None = None,
+                 device_merge: bool = False):
         if isinstance(verts_or_zip, (str, bytes, bytearray)):
             ts = host.TileSet.from_zip(verts_or_zip)
         else:
@@ -20,6 +21,10 @@ class GSWTPipeline:
         self.wang = host.WangTile(ts)                      # State::new: WangTile::new(scene_vec)
         self.renderer = renderer or GSWTRenderer(device_id)
         self.wang.upload_to(self.renderer)                 # GSWTRenderer::new(.., wang.preload())
+        self.device_merge = device_merge
+        if device_merge:                                   # merged-group lists are then built on the GPU per sort event
+            self.wang.upload_raw_depth_to(self.renderer)
+            self.wang.set_device_merge(True)
         self.configure(user)
         self.sort = None
         self._last_vp = None
@@ -42,7 +47,14 @@ class GSWTPipeline:
             self.sort = self.wang.sort_tiles(cam_pos, vp)
             self._last_vp = vp.copy()
             s = self.sort
-            self.renderer.set_draws(s.draws, s.merged_gs_index, s.merged_map_id, s.merged_lod_id)
+            if self.device_merge:
+                import ctypes as C
+                from . import _lib as L
+                g = (L.MergeGroup * max(1, len(s.groups)))(*s.groups)
+                m = (L.MergeMember * max(1, len(s.members)))(*s.members)
+                self.renderer.set_draws_merge_groups(s.draws, g, len(s.groups), m, len(s.members))
+            else:
+                self.renderer.set_draws(s.draws, s.merged_gs_index, s.merged_map_id, s.merged_lod_id)
             return True
         return False
 

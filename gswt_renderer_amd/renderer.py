@@ -113,6 +113,20 @@ class GSWTRenderer:
         n = 0 if gi is None else gi.shape[0]
         self._check(self._lib.gswt_set_draws(self._h, arr, len(draws), _ptr(gi), _ptr(mi), _ptr(li), n))
 
+    def set_draws_merge_groups(self, draws, groups_ptr, n_groups: int, members_ptr, n_members: int):
+        """SortData swap-in with the merged lists built on the device (groups / members: C arrays of
+        gswt_merge_group / gswt_merge_member, e.g. straight from libgswt_host's sort data)."""
+        arr = (L.Draw * max(1, len(draws)))(*draws)
+        self._check(self._lib.gswt_set_draws_merge_groups(self._h, arr, len(draws), groups_ptr, n_groups, members_ptr, n_members))
+
+    def read_merged(self):
+        n = C.c_size_t(0)
+        self._check(self._lib.gswt_debug_read_merged(self._h, None, None, 0, C.byref(n)))
+        a = np.zeros(max(1, n.value), dtype=np.uint32)
+        b = np.zeros(max(1, n.value), dtype=np.uint32)
+        self._check(self._lib.gswt_debug_read_merged(self._h, _ptr(a), _ptr(b), a.shape[0], C.byref(n)))
+        return a[:n.value], b[:n.value]
+
     # -- GSWTRenderer::render (renderer.rs:407) ---------------------------------------
     def render(self, camera, scene, width: int, height: int, *, culling_dist: float = 1.0,
                lod_enable_mask: int = 0xFFFFFFFF, order_mode: int = L.GSWT_ORDER_REFERENCE,

@@ -114,7 +114,8 @@ typedef struct {
     uint32_t cull_enable;   /* 1 iff render_data_key.tid.len() == 1                        */
     float corners[12];      /* tile_instance.corner_data[ci].0, ci = 0..3                  */
     uint32_t lod;           /* tid.0, index into lod_enable (renderer.rs:495)              */
-    uint32_t _pad[3];
+    uint32_t merged_group;  /* gswt_set_draws_merge_groups only: index of this draw's group        */
+    uint32_t _pad[2];
 } gswt_draw;
 
 /* The parts of RenderConfig (structure.rs:346-388) read on the hot path. */
@@ -181,6 +182,35 @@ GSWT_API int gswt_configure(gswt_ctx *ctx, const float *height_map, int hm_w, in
 GSWT_API int gswt_set_draws(gswt_ctx *ctx, const gswt_draw *draws, int n_draws,
                             const uint32_t *merged_gs_index, const uint32_t *merged_map_id,
                             const uint32_t *merged_lod_id, size_t n_merged);
+
+/* On-device merged lists (replaces the CPU hot loop of sort_tiles, wangtile.rs:595-670, and the per-sort-event
+ * upload of 12 B per merged splat, renderer.rs:517-561).
+ * gswt_upload_raw_depth: TileBaseData.raw_depth of every [lod][tile][view] (structure.rs:551; one i32 per splat
+ *   of that tile scene) and splats_merge_offset[lod][tile] (wangtile.rs:34), once after gswt_upload_scene.
+ * gswt_set_draws_merge_groups: like gswt_set_draws, but the merged arrays are built on the device from the
+ *   group descriptions: group g = one MergedFrom tile (view_id, members in from_vec order); member = (map index,
+ *   tid, and the other LOD it is Changing to, or -1).  A merged draw's merged_offset / merged_count must be
+ *   the group's range in the concatenation of all groups (sum of the members' raw-depth lengths, in order);
+ *   draws[i].merged_group names its group. */
+typedef struct {
+    uint32_t view_id;
+    uint32_t first_member;
+    uint32_t n_members;
+    uint32_t _pad;
+} gswt_merge_group;
+typedef struct {
+    uint32_t map_index;
+    uint32_t lod, tile;
+    int32_t other_lod;   /* lod + 1 for Changing(true), lod - 1 for Changing(false), -1 otherwise */
+} gswt_merge_member;
+GSWT_API int gswt_upload_raw_depth(gswt_ctx *ctx, const int32_t *const *raw_depth /* [n_lod*n_tile*n_view] */,
+                                   const uint32_t *counts /* [n_lod*n_tile] */,
+                                   const uint32_t *merge_offset /* [n_lod*n_tile] */);
+GSWT_API int gswt_set_draws_merge_groups(gswt_ctx *ctx, const gswt_draw *draws, int n_draws,
+                                         const gswt_merge_group *groups, int n_groups,
+                                         const gswt_merge_member *members, int n_members);
+/* Test hook: the device-resident merged arrays (gs_index | lod << 28, map id), n entries each. Host pointers. */
+GSWT_API int gswt_debug_read_merged(gswt_ctx *ctx, uint32_t *packed_list, uint32_t *map_id, size_t capacity, size_t *n);
 
 /* GSWTRenderer::render (renderer.rs:407-592), per frame.  bg_rgba (W*H*4 f32) is the
  * colour attachment content the pass loads (LoadOp::Load, :425; skybox/proxy output) or

@@ -126,6 +126,7 @@ typedef struct {
     uint32_t merged_count;
     int32_t single_lod_id;
     uint32_t cache_hit;               /* value came from the LRU cache (wangtile.rs:575-593)      */
+    uint32_t merged_group;            /* index into gswt_sort_data.groups when merged               */
 } gswt_sorted_tile;
 
 typedef struct {
@@ -133,7 +134,11 @@ typedef struct {
     uint32_t n_tiles;
     const gswt_sorted_tile *tiles;    /* back-to-front */
     size_t n_merged;
-    const uint32_t *merged_gs_index, *merged_map_id, *merged_lod_id;
+    const uint32_t *merged_gs_index, *merged_map_id, *merged_lod_id;   /* NULL in device-merge mode */
+    /* group descriptions for gswt_set_draws_merge_groups (always filled) */
+    uint32_t n_groups, n_members;
+    const gswt_merge_group *groups;
+    const gswt_merge_member *members;
 } gswt_sort_data;
 
 /* PreloadData (structure.rs:731-736) */
@@ -164,6 +169,14 @@ GSWT_API int gswt_wang_build_tiles(gswt_wang *w, const float cam_pos[3], gswt_sc
 /* WangTile::sort_tiles (wangtile.rs:476-690) */
 GSWT_API int gswt_wang_sort_tiles(gswt_wang *w, const float cam_pos[3], const float view_proj16[16],
                                   gswt_sort_data *out);
+/* Device-merge mode: sort_tiles only describes the merged groups (members, view) and leaves the
+ * counting sort of their splats to libgswt_hip (gswt_set_draws_merge_groups); the CPU lists and the LRU
+ * cache (wangtile.rs:575-593,642-675) are skipped. */
+GSWT_API int gswt_wang_set_device_merge(gswt_wang *w, int enable);
+/* Raw-depth tables for gswt_upload_raw_depth: ptrs[(lod*n_tile+tile)*n_view+view], counts / merge_offset [lod*n_tile+tile]. */
+GSWT_API int gswt_wang_raw_depth_tables(gswt_wang *w, const int32_t *const **ptrs, const uint32_t **counts,
+                                        const uint32_t **merge_offset);
+
 /* Inspect / override the tile-id map (tile ids come from an unpinned RNG in the reference; parity
  * fixtures pass them explicitly).  ids: tile_map_wh[0] * tile_map_wh[1], index = x * h + y. */
 GSWT_API int gswt_wang_get_tile_ids(const gswt_wang *w, uint32_t *ids, size_t cap);

@@ -171,3 +171,37 @@ def test_async_pipelined_frames_match_sync(renderer):
     for o, wimg in zip(outs, want):
         assert np.array_equal(o.cpu().numpy(), wimg)
     assert renderer.timings()["n_pairs"] > 0
+
+
+def test_device_side_merged_lists_bit_exact(renderer):
+    """gswt_set_draws_merge_groups: the merged-group lists built on the GPU (segmented stable radix sort on
+    (group, 16-bit depth bucket)) equal the host's Scene::sort_raw_depth_vec lists entry for entry, and the
+    rendered image is unchanged."""
+    from gswt_renderer_amd import _lib as L
+    cfg = dict(tile_map_half_wh=(4, 4), surface_type=0, lod_max_dist=22.0, tile_sort_type=3, merge_type=2, merge_topk=40)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=900)
+    W, Hh = 320, 200
+    for pos, tgt in (((4.2, 1.0, 1.5), (5.0, 4.0, 1.0)), ((-3.0, 2.5, 2.5), (-1.0, 7.0, 1.0))):
+        cu, vp = host.camera_uniforms(pos, tgt, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
+        ph = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer)
+        ph.update(pos, vp)
+        s = ph.sort
+        assert any(t.merged for t in s.tiles) and len(s.groups) >= 1
+        img_host = ph.render(cu, W, Hh)
+        want_list = s.merged_gs_index.copy()
+        has_lod = np.zeros(len(want_list), dtype=bool)
+        for t in s.tiles:
+            if t.merged and t.single_lod_id == -1:
+                has_lod[t.merged_offset:t.merged_offset + t.merged_count] = True
+        want_map = s.merged_map_id.copy()
+        want_lod = s.merged_lod_id.copy()
+        pd = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer, device_merge=True)
+        pd.update(pos, vp)
+        assert [t.map_index for t in pd.sort.tiles] == [t.map_index for t in s.tiles]
+        got_packed, got_map = renderer.read_merged()
+        assert got_packed.shape == want_list.shape
+        assert np.array_equal(got_packed & ((1 << 28) - 1), want_list)
+        assert np.array_equal(got_map, want_map)
+        assert np.array_equal((got_packed >> 28)[has_lod], want_lod[has_lod])
+        img_dev = pd.render(cu, W, Hh)
+        assert np.array_equal(img_dev, img_host)
