@@ -117,7 +117,7 @@ def main():
     W, H = w["width"], w["height"]
     r = GSWTRenderer(local_rank)                       # raises when libgswt_hip.so / the GPU is missing
     stream = torch.cuda.Stream(device=dev)
-    r.set_stream(stream.cuda_stream)                    # kernels, hipEvents and the all-gather share this stream
+    r.set_stream(stream.cuda_stream)                    # ctx stream: fences, all-gather and unshard are ordered on it
     from gswt_renderer_amd import _lib as L
     r.set_option(L.GSWT_OPT_TIMING, args.timing)
     wang.upload_to(r)
@@ -139,16 +139,20 @@ def main():
     last = [None]
 
     def submit(i):
+        # the frame runs on its slot's own stream (two frames overlap on the GPU); the all-gather of frame i is
+        # queued on the ctx stream behind a device-side fence, AFTER frame i+1 has been submitted
         o = outs[i % 2]
-        with torch.cuda.stream(stream):
-            ticket = r.render_async(cu, su, W, H, o.data_ptr(), transmittance_eps=args.t_eps, shard=shard)
-            if use_dist:
-                dist.all_gather_into_tensor(gathered, o)
-                r.unshard(gathered.data_ptr(), W, H, world, frame.data_ptr())
-        inflight.append(ticket)
+        ticket = r.render_async(cu, su, W, H, o.data_ptr(), transmittance_eps=args.t_eps, shard=shard)
+        inflight.append((ticket, o))
 
     def collect():
-        r.render_wait(inflight.pop(0))
+        ticket, o = inflight.pop(0)
+        if use_dist:
+            r.render_fence(ticket)
+            with torch.cuda.stream(stream):
+                dist.all_gather_into_tensor(gathered, o)
+                r.unshard(gathered.data_ptr(), W, H, world, frame.data_ptr())
+        r.render_wait(ticket)
         t = r.timings()
         comp_ms.append(t["ms_composite_kernel"]); total_ms.append(t["ms_total"]); pairs.append(t["n_pairs"])
         last[0] = t
@@ -160,6 +164,7 @@ def main():
                 collect()
         while inflight:
             collect()
+        stream.synchronize()
 
     run(args.warmup)
     comp_ms.clear(); total_ms.clear(); pairs.clear()

@@ -104,6 +104,7 @@ SYMBOLS = {
     "gswt_render": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int]),
     "gswt_render_async": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
     "gswt_render_wait": (C.c_int, [_P, C.c_int]),
+    "gswt_render_fence": (C.c_int, [_P, C.c_int]),
     "gswt_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "gswt_shard_rows_padded": (C.c_int, [C.c_int, C.c_int]),
     "gswt_unshard": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),

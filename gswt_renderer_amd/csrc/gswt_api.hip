@@ -38,7 +38,7 @@ void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*);
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint32_t*, float4*, hipEvent_t, hipEvent_t);
+                      uint32_t, uint32_t, uint32_t*, uint2*, float4*, hipEvent_t, hipEvent_t);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
 }  // namespace gswt
 
@@ -82,14 +82,33 @@ struct FrameArgs {
     float4* d_out = nullptr;
 };
 
+// One frame in flight.  Each slot owns a stream and every per-frame buffer, so two frames overlap on the GPU:
+// the latency-bound kernels of one (sort passes, single-workgroup scans, tails) fill the gaps of the other.
 struct FrameSlot {
+    hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};
+    hipEvent_t ev_in = nullptr;            // recorded on the ctx stream at enqueue: the frame starts after it
     unsigned long long* hc = nullptr;      // pinned host: [0] visible [1] pairs [2] scratch [3] overflow ... [7] staging
     bool pending = false;
     FrameArgs args;
     uint32_t cap = 0;
     int n_tiles = 0;
     int timing_level = 0;
+    // per-frame HBM buffers
+    DevBuf<uint2> rects;
+    DevBuf<Rec> recs;
+    DevBuf<uint32_t> block_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
+    DevBuf<uint2> ranges;
+    DevBuf<uint32_t> item_base;
+    DevBuf<uint2> item_tab;
+    DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x n_slots key/val ping-pong + per-block counts
+    DevBuf<float4> partials;
+    void release_buffers()
+    {
+        rects.release(); recs.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
+        keys_b.release(); vals_a.release(); vals_b.release(); ghist.release(); ranges.release(); item_base.release();
+        depth_ws.release(); partials.release(); item_tab.release();
+    }
 };
 
 struct gswt_ctx {
@@ -123,16 +142,9 @@ struct gswt_ctx {
     uint32_t n_draws = 0, n_chunks = 0;
     uint64_t n_entries = 0;
     bool draws_ready = false;
-    // frame
-    DevBuf<uint2> rects;
-    DevBuf<Rec> recs;
-    DevBuf<uint32_t> block_sums, super_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
+    // frame (the per-frame buffers live in the slots)
     uint32_t pair_cap = 0;                 // capacity the pair buffers / grids are sized for (grows on overflow)
-    DevBuf<uint2> ranges;
-    DevBuf<uint32_t> item_base;
-    DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x n_slots key/val ping-pong + per-block counts
-    DevBuf<float4> partials;
-    DevBuf<unsigned long long> counters;   // [0] visible splats, [1] pairs, [2] scan scratch, [3] pair-capacity overflow flag
+    int last_slot = 0;
     DevBuf<float4> bg_rgba, out_img;
     DevBuf<float> bg_depth;
     DevBuf<Varyings> dbg;
@@ -157,6 +169,15 @@ int fail(gswt_ctx* c, int code, const char* fmt, ...)
     va_end(ap);
     if (c) c->err = buf;
     return code;
+}
+
+ // waits for the ctx stream and every frame slot's stream
+hipError_t sync_all(gswt_ctx* c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    for (auto& sl : c->slots)
+        if (sl.stream) { hipError_t e2 = hipStreamSynchronize(sl.stream); if (e == hipSuccess) e = e2; }
+    return e;
 }
 
 #define HIP_TRY(c, expr)                                                                              \
@@ -193,12 +214,13 @@ int gswt_create(int device_id, gswt_ctx** out)
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
     for (auto& sl : c->slots) {
+        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+        if (hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         for (auto& e : sl.ev)
             if (hipEventCreate(&e) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         if (hipHostMalloc(reinterpret_cast<void**>(&sl.hc), 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         memset(sl.hc, 0, 8 * sizeof(unsigned long long));
     }
-    if (c->counters.ensure(8) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
     *out = c;
     return GSWT_OK;
 }
@@ -207,13 +229,17 @@ void gswt_destroy(gswt_ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    sync_all(c);
     c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release();
-    c->merged_list.release(); c->merged_map.release(); c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release(); c->mg_ws.release(); c->rects.release(); c->recs.release(); c->block_sums.release();
-    c->scan_ws.release(); c->super_sums.release(); c->draw_culled.release(); c->keys_a.release(); c->keys_b.release(); c->vals_a.release(); c->vals_b.release();
-    c->ghist.release(); c->ranges.release(); c->item_base.release(); c->partials.release(); c->depth_ws.release(); c->counters.release(); c->bg_rgba.release(); c->out_img.release();
-    c->bg_depth.release(); c->dbg.release();
-    for (auto& sl : c->slots) { for (auto& e : sl.ev) if (e) hipEventDestroy(e); if (sl.hc) hipHostFree(sl.hc); }
+    c->merged_list.release(); c->merged_map.release(); c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release();
+    c->mg_ws.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
+    for (auto& sl : c->slots) {
+        sl.release_buffers();
+        for (auto& e : sl.ev) if (e) hipEventDestroy(e);
+        if (sl.ev_in) hipEventDestroy(sl.ev_in);
+        if (sl.hc) hipHostFree(sl.hc);
+        if (sl.stream) hipStreamDestroy(sl.stream);
+    }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -223,7 +249,7 @@ const char* gswt_last_error(const gswt_ctx* c) { return c ? c->err.c_str() : "nu
 int gswt_set_stream(gswt_ctx* c, void* hip_stream)
 {
     if (!c) return GSWT_ERR_BAD_ARG;
-    hipStreamSynchronize(c->stream);
+    sync_all(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
@@ -254,7 +280,7 @@ int gswt_upload_scene(gswt_ctx* c, const uint32_t* tex_data, size_t n_splats, co
     if (n_lod > 16) return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_scene: n_lod %d > 16 (transition_dist_vec holds 16)", n_lod);
     if (n_splats > (size_t)kIdxMask) return fail(c, GSWT_ERR_CAPACITY, "gswt_upload_scene: %zu splats exceed 2^28", n_splats);
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     c->scene_ready = false; c->draws_ready = false;
     HIP_TRY(c, c->tex.ensure(2 * n_splats));
     HIP_TRY(c, hipMemcpy(c->tex.p, tex_data, n_splats * 32, hipMemcpyHostToDevice));
@@ -295,7 +321,7 @@ int gswt_configure(gswt_ctx* c, const float* height_map, int hm_w, int hm_h)
 {
     if (!c) return GSWT_ERR_BAD_ARG;
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     if (!height_map || hm_w <= 0 || hm_h <= 0) { c->hm_w = c->hm_h = 0; return GSWT_OK; }
     HIP_TRY(c, c->hmap.ensure((size_t)hm_w * hm_h));
     HIP_TRY(c, hipMemcpy(c->hmap.p, height_map, (size_t)hm_w * hm_h * 4, hipMemcpyHostToDevice));
@@ -314,7 +340,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     if (!device_merge && n_merged && (!merged_gs_index || !merged_map_id)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged arrays missing");
     if (n_merged >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: merged lists exceed 2^32 entries");
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     c->draws_ready = false;
     std::vector<DrawDev> dd((size_t)n_draws);
     uint64_t entries = 0;
@@ -393,14 +419,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     c->n_draws = (uint32_t)n_draws;
     c->n_chunks = (uint32_t)chunks.size();
     c->n_entries = entries;
-    // per-slot frame buffers
-    const size_t n_slots = (size_t)c->n_chunks * kChunk;
-    HIP_TRY(c, c->rects.ensure(n_slots + 1));
-    HIP_TRY(c, c->recs.ensure(n_slots + 1));
-    HIP_TRY(c, c->block_sums.ensure((size_t)c->n_chunks + 1));
-    HIP_TRY(c, c->super_sums.ensure(2 * ((size_t)c->n_chunks / 256 + 1) + 2));
-    HIP_TRY(c, c->draw_culled.ensure((size_t)n_draws + 1));
-    c->draws_ready = true;
+    c->draws_ready = true;       // the per-frame buffers are sized by enqueue_frame, per slot
     return GSWT_OK;
 }
 
@@ -415,7 +434,7 @@ int gswt_upload_raw_depth(gswt_ctx* c, const int32_t* const* raw_depth, const ui
     if (!c || !raw_depth || !counts || !merge_offset) return GSWT_ERR_BAD_ARG;
     if (!c->scene_ready) return fail(c, GSWT_ERR_STATE, "gswt_upload_raw_depth before gswt_upload_scene");
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     const size_t nlt = (size_t)c->n_lod * c->n_tile, nv = (size_t)c->n_view;
     c->raw_cnt.assign(counts, counts + nlt);
     c->raw_merge_offset.assign(merge_offset, merge_offset + nlt);
@@ -511,7 +530,7 @@ int gswt_debug_read_merged(gswt_ctx* c, uint32_t* packed_list, uint32_t* map_id,
     if (!packed_list || !map_id) return GSWT_OK;
     if (capacity < c->n_merged) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu entries, need %zu", capacity, c->n_merged);
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     if (c->n_merged) {
         HIP_TRY(c, hipMemcpy(packed_list, c->merged_list.p, c->n_merged * 4, hipMemcpyDeviceToHost));
         HIP_TRY(c, hipMemcpy(map_id, c->merged_map.p, c->n_merged * 4, hipMemcpyDeviceToHost));
@@ -567,8 +586,19 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     const gswt_scene_uniforms* su = &a.su;
     const gswt_render_config* cfg = &a.cfg;
     const int width = a.width, height = a.height;
-    hipStream_t s = c->stream;
+    hipStream_t s = sl.stream;
     const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
+    // the frame starts after everything submitted to the ctx stream so far (inputs produced there, earlier
+    // readers of the output buffer), and runs on the slot's own stream
+    HIP_TRY(c, hipEventRecord(sl.ev_in, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(s, sl.ev_in, 0));
+    {
+        const size_t n_slots_all = (size_t)c->n_chunks * kChunk;
+        HIP_TRY(c, sl.rects.ensure(n_slots_all + 1));
+        HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
+        HIP_TRY(c, sl.block_sums.ensure((size_t)c->n_chunks + 1));
+        HIP_TRY(c, sl.draw_culled.ensure((size_t)c->n_draws + 1));
+    }
 
     Frame f;
     memset(&f, 0, sizeof(f));
@@ -606,7 +636,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     const size_t out_px = (size_t)out_rows * width;
     sl.n_tiles = n_tiles;
     float4* const d_out = a.d_out;
-    HIP_TRY(c, c->ranges.ensure((size_t)n_tiles + 1));
+    HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1));
     const bool dbg = c->opt_debug_varyings != 0;
     if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)c->n_entries + 1));
     if (sc > 1 && out_rows * width > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
@@ -620,61 +650,63 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_entries / 4, 1u << 20), 0xFFFFFF00ull);
     const uint32_t cap = c->pair_cap;
     sl.cap = cap;
-    HIP_TRY(c, c->keys_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->keys_b.ensure((size_t)cap + 1));
-    HIP_TRY(c, c->vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, c->vals_b.ensure((size_t)cap + 1));
+    HIP_TRY(c, sl.keys_a.ensure((size_t)cap + 1)); HIP_TRY(c, sl.keys_b.ensure((size_t)cap + 1));
+    HIP_TRY(c, sl.vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure((size_t)cap + 1));
     const size_t n_super2 = 2 * ((size_t)c->n_chunks / 256 + 1);
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
     const uint32_t n_slots = c->n_chunks * (uint32_t)kChunk;
     const size_t depth_radix_words = depth_order ? radix_ws_words(n_slots, 32) : 0;
     const size_t radix_words = radix_ws_words(cap, key_bits) + depth_radix_words;
     if (depth_order) {
-        HIP_TRY(c, c->depth_ws.ensure(4 * (size_t)n_slots + (size_t)c->n_chunks + 16));
-        HIP_TRY(c, c->scan_ws.ensure((size_t)c->n_chunks / 1024 + 4096));
+        HIP_TRY(c, sl.depth_ws.ensure(4 * (size_t)n_slots + (size_t)c->n_chunks + 16));
+        HIP_TRY(c, sl.scan_ws.ensure((size_t)c->n_chunks / 1024 + 4096));
     }
     // one contiguous u32 region cleared by k_cull: [counters: 16][super_sums: n_super2][radix histograms]
-    HIP_TRY(c, c->ghist.ensure(16 + n_super2 + radix_words + 16));
-    uint32_t* const zero_a = c->ghist.p;
+    HIP_TRY(c, sl.ghist.ensure(16 + n_super2 + radix_words + 16));
+    uint32_t* const zero_a = sl.ghist.p;
     unsigned long long* const d_counters = reinterpret_cast<unsigned long long*>(zero_a);
     uint32_t* const d_super = zero_a + 16;
     uint32_t* const d_radix = d_super + n_super2;
     const uint32_t seg = (uint32_t)c->opt_segment;
-    HIP_TRY(c, c->item_base.ensure((size_t)n_tiles + 2));
-    HIP_TRY(c, c->partials.ensure(((size_t)n_tiles + cap / seg + 1) * 256));
+    HIP_TRY(c, sl.item_base.ensure((size_t)n_tiles + 2));
+    HIP_TRY(c, sl.partials.ensure(((size_t)n_tiles + cap / seg + 1) * 256));
+    HIP_TRY(c, sl.item_tab.ensure((size_t)n_tiles + cap / seg + 2));
     unsigned long long* const d_P = d_counters + 1;
     hipEvent_t* ev = sl.ev;
     // ---- cull (+ clears the frame's accumulators) + project
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
-    launch_cull(s, f, c->draws.p, c->n_draws, c->draw_culled.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
-                reinterpret_cast<uint32_t*>(c->ranges.p), (uint32_t)n_tiles * 2u);
+    launch_cull(s, f, c->draws.p, c->n_draws, sl.draw_culled.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
+                reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
     launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
-                   c->tex.p, c->hmap.p, c->draw_culled.p, c->rects.p, c->recs.p, c->block_sums.p, d_super,
+                   c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
     // ---- emit
     if (!depth_order) {
-        launch_emit(s, f, c->n_chunks, c->rects.p, c->block_sums.p, d_super, cap, d_counters, c->keys_a.p, c->vals_a.p);
+        launch_emit(s, f, c->n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     } else {
         // d_counters[4] = n_slots (the radix kernels read their item count from device memory)
         sl.hc[7] = n_slots;
         HIP_TRY(c, hipMemcpyAsync(d_counters + 4, &sl.hc[7], 8, hipMemcpyHostToDevice, s));
-        uint32_t* dw = c->depth_ws.p;
-        launch_emit_depth(s, f, n_slots, d_counters + 4, c->rects.p, c->recs.p, c->block_sums.p, dw, dw + n_slots, dw + 2 * (size_t)n_slots,
-                          dw + 3 * (size_t)n_slots, d_radix + radix_ws_words(cap, key_bits), dw + 4 * (size_t)n_slots, c->scan_ws.p,
-                          reinterpret_cast<uint32_t*>(d_counters + 2), cap, d_counters, c->keys_a.p, c->vals_a.p);
+        uint32_t* dw = sl.depth_ws.p;
+        launch_emit_depth(s, f, n_slots, d_counters + 4, sl.rects.p, sl.recs.p, sl.block_sums.p, dw, dw + n_slots, dw + 2 * (size_t)n_slots,
+                          dw + 3 * (size_t)n_slots, d_radix + radix_ws_words(cap, key_bits), dw + 4 * (size_t)n_slots, sl.scan_ws.p,
+                          reinterpret_cast<uint32_t*>(d_counters + 2), cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     }
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
     // ---- stable sort on the tile bits
-    int where = launch_sort(s, c->keys_a.p, c->vals_a.p, c->keys_b.p, c->vals_b.p, cap, d_P, key_bits, d_radix);
-    const uint32_t* keys_sorted = where ? c->keys_b.p : c->keys_a.p;
-    const uint32_t* vals_sorted = where ? c->vals_b.p : c->vals_a.p;
+    int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix);
+    const uint32_t* keys_sorted = where ? sl.keys_b.p : sl.keys_a.p;
+    const uint32_t* vals_sorted = where ? sl.vals_b.p : sl.vals_a.p;
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[4], s));
     // ---- ranges
-    launch_ranges(s, keys_sorted, cap, d_P, c->ranges.p, (uint32_t)n_tiles);
+    launch_ranges(s, keys_sorted, cap, d_P, sl.ranges.p, (uint32_t)n_tiles);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[5], s));
     // ---- composite
-    launch_composite(s, f, c->ranges.p, vals_sorted, c->recs.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
-                     c->item_base.p, nullptr, c->partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr);
+    launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
+                     sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr);
     c->last_n_tiles = (uint32_t)n_tiles;
+    c->last_slot = (int)(&sl - c->slots);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(sl.hc, d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -791,6 +823,16 @@ int gswt_render_wait(gswt_ctx* c, int ticket)
     return finish_frame(c, sl);
 }
 
+int gswt_render_fence(gswt_ctx* c, int ticket)
+{
+    if (!c || ticket < 0 || ticket >= kFrameSlots) return GSWT_ERR_BAD_ARG;
+    FrameSlot& sl = c->slots[ticket];
+    if (!sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render_fence: ticket %d is not in flight", ticket);
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.ev[9], 0));
+    return GSWT_OK;
+}
+
 int gswt_unshard(gswt_ctx* c, const float* gathered, int width, int height, int shard_count, float* out_rgba)
 {
     if (!c || !gathered || !out_rgba || width <= 0 || height <= 0 || shard_count < 1) return GSWT_ERR_BAD_ARG;
@@ -805,7 +847,7 @@ int gswt_synchronize(gswt_ctx* c)
 {
     if (!c) return GSWT_ERR_BAD_ARG;
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     return GSWT_OK;
 }
 
@@ -823,8 +865,8 @@ int gswt_debug_read_ranges(gswt_ctx* c, uint32_t* out, size_t capacity_tiles, si
     if (!out) return GSWT_OK;
     if (capacity_tiles < c->last_n_tiles) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu tiles, need %u", capacity_tiles, c->last_n_tiles);
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out, c->ranges.p, (size_t)c->last_n_tiles * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, sync_all(c));
+    HIP_TRY(c, hipMemcpy(out, c->slots[c->last_slot].ranges.p, (size_t)c->last_n_tiles * 8, hipMemcpyDeviceToHost));
     return GSWT_OK;
 }
 
@@ -836,7 +878,7 @@ int gswt_debug_read_projected(gswt_ctx* c, void* out, size_t capacity_entries, s
     if (!c->opt_debug_varyings || !c->dbg.p) return fail(c, GSWT_ERR_STATE, "enable GSWT_OPT_DEBUG_VARYINGS and render first");
     if (capacity_entries < c->n_entries) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu entries, need %llu", capacity_entries, (unsigned long long)c->n_entries);
     hipSetDevice(c->device);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(out, c->dbg.p, (size_t)c->n_entries * sizeof(Varyings), hipMemcpyDeviceToHost));
     return GSWT_OK;
 }

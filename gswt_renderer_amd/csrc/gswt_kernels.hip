@@ -786,10 +786,11 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 // ------------------------------------------------------------------------------------
 // Work items: a tile's pair list is cut into segments of `seg` pairs; item = (tile, segment).
 // seg_count[t] = max(1, ceil(len / seg)) so empty tiles still get one item (they write the background).
-// item_base[t] = exclusive scan of seg_count, item_base[n_tiles] = number of items.  Single workgroup
-// (n_tiles is a few thousand to a few tens of thousands): one launch instead of count + 3 scan launches.
+// item_base[t] = exclusive scan of seg_count, item_base[n_tiles] = number of items; item_tab[item] =
+// (tile, segment << 1 | tile has several segments).  Single workgroup (n_tiles is a few thousand to a few
+// tens of thousands): one launch instead of count + 3 scan launches.
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
-                                                uint32_t* __restrict__ item_base)
+                                                uint32_t* __restrict__ item_base, uint2* __restrict__ item_tab, uint32_t max_items)
 {
     __shared__ uint32_t s_w[16];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -807,7 +808,12 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
         for (uint32_t i = 0; i < 16u; i++) { if (i < w) wbase += s_w[i]; tot += s_w[i]; }
-        if (t < n_tiles) item_base[t] = carry + wbase + inc - cnt;
+        if (t < n_tiles) {
+            const uint32_t first = carry + wbase + inc - cnt;
+            item_base[t] = first;
+            const uint32_t multi = cnt > 1u ? 1u : 0u;
+            for (uint32_t k = 0; k < cnt && first + k < max_items; k++) item_tab[first + k] = make_uint2((uint32_t)t, (k << 1) | multi);
+        }
         carry += tot;
         __syncthreads();
     }
@@ -818,32 +824,35 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
 __device__ unsigned long long g_stats[8];
 #define GSWT_STAT_STEP(C) { unsigned long long cm_ = __ballot(C); if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[0], 1ull); \
     atomicAdd(&g_stats[1], (unsigned long long)__popcll(cm_)); if (cm_ == 0ull) atomicAdd(&g_stats[2], 1ull); } }
+#define GSWT_STAT_BATCH(NMAX, C0, C1, C2, C3) { if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)(NMAX)); \
+    atomicAdd(&g_stats[5], (unsigned long long)((C0) + (C1) + (C2) + (C3))); } }
 #else
 #define GSWT_STAT_STEP(C)
+#define GSWT_STAT_BATCH(NMAX, C0, C1, C2, C3)
 #endif
+// LDS record of a staged pair (two 16-B words; one more dword when a depth buffer is bound):
+//   q0 = (iu.x, iu.y, -ku, log2 alpha)   q1 = (iv.x, iv.y, -kv, rgba8 bits)
+// alpha rides in the exponent (B = 2^(-r2 log2 e + log2 alpha): one fma + v_exp), the colour stays packed and is
+// unpacked by v_cvt_f32_ubyteN in the blend; the accumulators run in 0..255 units and are scaled once at the end.
 template <bool EARLY, bool DEPTH>
 __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
-                                                   const uint32_t* __restrict__ item_base, uint32_t seg,
-                                                   const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
+                                                   const uint32_t* __restrict__ item_base, const uint2* __restrict__ item_tab,
+                                                   uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
                                                    const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
                                                    float4* __restrict__ out, float4* __restrict__ partials,
                                                    int n_tiles, int out_rows)
 {
-    __shared__ float4 s_q0[256], s_q1[256], s_q2[256], s_q3[256];
+    __shared__ float4 s_q0[256], s_q1[256], s_bb[256];
+    __shared__ float s_dep[DEPTH ? 256 : 1];
     __shared__ uint8_t s_list[4][4][260];         // [wave][sub-block][i] -> index of the i-th hit in the batch (+4: prefetch overrun)
-    // work item -> (tile, segment): item_base is the exclusive scan of per-tile segment counts
-    // (item_base[n_tiles] = number of items).  Consecutive items are dealt round-robin over the
-    // 8 XCDs by the dispatcher, which balances the skewed tile-list lengths.
+    // work item -> (tile, segment) through the table k_items left behind.  Consecutive items are dealt
+    // round-robin over the 8 XCDs by the dispatcher, which balances the skewed tile-list lengths.
     const uint32_t item = blockIdx.x;
     if (item >= item_base[n_tiles]) return;
-    int lo = 0, hi = n_tiles;                       // largest t with item_base[t] <= item
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (item_base[mid] <= item) lo = mid; else hi = mid;
-    }
-    const int tile = lo;
-    const uint32_t seg_idx = item - item_base[tile];
-    const uint32_t n_seg = item_base[tile + 1] - item_base[tile];
+    const uint2 it = item_tab[item];
+    const int tile = (int)it.x;
+    const uint32_t seg_idx = it.y >> 1;
+    const bool multi_seg = (it.y & 1u) != 0u;
     const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
@@ -877,27 +886,38 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
     // stale index can name must hold finite data: zero-fill once (each lane its own entry; staging overwrites).
     s_q0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_q2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DEPTH) s_dep[tid] = 0.0f;
+    // Software-pipelined gather: the records of batch b+1 and the slot indices of batch b+2 are in flight
+    // while batch b is binned and walked (two dependent HBM latencies per batch otherwise sit between barriers).
+    // The loads are unconditional with clamped indices (lanes past the end re-read the last pair and never stage
+    // it): a load under a lane mask would be merged back through register copies that wait for it on the spot.
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    uint32_t slot_nxt = 0;
+    const uint32_t last_pair = rg.y - 1u;
+    if (rg.x < rg.y && !(f.dbg_flags & 4)) {
+        const float4* rp = reinterpret_cast<const float4*>(recs + vals[min(rg.x + tid, last_pair)]);
+        ra = rp[0]; rb = rp[1]; rc = rp[2];
+        slot_nxt = vals[min(rg.x + 256u + tid, last_pair)];
+    }
     for (uint32_t base = rg.x; base < rg.y; base += 256u) {
         const uint32_t n = min(256u, rg.y - base);
         if (f.dbg_flags & 4) break;                       // ablation: no staging at all
         if (tid < n) {
-            const uint32_t slot = vals[base + tid];
-            const float4* rp = reinterpret_cast<const float4*>(recs + slot);
-            const float4 a = rp[0], b = rp[1], c = rp[2];
             // F3: per-(splat, tile) constants
-            const float ox = a.z - fbx, oy = b.z - fby;
-            const float nku = -fmaf(a.x, ox, a.y * oy);
-            const float nkv = -fmaf(b.x, ox, b.y * oy);
-            const uint32_t cw = __float_as_uint(c.x);
-            const float k255 = 1.0f / 255.0f;      // colour is continuous: x * (1/255) vs x / 255 differs by <= 1 ulp
-            s_q0[tid] = make_float4(a.x, a.y, nku, a.w);
-            s_q1[tid] = make_float4(b.x, b.y, nkv, b.w);
-            s_q2[tid] = make_float4((float)(cw & 0xFFu) * k255, (float)((cw >> 8) & 0xFFu) * k255,
-                                    (float)((cw >> 16) & 0xFFu) * k255, 0.0f);
-            s_q3[tid] = make_float4(ox - c.y, ox + c.y, oy - c.z, oy + c.z);     // pixel bbox, tile-local
+            const float ox = ra.z - fbx, oy = rb.z - fby;
+            const float nku = -fmaf(ra.x, ox, ra.y * oy);
+            const float nkv = -fmaf(rb.x, ox, rb.y * oy);
+            s_q0[tid] = make_float4(ra.x, ra.y, nku, __builtin_amdgcn_logf(ra.w));   // v_log_f32 = log2; log2(0) = -inf -> B = 0
+            s_q1[tid] = make_float4(rb.x, rb.y, nkv, rc.x);
+            s_bb[tid] = make_float4(ox - rc.y, ox + rc.y, oy - rc.z, oy + rc.z);     // pixel bbox, tile-local
+            if (DEPTH) s_dep[tid] = rb.w;
         }
         __syncthreads();
+        {
+            const float4* rp = reinterpret_cast<const float4*>(recs + slot_nxt);
+            ra = rp[0]; rb = rp[1]; rc = rp[2];
+            slot_nxt = vals[min(base + 512u + tid, last_pair)];
+        }
         if (wave_live && !(f.dbg_flags & 2)) {             // ablation bit 2: stage only
             // bin: append this batch's hits to the four sub-block lists (list order preserved)
             uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
@@ -906,7 +926,7 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
                 const uint32_t idx = (uint32_t)c * 64u + lane;
                 bool hl = false, hr = false, ht = false, hb = false;
                 if (idx < n) {
-                    const float4 bb = s_q3[idx];                     // (x_lo, x_hi, y_lo, y_hi) of the pixel-centre box
+                    const float4 bb = s_bb[idx];                     // (x_lo, x_hi, y_lo, y_hi) of the pixel-centre box
                     hl = bb.y >= xl0 && bb.x <= xl1; hr = bb.y >= xr0 && bb.x <= xr1;
                     ht = bb.w >= yt0 && bb.z <= yt1; hb = bb.w >= yb0 && bb.z <= yb1;
                 }
@@ -922,11 +942,12 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
             }
             const uint32_t n_mine = grp == 0u ? cnt0 : grp == 1u ? cnt1 : grp == 2u ? cnt2 : cnt3;
             const uint32_t n_max = max(max(cnt0, cnt1), max(cnt2, cnt3));
+            GSWT_STAT_BATCH(n_max, cnt0, cnt1, cnt2, cnt3)
             // walk: one splat per 16-lane group per step.  Two-deep software pipeline, unrolled x2 so the
             // two record register sets (A, B) never need copying: the list byte is fetched two steps
             // ahead, the record one step ahead (entries past a list's end are stale but in-range; the
             // step is masked by `i < n_mine`).
-#define GSWT_STEP(Q0, Q1, Q2, I)                                                                        \
+#define GSWT_STEP(Q0, Q1, DV, I)                                                                        \
             {                                                                                           \
                 const float pu_y = fmaf(Q0.y, ly, Q0.z);                                                \
                 const float pv_y = fmaf(Q1.y, ly, Q1.z);                                                \
@@ -934,30 +955,34 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
                 const float ppy = fmaf(Q1.x, lx, pv_y);                                                 \
                 const float r2 = fmaf(ppy, ppy, ppx * ppx);                                             \
                 bool cover = ((I) < n_mine) && r2 <= 4.0f;                                              \
-                if (DEPTH) cover = cover && Q1.w < dbuf;                                                \
+                if (DEPTH) cover = cover && DV < dbuf;                                                  \
                 if (EARLY) cover = cover && T >= t_eps;                                                 \
                 GSWT_STAT_STEP(cover)                                                                   \
                 if (__ballot(cover) != 0ull) { /* wave-uniform skip; lanes are predicated, not masked */ \
-                    const float e = __builtin_amdgcn_exp2f(r2 * -1.4426950408889634f) * Q0.w;           \
+                    const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q0.w));       \
                     const float Bv = cover ? e : 0.0f;                                                  \
                     const float wgt = T * Bv;                                                           \
-                    ar = fmaf(wgt, Q2.x, ar);                                                           \
-                    ag = fmaf(wgt, Q2.y, ag);                                                           \
-                    ab = fmaf(wgt, Q2.z, ab);                                                           \
+                    const uint32_t cw = __float_as_uint(Q1.w);                                          \
+                    ar = fmaf(wgt, (float)(cw & 0xFFu), ar);                                            \
+                    ag = fmaf(wgt, (float)((cw >> 8) & 0xFFu), ag);                                     \
+                    ab = fmaf(wgt, (float)((cw >> 16) & 0xFFu), ab);                                    \
                     T = T - wgt;                                                                        \
                 }                                                                                       \
             }
             if (!(f.dbg_flags & 1) && n_max) {
                 uint32_t kA = my_list[0], kB = my_list[1];
-                float4 a0 = s_q0[kA], a1 = s_q1[kA], a2 = s_q2[kA];
+                float4 a0 = s_q0[kA], a1 = s_q1[kA];
+                float da = DEPTH ? s_dep[kA] : 0.0f, db = 0.0f;
                 for (uint32_t i = 0; i < n_max; i += 2u) {
-                    const float4 b0 = s_q0[kB], b1 = s_q1[kB], b2 = s_q2[kB];   // record of step i+1
+                    const float4 b0 = s_q0[kB], b1 = s_q1[kB];                     // record of step i+1
+                    if (DEPTH) db = s_dep[kB];
                     kA = my_list[i + 2u];                                          // index of step i+2
-                    GSWT_STEP(a0, a1, a2, i)
+                    GSWT_STEP(a0, a1, da, i)
                     if (i + 1u >= n_max) break;
-                    a0 = s_q0[kA]; a1 = s_q1[kA]; a2 = s_q2[kA];                   // record of step i+2
+                    a0 = s_q0[kA]; a1 = s_q1[kA];                                  // record of step i+2
+                    if (DEPTH) da = s_dep[kA];
                     kB = my_list[i + 3u];                                          // index of step i+3
-                    GSWT_STEP(b0, b1, b2, i + 1u)
+                    GSWT_STEP(b0, b1, db, i + 1u)
                 }
             }
 #undef GSWT_STEP
@@ -966,7 +991,9 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
         if (EARLY) { if (__syncthreads_and(wave_live ? 0 : 1)) break; }
         else __syncthreads();
     }
-    if (n_seg > 1u) {
+    const float k255 = 1.0f / 255.0f;      // colour is continuous: sum(w * byte) / 255 vs sum(w * (byte / 255)) differ in the last bits only
+    ar *= k255; ag *= k255; ab *= k255;
+    if (multi_seg) {
         // partial (C, T) of this segment; k_combine folds the segments front to back
         partials[(size_t)item * 256u + tid] = make_float4(ar, ag, ab, T);
         return;
@@ -1160,17 +1187,16 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const un
 // k_composite over an upper bound of items -> k_combine.
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
                       const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
-                      uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint32_t* scan_ws, float4* partials,
+                      uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint2* item_tab, float4* partials,
                       hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     if (n_tiles == 0) return;
-    (void)scan_ws;
-    hipLaunchKernelGGL(k_items, dim3(1), dim3(1024), 0, s, ranges, n_tiles, seg, item_base);
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
+    hipLaunchKernelGGL(k_items, dim3(1), dim3(1024), 0, s, ranges, n_tiles, seg, item_base, item_tab, max_items);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0;
     if (ev_begin) hipEventRecord(ev_begin, s);
 #define GSWT_LAUNCH_COMPOSITE(E, D)                                                                                         \
-    hipLaunchKernelGGL((k_composite<E, D>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, seg, vals, recs, bg_rgba, \
+    hipLaunchKernelGGL((k_composite<E, D>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, item_tab, seg, vals, recs, bg_rgba, \
                        bg_depth, out, partials, n_tiles, out_rows)
     if (early && depth) GSWT_LAUNCH_COMPOSITE(true, true);
     else if (early) GSWT_LAUNCH_COMPOSITE(true, false);

@@ -177,6 +177,10 @@ class GSWTRenderer:
     def render_wait(self, ticket: int):
         self._check(self._lib.gswt_render_wait(self._h, ticket))
 
+    def render_fence(self, ticket: int):
+        """Device-side: work submitted to the ctx stream afterwards waits for this frame."""
+        self._check(self._lib.gswt_render_fence(self._h, ticket))
+
     def shard_rows_padded(self, height: int, shard_count: int) -> int:
         return int(self._lib.gswt_shard_rows_padded(height, shard_count))
 

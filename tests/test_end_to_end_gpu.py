@@ -161,6 +161,7 @@ def test_async_pipelined_frames_match_sync(renderer):
     su = pipe.wang.scene_uniforms()
     want = [renderer.render(cu, su, W, Hh) for cu, _ in cams]
     outs = [torch.zeros((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+    torch.cuda.synchronize()          # the zero fills ran on torch's stream, the frames run on the ctx's slot streams
     tickets = []
     for (cu, _), o in zip(cams, outs):
         tickets.append(renderer.render_async(cu, su, W, Hh, o.data_ptr()))
