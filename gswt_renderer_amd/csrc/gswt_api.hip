@@ -32,12 +32,12 @@ void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, MergeGroup*, uin
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, const uint32_t*, const uint32_t*,
                     const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, uint32_t*, uint32_t*,
-                    unsigned long long*, Varyings*);
+                    unsigned long long*, Varyings*, float4*);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
                  uint32_t*, uint32_t*);
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*);
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
-void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float*, float4*, int, int,
+void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint2*, float4*, hipEvent_t, hipEvent_t);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
 }  // namespace gswt
@@ -103,11 +103,12 @@ struct FrameSlot {
     DevBuf<uint2> item_tab;
     DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x n_slots key/val ping-pong + per-block counts
     DevBuf<float4> partials;
+    DevBuf<float4> col_f;                  // debug draw modes: float colours per slot
     void release_buffers()
     {
         rects.release(); recs.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
         keys_b.release(); vals_a.release(); vals_b.release(); ghist.release(); ranges.release(); item_base.release();
-        depth_ws.release(); partials.release(); item_tab.release();
+        depth_ws.release(); partials.release(); item_tab.release(); col_f.release();
     }
 };
 
@@ -353,6 +354,9 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
         d.changing = g.tile.changing;
         d.changing_to_lower = g.tile.changing_to_lower;
         d.tile_lod = g.tile.tile_id[0];
+        d.tile_idx = g.tile.tile_id[1]; d.tile_view = g.tile.tile_id[2];
+        d.single_lod_id = g.tile.single_lod_id;
+        d.map_coord[0] = g.tile.map_coord[0]; d.map_coord[1] = g.tile.map_coord[1];
         d.off[0] = g.tile.offset[0]; d.off[1] = g.tile.offset[1]; d.off[2] = g.tile.offset[2];
         d.cull_enable = g.cull_enable;
         d.lod = g.lod;
@@ -569,8 +573,10 @@ static int validate_frame(gswt_ctx* c, const gswt_camera_uniforms* cam, const gs
         return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: camera viewport (%g,%g) != target %dx%d", cam->viewport[0], cam->viewport[1], width, height);
     if (su->surface_type == 1u && (c->hm_w == 0 || c->hm_h == 0))
         return fail(c, GSWT_ERR_STATE, "gswt_render: surface_type HeightMap without gswt_configure height map");
-    if (su->surface_type > 1u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: surface_type %u not supported yet", su->surface_type);
-    if (su->draw_mode != 0u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: debug draw modes are not part of the hot path");
+    if (su->surface_type > 2u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: unknown surface_type %u", su->surface_type);
+    if (su->surface_type == 2u && (su->map_half_wh[0] == 0u || su->map_half_wh[1] == 0u))
+        return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: Sphere surface needs a non-empty map");
+    if (su->draw_mode > 4u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: unknown draw_mode %u", su->draw_mode);
     if (cfg->order_mode != GSWT_ORDER_REFERENCE && cfg->order_mode != GSWT_ORDER_DEPTH)
         return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: unknown order mode %d", cfg->order_mode);
     const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
@@ -598,6 +604,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.block_sums.ensure((size_t)c->n_chunks + 1));
         HIP_TRY(c, sl.draw_culled.ensure((size_t)c->n_draws + 1));
+        if (su->draw_mode != 0u) HIP_TRY(c, sl.col_f.ensure(n_slots_all + 1));
     }
 
     Frame f;
@@ -617,6 +624,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     f.W = (float)width; f.H = (float)height;
     f.splat_scale = su->splat_scale; f.tile_width = su->tile_width; f.clip_height = su->clip_height;
     f.point_cloud_radius = su->point_cloud_radius; f.transition_width_ratio = su->transition_width_ratio;
+    f.sphere_radius = su->sphere_radius;
     f.use_clip = su->use_clip; f.surface_type = su->surface_type; f.num_lod = su->num_lod; f.draw_mode = su->draw_mode;
     f.map_half_wh[0] = su->map_half_wh[0]; f.map_half_wh[1] = su->map_half_wh[1];
     f.center_coord[0] = su->center_coord[0]; f.center_coord[1] = su->center_coord[1];
@@ -679,7 +687,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
     launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, sl.block_sums.p, d_super,
-                   d_counters, c->dbg.p);
+                   d_counters, c->dbg.p, sl.col_f.p);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
     // ---- emit
     if (!depth_order) {
@@ -703,7 +711,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     launch_ranges(s, keys_sorted, cap, d_P, sl.ranges.p, (uint32_t)n_tiles);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[5], s));
     // ---- composite
-    launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
+    launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
                      sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr);
     c->last_n_tiles = (uint32_t)n_tiles;
     c->last_slot = (int)(&sl - c->slots);

@@ -27,7 +27,10 @@ struct DrawDev {
     uint32_t lod;             // tid.0 for lod_enable
     float corners[12];
     uint32_t entry_base;      // index of the first entry in draw order (debug output)
-    uint32_t _pad;
+    int32_t single_lod_id;    // TileUniforms.single_lod_id (debug draw mode 3)
+    uint32_t tile_idx;        // tile_id.y (debug draw mode 1)
+    uint32_t tile_view;       // tile_id.z (debug draw mode 4)
+    uint32_t map_coord[2];    // TileUniforms.map_coord (sphere surface)
 };
 
 // Per-frame constants (kernel argument, by value).
@@ -40,7 +43,7 @@ struct Frame {
     float cam_pos[3];
     float W, H;
     // scene uniforms
-    float splat_scale, tile_width, clip_height, point_cloud_radius, transition_width_ratio;
+    float splat_scale, tile_width, clip_height, point_cloud_radius, transition_width_ratio, sphere_radius;
     uint32_t use_clip, surface_type, num_lod, draw_mode;
     uint32_t map_half_wh[2];
     int32_t center_coord[2];

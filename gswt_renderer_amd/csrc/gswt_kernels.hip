@@ -49,6 +49,117 @@ __device__ __forceinline__ float sample_height(const float* __restrict__ hm, int
     return i0 * (1.0f - ty) + i1 * ty;
 }
 
+// Canonical sin / cos (operation sequence fixed in DESIGN.md section 4; the CPU checker restates it): WGSL leaves sin()/cos()
+// accuracy to the implementation, so what must hold is CPU-oracle == GPU bit for bit.
+__device__ __forceinline__ void csincosf(float x, float& sn, float& cs)
+{
+    const float kf = rintf(x * 0.636619772367581343f);
+    float r = fmaf(kf, -1.5703125f, x);
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    const float s = fmaf(ps * z, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const int q = (int)kf & 3;
+    float so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    if (q == 2 || q == 3) so = -so;
+    if (q == 1 || q == 2) co = -co;
+    sn = so; cs = co;
+}
+
+// sphere_get_uv + sphere_uv_to_pos, gswt.wgsl:515-564
+__device__ __forceinline__ void sphere_point(float block_w, float bidx, float bidy, float bx, float by, float p[3])
+{
+    const float PI = 3.1415926535897932384626433832795f;
+    float u, v;
+    if (bidy == 0.0f) {
+        if (by < bx) {
+            if (bx - by == block_w) u = 0.0f;
+            else u = (by / (block_w - (bx - by)) + bidx) / 5.0f;
+            v = ((block_w - (bx - by)) / block_w) / 3.0f;
+        } else {
+            u = (bx / block_w + bidx) / 5.0f + ((by - bx) / block_w) * 0.1f;
+            v = ((by - bx) / block_w) / 3.0f + (1.0f / 3.0f);
+        }
+    } else {
+        if (by < bx) {
+            u = (bx / block_w + bidx) / 5.0f + ((block_w - (bx - by)) / block_w) * 0.1f;
+            v = ((block_w - (bx - by)) / block_w) / 3.0f + (1.0f / 3.0f);
+        } else {
+            if (by - bx == block_w) u = 0.0f;
+            else u = (bx / (block_w - (by - bx)) + bidx) / 5.0f + 0.1f;
+            v = ((by - bx) / block_w) / 3.0f + (2.0f / 3.0f);
+        }
+    }
+    u = u + 0.5f * floorf(v);
+    u = u * (2.0f * PI);
+    v = (v - 0.5f) * PI;
+    float su, cu, sv, cv;
+    csincosf(u, su, cu);
+    csincosf(v, sv, cv);
+    p[0] = cv * cu; p[1] = cv * su; p[2] = sv;
+}
+
+// rand(), gswt.wgsl:502-504
+__device__ __forceinline__ float dbg_rand(float cx, float cy)
+{
+    const float d = cx * 12.9898f + cy * 78.233f;
+    float sn, cs;
+    csincosf(d, sn, cs);
+    const float v = sn * 43758.5453f;
+    return v - floorf(v);
+}
+
+// Debug draw recolouring, gswt.wgsl:268-399 (draw_mode 1..4); rgb in / out
+__device__ __forceinline__ void debug_draw_color(const Frame& f, const DrawDev& d, float vx, float vy, uint32_t lod_id, float t_ratio,
+                                                 float& cr, float& cg, float& cb)
+{
+    const float tw = f.tile_width;
+    if (f.draw_mode == 1u) {
+        const float g = clampf(((cr + cg) + cb) / 0.6f, 0.0f, 1.0f);
+        cr = cg = cb = g;
+        const float margin = 0.05f * tw;
+        const bool sphere = f.surface_type == 2u;
+        if (d.single_draw == 1u) {
+            cr = cr * dbg_rand(d.off[0], d.off[1]);
+            cg = cg * dbg_rand(d.off[0] + 23.45f, d.off[1] + 23.45f);
+            cb = cb * dbg_rand(d.off[0] + 67.89f, d.off[1] + 67.89f);
+        } else if (vx < margin || vx > tw - margin) {
+            const uint32_t bit = vx < margin ? d.tile_idx / 8u % 2u : d.tile_idx / 2u % 2u;
+            if (vy < margin || vy > tw - margin) { cr = cg = cb = 0.5f; }
+            else if (bit == 0u) { cr = 1.0f; cg = 0.0f; cb = 0.0f; }
+            else { cr = 0.0f; cg = 1.0f; cb = 0.13f; }
+        } else if (vy < margin || vy > tw - margin) {
+            const uint32_t bit = vy < margin ? d.tile_idx % 2u : d.tile_idx / 4u % 2u;
+            if (bit == 0u) {
+                if (sphere) { cr = 1.0f; cg = 0.0f; cb = 0.0f; } else { cr = 1.0f; cg = 0.85f; cb = 0.0f; }
+            } else {
+                if (sphere) { cr = 0.0f; cg = 1.0f; cb = 0.13f; } else { cr = 0.0f; cg = 0.58f; cb = 1.0f; }
+            }
+        }
+    } else if (f.draw_mode == 2u || f.draw_mode == 3u) {
+        if (t_ratio > 0.0f && t_ratio < 1.0f) { cr = cg = cb = 0.0f; return; }
+        if (f.draw_mode == 2u && d.changing == 1u) { cr = 0.0f; cg = 1.0f; cb = 0.0f; return; }
+        uint32_t L = d.tile_lod;
+        if (f.draw_mode == 3u) L = d.single_lod_id >= 0 ? (uint32_t)d.single_lod_id : lod_id;
+        float cx = 0.0f, cy = 1.0f;
+        if (L < 3u) cx = (3.0f - (float)L) / 3.0f;
+        else cy = (6.0f - (float)L) / 3.0f;
+        cr = 0.5f; cg = cx; cb = cy;
+    } else if (f.draw_mode == 4u) {
+        const uint32_t v = d.tile_view;
+        float cx = 0.0f, cy = 0.0f;
+        if (v < 4u) cx = (4.0f - (float)v) / 4.0f;
+        if (v >= 4u) cy = (8.0f - (float)v) / 4.0f;
+        if (v >= 8u) { cx = 1.0f; cy = 1.0f; }
+        cr = 0.5f; cg = cx; cb = cy;
+    }
+}
+
 // Number of 16-px tile rows in [ty0, ty1] owned by this shard (row % count == index).
 __device__ __forceinline__ int owned_rows(int ty0, int ty1, int index, int count)
 {
@@ -104,7 +215,7 @@ __global__ __launch_bounds__(256) void k_project(
     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
     const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, uint2* __restrict__ rects,
     Rec* __restrict__ recs, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
-    Varyings* __restrict__ dbg)
+    Varyings* __restrict__ dbg, float4* __restrict__ col_f)
 {
     __shared__ uint32_t s_wsum[4], s_wvis[4];
     const uint2 ct = chunk_tab[blockIdx.x];
@@ -182,7 +293,41 @@ __global__ __launch_bounds__(256) void k_project(
                 c2 = nz + F[8] * z;
                 mapped_z = nz;
             } else if (f.surface_type == 2u) {
-                break;  // sphere mapping not built yet
+                // surface_mapping, gswt.wgsl:600-623 (icosahedral-strip parametrisation, 5 x 2 blocks)
+                const float DELTA = 0.001f;
+                const float xmax = ((float)f.map_half_wh[0] * 2.0f) * f.tile_width;
+                const float ymax = ((float)f.map_half_wh[1] * 2.0f) * f.tile_width;
+                const float block_w = xmax / 5.0f;
+                const float nx = c0 - (float)(f.center_coord[0] - (int32_t)f.map_half_wh[0]) * f.tile_width;
+                const float ny = c1 - (float)(f.center_coord[1] - (int32_t)f.map_half_wh[1]) * f.tile_width;
+                float bidx = (float)(5u * d.map_coord[0] / (f.map_half_wh[0] * 2u));
+                float bidy = (float)(2u * d.map_coord[1] / (f.map_half_wh[1] * 2u));
+                if (d.single_draw == 1u) {
+                    const uint32_t map_height = 2u * f.map_half_wh[1];
+                    const uint32_t map_id = merged_map[d.list_base + j];
+                    bidx = (float)(5u * (map_id / map_height) / (f.map_half_wh[0] * 2u));
+                    bidy = (float)(2u * (map_id % map_height) / (f.map_half_wh[1] * 2u));
+                }
+                const float bx = nx - bidx * block_w, by = ny - bidy * block_w;
+                float lz[3], pr[3], pl[3], pu[3], pd[3];
+                sphere_point(block_w, bidx, bidy, bx, by, lz);
+                const float R = f.sphere_radius;
+                const float dt = DELTA * ymax;
+                sphere_point(block_w, bidx, bidy, bx + dt, by, pr);
+                sphere_point(block_w, bidx, bidy, bx - dt, by, pl);
+                sphere_point(block_w, bidx, bidy, bx, by + dt, pu);
+                sphere_point(block_w, bidx, bidy, bx, by - dt, pd);
+                for (int k = 0; k < 3; k++) {
+                    F[k] = (pr[k] * R - pl[k] * R) / (2.0f * dt);
+                    F[3 + k] = (pu[k] * R - pd[k] * R) / (2.0f * dt);
+                    F[6 + k] = lz[k];
+                }
+                const float z = c2;
+                const float n0 = lz[0] * R, n1 = lz[1] * R, n2 = lz[2] * R;
+                c0 = n0 + F[6] * z;
+                c1 = n1 + F[7] * z;
+                c2 = n2 + F[8] * z;
+                mapped_z = n2;
             }
             if (f.use_clip == 1u && mapped_z < f.clip_height) break;
             // A5 :91-150
@@ -281,6 +426,7 @@ __global__ __launch_bounds__(256) void k_project(
             float cg = (float)((w1.w >> 8) & 0xFFu) / 255.0f;
             float cb = (float)((w1.w >> 16) & 0xFFu) / 255.0f;
             float ca = (float)((w1.w >> 24) & 0xFFu) / 255.0f;
+            if (f.draw_mode != 0u) debug_draw_color(f, d, u2f(w0.x), u2f(w0.y), lod_id, t_ratio, cr, cg, cb);   // :268-399
             if (d.changing == 1u) {
                 if (lod_id != higher_lod) ca = ca * t_ratio;
                 else ca = ca * (1.0f - t_ratio);
@@ -330,6 +476,7 @@ __global__ __launch_bounds__(256) void k_project(
                     reinterpret_cast<float4*>(dst)[0] = make_float4(r_iux, r_iuy, cxp, ca);
                     reinterpret_cast<float4*>(dst)[1] = make_float4(r_ivx, r_ivy, cyp, depth);
                     reinterpret_cast<float4*>(dst)[2] = make_float4(__uint_as_float(w1.w), hx, hy, 0.0f);
+                    if (f.draw_mode != 0u) col_f[slot] = make_float4(cr, cg, cb, 0.0f);   // debug colours are not bytes
                 }
             }
         } while (0);
@@ -834,15 +981,18 @@ __device__ unsigned long long g_stats[8];
 //   q0 = (iu.x, iu.y, -ku, log2 alpha)   q1 = (iv.x, iv.y, -kv, rgba8 bits)
 // alpha rides in the exponent (B = 2^(-r2 log2 e + log2 alpha): one fma + v_exp), the colour stays packed and is
 // unpacked by v_cvt_f32_ubyteN in the blend; the accumulators run in 0..255 units and are scaled once at the end.
-template <bool EARLY, bool DEPTH>
+// COLF (debug draw modes only): colours are floats from the side buffer col_f[slot], staged into a third LDS word.
+template <bool EARLY, bool DEPTH, bool COLF>
 __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ item_base, const uint2* __restrict__ item_tab,
                                                    uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
+                                                   const float4* __restrict__ col_f,
                                                    const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
                                                    float4* __restrict__ out, float4* __restrict__ partials,
                                                    int n_tiles, int out_rows)
 {
     __shared__ float4 s_q0[256], s_q1[256], s_bb[256];
+    __shared__ float4 s_q2[COLF ? 256 : 1];
     __shared__ float s_dep[DEPTH ? 256 : 1];
     __shared__ uint8_t s_list[4][4][260];         // [wave][sub-block][i] -> index of the i-th hit in the batch (+4: prefetch overrun)
     // work item -> (tile, segment) through the table k_items left behind.  Consecutive items are dealt
@@ -887,16 +1037,19 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
     s_q0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (DEPTH) s_dep[tid] = 0.0f;
+    if (COLF) s_q2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
     // Software-pipelined gather: the records of batch b+1 and the slot indices of batch b+2 are in flight
     // while batch b is binned and walked (two dependent HBM latencies per batch otherwise sit between barriers).
     // The loads are unconditional with clamped indices (lanes past the end re-read the last pair and never stage
     // it): a load under a lane mask would be merged back through register copies that wait for it on the spot.
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
     uint32_t slot_nxt = 0;
     const uint32_t last_pair = rg.y - 1u;
     if (rg.x < rg.y && !(f.dbg_flags & 4)) {
-        const float4* rp = reinterpret_cast<const float4*>(recs + vals[min(rg.x + tid, last_pair)]);
+        const uint32_t slot0 = vals[min(rg.x + tid, last_pair)];
+        const float4* rp = reinterpret_cast<const float4*>(recs + slot0);
         ra = rp[0]; rb = rp[1]; rc = rp[2];
+        if (COLF) rd = col_f[slot0];
         slot_nxt = vals[min(rg.x + 256u + tid, last_pair)];
     }
     for (uint32_t base = rg.x; base < rg.y; base += 256u) {
@@ -911,11 +1064,13 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
             s_q1[tid] = make_float4(rb.x, rb.y, nkv, rc.x);
             s_bb[tid] = make_float4(ox - rc.y, ox + rc.y, oy - rc.z, oy + rc.z);     // pixel bbox, tile-local
             if (DEPTH) s_dep[tid] = rb.w;
+            if (COLF) s_q2[tid] = rd;
         }
         __syncthreads();
         {
             const float4* rp = reinterpret_cast<const float4*>(recs + slot_nxt);
             ra = rp[0]; rb = rp[1]; rc = rp[2];
+            if (COLF) rd = col_f[slot_nxt];
             slot_nxt = vals[min(base + 512u + tid, last_pair)];
         }
         if (wave_live && !(f.dbg_flags & 2)) {             // ablation bit 2: stage only
@@ -947,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
             // two record register sets (A, B) never need copying: the list byte is fetched two steps
             // ahead, the record one step ahead (entries past a list's end are stale but in-range; the
             // step is masked by `i < n_mine`).
-#define GSWT_STEP(Q0, Q1, DV, I)                                                                        \
+#define GSWT_STEP(Q0, Q1, Q2, DV, I)                                                                    \
             {                                                                                           \
                 const float pu_y = fmaf(Q0.y, ly, Q0.z);                                                \
                 const float pv_y = fmaf(Q1.y, ly, Q1.z);                                                \
@@ -963,26 +1118,30 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
                     const float Bv = cover ? e : 0.0f;                                                  \
                     const float wgt = T * Bv;                                                           \
                     const uint32_t cw = __float_as_uint(Q1.w);                                          \
-                    ar = fmaf(wgt, (float)(cw & 0xFFu), ar);                                            \
-                    ag = fmaf(wgt, (float)((cw >> 8) & 0xFFu), ag);                                     \
-                    ab = fmaf(wgt, (float)((cw >> 16) & 0xFFu), ab);                                    \
+                    ar = fmaf(wgt, COLF ? Q2.x : (float)(cw & 0xFFu), ar);                              \
+                    ag = fmaf(wgt, COLF ? Q2.y : (float)((cw >> 8) & 0xFFu), ag);                       \
+                    ab = fmaf(wgt, COLF ? Q2.z : (float)((cw >> 16) & 0xFFu), ab);                      \
                     T = T - wgt;                                                                        \
                 }                                                                                       \
             }
             if (!(f.dbg_flags & 1) && n_max) {
                 uint32_t kA = my_list[0], kB = my_list[1];
                 float4 a0 = s_q0[kA], a1 = s_q1[kA];
+                float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a2;
+                if (COLF) a2 = s_q2[kA];
                 float da = DEPTH ? s_dep[kA] : 0.0f, db = 0.0f;
                 for (uint32_t i = 0; i < n_max; i += 2u) {
                     const float4 b0 = s_q0[kB], b1 = s_q1[kB];                     // record of step i+1
+                    if (COLF) b2 = s_q2[kB];
                     if (DEPTH) db = s_dep[kB];
                     kA = my_list[i + 2u];                                          // index of step i+2
-                    GSWT_STEP(a0, a1, da, i)
+                    GSWT_STEP(a0, a1, a2, da, i)
                     if (i + 1u >= n_max) break;
                     a0 = s_q0[kA]; a1 = s_q1[kA];                                  // record of step i+2
+                    if (COLF) a2 = s_q2[kA];
                     if (DEPTH) da = s_dep[kA];
                     kB = my_list[i + 3u];                                          // index of step i+3
-                    GSWT_STEP(b0, b1, db, i + 1u)
+                    GSWT_STEP(b0, b1, b2, db, i + 1u)
                 }
             }
 #undef GSWT_STEP
@@ -992,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
         else __syncthreads();
     }
     const float k255 = 1.0f / 255.0f;      // colour is continuous: sum(w * byte) / 255 vs sum(w * (byte / 255)) differ in the last bits only
-    ar *= k255; ag *= k255; ab *= k255;
+    if (!COLF) { ar *= k255; ag *= k255; ab *= k255; }
     if (multi_seg) {
         // partial (C, T) of this segment; k_combine folds the segments front to back
         partials[(size_t)item * 256u + tid] = make_float4(ar, ag, ab, T);
@@ -1073,16 +1232,16 @@ void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
                     const float* hmap, const uint32_t* draw_culled, uint2* rects, Rec* recs, uint32_t* block_sums,
-                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg)
+                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f)
 {
     if (n_chunks == 0) return;
     const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs x n_super][visible x n_super], zeroed by the caller
     if (debug)
         hipLaunchKernelGGL(k_project<true>, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,
-                           merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg);
+                           merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg, col_f);
     else
         hipLaunchKernelGGL(k_project<false>, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,
-                           merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg);
+                           merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg, col_f);
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters);
 }
 
@@ -1186,22 +1345,26 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const un
 // ranges -> per-tile segment counts -> item_base (exclusive scan, item_base[n_tiles] = #items) ->
 // k_composite over an upper bound of items -> k_combine.
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
-                      const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
+                      const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint2* item_tab, float4* partials,
                       hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     if (n_tiles == 0) return;
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
     hipLaunchKernelGGL(k_items, dim3(1), dim3(1024), 0, s, ranges, n_tiles, seg, item_base, item_tab, max_items);
-    const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0;
+    const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
-#define GSWT_LAUNCH_COMPOSITE(E, D)                                                                                         \
-    hipLaunchKernelGGL((k_composite<E, D>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, item_tab, seg, vals, recs, bg_rgba, \
-                       bg_depth, out, partials, n_tiles, out_rows)
-    if (early && depth) GSWT_LAUNCH_COMPOSITE(true, true);
-    else if (early) GSWT_LAUNCH_COMPOSITE(true, false);
-    else if (depth) GSWT_LAUNCH_COMPOSITE(false, true);
-    else GSWT_LAUNCH_COMPOSITE(false, false);
+#define GSWT_LAUNCH_COMPOSITE(E, D, C)                                                                                         \
+    hipLaunchKernelGGL((k_composite<E, D, C>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, item_tab, seg, vals, recs, \
+                       col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
+    if (colf) {                       // debug draw modes: float colours from the side buffer
+        if (depth) GSWT_LAUNCH_COMPOSITE(false, true, true);
+        else GSWT_LAUNCH_COMPOSITE(false, false, true);
+    }
+    else if (early && depth) GSWT_LAUNCH_COMPOSITE(true, true, false);
+    else if (early) GSWT_LAUNCH_COMPOSITE(true, false, false);
+    else if (depth) GSWT_LAUNCH_COMPOSITE(false, true, false);
+    else GSWT_LAUNCH_COMPOSITE(false, false, false);
 #undef GSWT_LAUNCH_COMPOSITE
     if (ev_end) hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows);

@@ -61,4 +61,9 @@ class GSWTPipeline:
     def render(self, camera_uniforms, width, height, **kw):
         su = self.wang.scene_uniforms(splat_scale=kw.pop("splat_scale", 1.0), scene_scale=kw.pop("scene_scale", (1.0, 1.0, 1.0)),
                                       height_map_scale_v=kw.pop("height_map_scale_v", 1.0))
+        # the other RenderConfig fields of SceneUniforms::from_data (renderer.rs:631-672)
+        su.draw_mode = int(kw.pop("draw_mode", 0))
+        su.point_cloud_radius = float(kw.pop("point_cloud_radius", 0.0))
+        su.use_clip = int(kw.pop("use_clip", 0))
+        su.clip_height = float(kw.pop("clip_height", 0.0))
         return self.renderer.render(camera_uniforms, su, width, height, **kw)

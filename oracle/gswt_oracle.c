@@ -330,7 +330,183 @@ static void surface_mapping_hmap(const orc_scene *s, const float *hm, int hw, in
     tr[6] = cz[0] / len; tr[7] = cz[1] / len; tr[8] = cz[2] / len;
 }
 
-/* vs_main, gswt.wgsl:27-422, draw_mode 0.  Canonical float sequence "A1..A10"
+/* Canonical sin / cos.  WGSL leaves the accuracy of sin()/cos() to the implementation, so the
+ * reference's own values are unpinnable; what must hold here is that the CPU oracle and the HIP
+ * kernels produce the SAME bits (the sphere mapping feeds discontinuous decisions, and the debug
+ * colour hash rand() amplifies one ulp of sin by 43758).  Both sides therefore evaluate this
+ * sequence: k = rint(x * 2/pi); three-term Cody-Waite reduction with fmaf; Cephes sinf/cosf
+ * minimax polynomials on [-pi/4, pi/4]; quadrant fix-up.  |x| < ~1e5. */
+ORC_API void orc_sincosf(float x, float *sn, float *cs)
+{
+    float kf = rintf(x * 0.636619772367581343f);
+    float r = fmaf(kf, -1.5703125f, x);
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.54978995489188216e-8f, r);
+    float z = r * r;
+    float ps = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = fmaf(ps, z, -1.6666654611e-1f);
+    float s = fmaf(ps * z, r, r);
+    float pc = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = fmaf(pc, z, 4.166664568298827e-2f);
+    float c = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    int q = (int)kf & 3;
+    float so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    if (q == 2 || q == 3) so = -so;
+    if (q == 1 || q == 2) co = -co;
+    *sn = so; *cs = co;
+}
+
+/* sphere_get_uv, gswt.wgsl:515-555 */
+static void sphere_get_uv(const orc_scene *s, float bidx, float bidy, float bx, float by, float uv[2])
+{
+    const float PI = 3.1415926535897932384626433832795f;
+    float xmax = ((float)s->map_half_wh[0] * 2.0f) * s->tile_width;
+    float block_w = xmax / 5.0f;
+    float u, v;
+    if (bidy == 0.0f) {
+        if (by < bx) {
+            if (bx - by == block_w) u = 0.0f;
+            else u = (by / (block_w - (bx - by)) + bidx) / 5.0f;
+            v = ((block_w - (bx - by)) / block_w) / 3.0f;
+        } else {
+            u = (bx / block_w + bidx) / 5.0f + ((by - bx) / block_w) * 0.1f;
+            v = ((by - bx) / block_w) / 3.0f + (1.0f / 3.0f);
+        }
+    } else {
+        if (by < bx) {
+            u = (bx / block_w + bidx) / 5.0f + ((block_w - (bx - by)) / block_w) * 0.1f;
+            v = ((block_w - (bx - by)) / block_w) / 3.0f + (1.0f / 3.0f);
+        } else {
+            if (by - bx == block_w) u = 0.0f;
+            else u = (bx / (block_w - (by - bx)) + bidx) / 5.0f + 0.1f;
+            v = ((by - bx) / block_w) / 3.0f + (2.0f / 3.0f);
+        }
+    }
+    u = u + 0.5f * floorf(v);
+    u = u * (2.0f * PI);
+    v = (v - 0.5f) * PI;
+    uv[0] = u; uv[1] = v;
+}
+
+/* sphere_uv_to_pos, gswt.wgsl:558-564 */
+static void sphere_uv_to_pos(const float uv[2], float p[3])
+{
+    float su, cu, sv, cv;
+    orc_sincosf(uv[0], &su, &cu);
+    orc_sincosf(uv[1], &sv, &cv);
+    p[0] = cv * cu; p[1] = cv * su; p[2] = sv;
+}
+
+/* surface_mapping, gswt.wgsl:565-624, Sphere branch (surface_type == 2). */
+static void surface_mapping_sphere(const orc_scene *s, const orc_tile *u, uint32_t map_id,
+                                   float px, float py, float new_pos[3], float tr[9])
+{
+    const float DELTA = 0.001f;
+    float xmax = ((float)s->map_half_wh[0] * 2.0f) * s->tile_width;
+    float ymax = ((float)s->map_half_wh[1] * 2.0f) * s->tile_width;
+    float block_w = xmax / 5.0f;
+    float nx = px - (float)(s->center_coord[0] - (int32_t)s->map_half_wh[0]) * s->tile_width;
+    float ny = py - (float)(s->center_coord[1] - (int32_t)s->map_half_wh[1]) * s->tile_width;
+    float bidx = (float)(5u * u->map_coord[0] / (s->map_half_wh[0] * 2u));
+    float bidy = (float)(2u * u->map_coord[1] / (s->map_half_wh[1] * 2u));
+    if (u->single_draw == 1u) {
+        uint32_t map_height = 2u * s->map_half_wh[1];
+        uint32_t mcx = map_id / map_height, mcy = map_id % map_height;
+        bidx = (float)(5u * mcx / (s->map_half_wh[0] * 2u));
+        bidy = (float)(2u * mcy / (s->map_half_wh[1] * 2u));
+    }
+    float bx = nx - bidx * block_w;
+    float by = ny - bidy * block_w;
+    float uv[2], lz[3];
+    sphere_get_uv(s, bidx, bidy, bx, by, uv);
+    sphere_uv_to_pos(uv, lz);
+    float R = s->sphere_radius;
+    for (int k = 0; k < 3; k++) new_pos[k] = lz[k] * R;
+    float dt = DELTA * ymax;
+    float pr[3], pl[3], pu[3], pd[3];
+    sphere_get_uv(s, bidx, bidy, bx + dt, by, uv); sphere_uv_to_pos(uv, pr);
+    sphere_get_uv(s, bidx, bidy, bx - dt, by, uv); sphere_uv_to_pos(uv, pl);
+    sphere_get_uv(s, bidx, bidy, bx, by + dt, uv); sphere_uv_to_pos(uv, pu);
+    sphere_get_uv(s, bidx, bidy, bx, by - dt, uv); sphere_uv_to_pos(uv, pd);
+    for (int k = 0; k < 3; k++) {
+        tr[k] = (pr[k] * R - pl[k] * R) / (2.0f * dt);
+        tr[3 + k] = (pu[k] * R - pd[k] * R) / (2.0f * dt);
+        tr[6 + k] = lz[k];
+    }
+}
+
+/* rand / randomVec3, gswt.wgsl:502-512 (debug draw mode 1) */
+static float dbg_rand(float cx, float cy)
+{
+    float d = cx * 12.9898f + cy * 78.233f;
+    float sn, cs;
+    orc_sincosf(d, &sn, &cs);
+    float v = sn * 43758.5453f;
+    return v - floorf(v);
+}
+
+/* Debug draw recolouring, gswt.wgsl:268-399 (draw_mode 1..4).  rgb in / out, alpha untouched. */
+static void debug_draw_color(const orc_scene *s, const orc_tile *u, const float vpos[3], uint32_t lod_id,
+                             float t_ratio, float rgb[3])
+{
+    const float tw = s->tile_width;
+    switch (s->draw_mode) {
+    case 1u: {
+        float g = clampf(((rgb[0] + rgb[1]) + rgb[2]) / 0.6f, 0.0f, 1.0f);
+        rgb[0] = rgb[1] = rgb[2] = g;
+        float margin = 0.05f * tw;
+        const int sphere = s->surface_type == 2u;
+        if (u->single_draw == 1u) {
+            float ox = u->offset[0], oy = u->offset[1];
+            rgb[0] = rgb[0] * dbg_rand(ox, oy);
+            rgb[1] = rgb[1] * dbg_rand(ox + 23.45f, oy + 23.45f);
+            rgb[2] = rgb[2] * dbg_rand(ox + 67.89f, oy + 67.89f);
+        } else if (vpos[0] < margin) {
+            if (vpos[1] < margin || vpos[1] > tw - margin) { rgb[0] = rgb[1] = rgb[2] = 0.5f; }
+            else if (u->tile_id[1] / 8u % 2u == 0u) { rgb[0] = 1.0f; rgb[1] = 0.0f; rgb[2] = 0.0f; }
+            else { rgb[0] = 0.0f; rgb[1] = 1.0f; rgb[2] = 0.13f; }
+        } else if (vpos[0] > tw - margin) {
+            if (vpos[1] < margin || vpos[1] > tw - margin) { rgb[0] = rgb[1] = rgb[2] = 0.5f; }
+            else if (u->tile_id[1] / 2u % 2u == 0u) { rgb[0] = 1.0f; rgb[1] = 0.0f; rgb[2] = 0.0f; }
+            else { rgb[0] = 0.0f; rgb[1] = 1.0f; rgb[2] = 0.13f; }
+        } else if (vpos[1] < margin || vpos[1] > tw - margin) {
+            const uint32_t bit = vpos[1] < margin ? u->tile_id[1] % 2u : u->tile_id[1] / 4u % 2u;
+            if (bit == 0u) {
+                if (sphere) { rgb[0] = 1.0f; rgb[1] = 0.0f; rgb[2] = 0.0f; }
+                else { rgb[0] = 1.0f; rgb[1] = 0.85f; rgb[2] = 0.0f; }
+            } else {
+                if (sphere) { rgb[0] = 0.0f; rgb[1] = 1.0f; rgb[2] = 0.13f; }
+                else { rgb[0] = 0.0f; rgb[1] = 0.58f; rgb[2] = 1.0f; }
+            }
+        }
+        break;
+    }
+    case 2u:
+    case 3u: {
+        if (t_ratio > 0.0f && t_ratio < 1.0f) { rgb[0] = rgb[1] = rgb[2] = 0.0f; break; }
+        if (s->draw_mode == 2u && u->changing == 1u) { rgb[0] = 0.0f; rgb[1] = 1.0f; rgb[2] = 0.0f; break; }
+        uint32_t L = u->tile_id[0];
+        if (s->draw_mode == 3u) L = u->single_lod_id >= 0 ? (uint32_t)u->single_lod_id : lod_id;
+        float cx = 0.0f, cy = 1.0f;
+        if (L < 3u) cx = (3.0f - (float)L) / 3.0f;
+        else cy = (6.0f - (float)L) / 3.0f;
+        rgb[0] = 0.5f; rgb[1] = cx; rgb[2] = cy;
+        break;
+    }
+    case 4u: {
+        uint32_t v = u->tile_id[2];
+        float cx = 0.0f, cy = 0.0f;
+        if (v < 4u) cx = (4.0f - (float)v) / 4.0f;
+        if (v >= 4u) cy = (8.0f - (float)v) / 4.0f;
+        if (v >= 8u) { cx = 1.0f; cy = 1.0f; }
+        rgb[0] = 0.5f; rgb[1] = cx; rgb[2] = cy;
+        break;
+    }
+    default: break;
+    }
+}
+
+/* vs_main, gswt.wgsl:27-422, every draw_mode.  Canonical float sequence "A1..A10"
  * of DESIGN.md.  Returns out->visible. */
 ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_tile *u,
                         const uint32_t *tex, uint32_t gs_index, uint32_t map_id, uint32_t lod_id,
@@ -366,7 +542,13 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
         c[2] = np[2] + F[8] * z;
         mapped_z = np[2];
     } else if (s->surface_type == 2u) {
-        return 0;   /* sphere mapping: SURVEY 8f rank 4, not restated yet */
+        float np[3];
+        surface_mapping_sphere(s, u, map_id, c[0], c[1], np, F);
+        float z = c[2];
+        c[0] = np[0] + F[6] * z;
+        c[1] = np[1] + F[7] * z;
+        c[2] = np[2] + F[8] * z;
+        mapped_z = np[2];
     }
     if (s->use_clip == 1u && mapped_z < s->clip_height) return 0;
     /* A5 :91-150 */
@@ -478,6 +660,7 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
     out->rgba[1] = (float)((cw >> 8) & 0xFFu) / 255.0f;
     out->rgba[2] = (float)((cw >> 16) & 0xFFu) / 255.0f;
     out->rgba[3] = (float)((cw >> 24) & 0xFFu) / 255.0f;
+    if (s->draw_mode != 0u) debug_draw_color(s, u, pos, lod_id, t_ratio, out->rgba);   /* :268-399 */
     if (u->changing == 1u) {
         if (lod_id != higher_lod) out->rgba[3] = out->rgba[3] * t_ratio;
         else out->rgba[3] = out->rgba[3] * (1.0f - t_ratio);

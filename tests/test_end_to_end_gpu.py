@@ -15,7 +15,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0.0, shard=None, culling_dist=1.0, order_mode=0):
+def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0.0, shard=None, culling_dist=1.0, order_mode=0,
+              render_config=None):
+    """render_config: RenderConfig fields of SceneUniforms (draw_mode, point_cloud_radius, use_clip, clip_height)."""
+    rc = dict(render_config or {})
     verts = synth.make_tileset(n_lod=n_lod, n_tile=16, lod0_count=lod0)
     pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer)
     cu, vp = host.camera_uniforms(cam[0], cam[1], (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
@@ -28,7 +31,7 @@ def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0
     osd = ow.build_tiles(cam[0])
     osort = ow.sort_tiles(cam[0], ocam.view_proj())
     odraws = wo.renderer_draws(pp, osort, ocam.view_proj(), culling_dist=culling_dist)
-    osu = wo.scene_uniforms_from_data(ou, osd["center_coord"])
+    osu = wo.scene_uniforms_from_data(ou, osd["center_coord"], **rc)
     hm = ou.height_map.reshape(ou.height_map_wh[1], ou.height_map_wh[0]) if ou.surface_type == 1 else None
     bg_rgba = bg_depth = None
     if bg:
@@ -42,7 +45,7 @@ def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0
         kinds["merged" if d.tile.single_draw else ("blend" if d.tile.changing else "plain")] += 1
     if shard is None:
         img = pipe.render(cu, W, Hh, bg_rgba=bg_rgba, bg_depth=bg_depth, transmittance_eps=t_eps, culling_dist=culling_dist,
-                          order_mode=order_mode)
+                          order_mode=order_mode, **rc)
         t = renderer.timings()
         assert t["n_visible"] == st["n_visible"]
         assert t["n_pairs"] == st["n_pairs16"]
@@ -52,7 +55,7 @@ def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0
         img = np.zeros((Hh, W, 4), dtype=np.float32)
         for r in range(n):
             part = pipe.render(cu, W, Hh, bg_rgba=bg_rgba, bg_depth=bg_depth, shard=(r, n), culling_dist=culling_dist,
-                               order_mode=order_mode)
+                               order_mode=order_mode, **rc)
             assert part.shape == (rows_p, W, 4)
             for y in range(Hh):
                 ty = y // 16
@@ -206,3 +209,23 @@ def test_device_side_merged_lists_bit_exact(renderer):
         assert np.array_equal((got_packed >> 28)[has_lod], want_lod[has_lod])
         img_dev = pd.render(cu, W, Hh)
         assert np.array_equal(img_dev, img_host)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_debug_draw_modes(renderer, mode):
+    """draw_mode 1..4 (TileID / TileLOD / LOD / View recolouring, gswt.wgsl:268-399) on a frame with plain, blending
+    and merged draws; mode 1 hashes the merged head's offset through the canonical sin (rand(), :502-512)."""
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    img, ref, kinds, st = _run_case(renderer, cfg, ((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)), 320, 208, render_config=dict(draw_mode=mode))
+    assert kinds["plain"] > 0 and kinds["blend"] > 0 and kinds["merged"] > 0, kinds
+    assert H.max_abs_diff(img, ref) <= TOL
+    plain, _, _, _ = _run_case(renderer, cfg, ((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)), 320, 208)
+    assert H.max_abs_diff(img, plain) > 0.05           # the mode really recolours
+
+
+def test_debug_draw_mode_with_point_cloud_and_depth(renderer):
+    """point-cloud covariance scales with 2^lod when a debug mode is on (gswt.wgsl:182-192); float colours with a depth buffer."""
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    img, ref, kinds, st = _run_case(renderer, cfg, ((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)), 256, 160, bg=True,
+                                    render_config=dict(draw_mode=3, point_cloud_radius=0.002))
+    assert H.max_abs_diff(img, ref) <= TOL

@@ -344,3 +344,20 @@ def test_k15_near_far_clip():
     img, _ = orc.render(cu, su, tex, _draw1(valid_lod_id=0), 32, 32)
     assert img.max() == 0.0
     assert vis(-1.0) == 0       # behind the camera
+
+
+def test_k16_canonical_sincos_matches_libm():
+    """The canonical sin / cos both sides evaluate is a real sin / cos: within 2e-7 of libm on the ranges the sphere
+    mapping and the debug hash use."""
+    import ctypes as C
+    lib = orc.lib()
+    lib.orc_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.orc_sincosf.restype = None
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(-8, 8, 2000), rng.uniform(-6000, 6000, 2000), [0.0, np.pi / 2, -np.pi, 1e-8]]).astype(np.float32)
+    worst = 0.0
+    for x in xs:
+        s, c = C.c_float(), C.c_float()
+        lib.orc_sincosf(float(x), C.byref(s), C.byref(c))
+        worst = max(worst, abs(s.value - np.sin(np.float64(x))), abs(c.value - np.cos(np.float64(x))))
+    assert worst < 2e-7, worst

@@ -56,3 +56,52 @@ def test_vertex_stage_bit_exact(renderer):
         a = got[fld][vis].view(np.uint32)
         b = want[fld][vis].view(np.uint32)
         assert np.array_equal(a, b), fld
+
+
+def _sphere_case(pp, half=(5, 2), tile_width=4.0, merged_cells=((2, 1), (3, 1))):
+    """Every cell of a 10 x 4 sphere map (icosahedral strip, 5 x 2 blocks) as a plain draw, except
+    `merged_cells`, which form one merged (single_draw) draw with per-splat map ids."""
+    case = H.Case(pp)
+    w, h = 2 * half[0], 2 * half[1]
+    for mx in range(w):
+        for my in range(h):
+            if (mx, my) in merged_cells:
+                continue
+            tile = (mx * 5 + my * 3) % pp.n_tile
+            case.add_static(lod=0, tile=tile, view=8, offset=((mx - half[0]) * tile_width, (my - half[1]) * tile_width, 0.0),
+                            valid_lod_id=0, map_index=mx * h + my, map_coord=(mx, my))
+    members = [(mx * h + my, 0, (mx * 5 + my * 3) % pp.n_tile, None) for mx, my in merged_cells]
+    case.add_merged(members=members, view=8, head_lod=0, head_tile=members[0][2], head_map_index=members[0][0])
+    return case
+
+
+@pytest.mark.parametrize("draw_mode", [0, 1])
+def test_sphere_surface_vertex_stage_and_image(renderer, draw_mode):
+    """surface_type 2 (gswt.wgsl:600-623): sphere_get_uv / sphere_uv_to_pos through the canonical sin / cos,
+    plain and merged (map-id) draws; per-splat outputs bit-exact, image within 1e-4."""
+    pp = H.tileset()
+    W, Hh = 320, 240
+    R = 6.5
+    su = orc.scene_uniforms(num_lod=pp.n_lod, map_half_wh=(5, 2), surface_type=2, sphere_radius=R, draw_mode=draw_mode)
+    case = _sphere_case(pp)
+    for pos, tgt in (((3.0, -19.0, 6.0), (0.0, 0.0, 0.0)), ((-14.0, 9.0, -8.0), (0.0, 0.0, 1.0))):
+        cam = orc.Camera(W, Hh, pos, tgt, [0, 0, 1]).uniforms()
+        renderer.set_option(L.GSWT_OPT_NO_LOD_PREFILTER, 1)
+        renderer.set_option(L.GSWT_OPT_DEBUG_VARYINGS, 1)
+        try:
+            case.upload(renderer)
+            img = renderer.render(cam, su, W, Hh)
+            got = renderer.read_projected()
+        finally:
+            renderer.set_option(L.GSWT_OPT_NO_LOD_PREFILTER, 0)
+            renderer.set_option(L.GSWT_OPT_DEBUG_VARYINGS, 0)
+        want = orc.project_draws(cam, su, pp.tex, case.orc_draws)
+        assert np.array_equal(got["visible"], want["visible"])
+        vis = want["visible"] == 1
+        assert vis.sum() > 2000
+        for fld in ("ndc", "depth", "major", "minor", "rgba"):
+            assert np.array_equal(got[fld][vis].view(np.uint32), want[fld][vis].view(np.uint32)), fld
+        ref, st = orc.render(cam, su, pp.tex, case.orc_draws, W, Hh)
+        assert renderer.timings()["n_visible"] == st["n_visible"]
+        assert H.max_abs_diff(img, ref) <= TOL
+        assert ref[..., 3].max() > 0.5
