@@ -649,10 +649,29 @@ int preprocess(gswt_wang& w)
     return GSWT_OK;
 }
 
-// ---- topology, wangtile.rs:257-338 (plane / height map) -----------------------------------
+// ---- topology, wangtile.rs:257-338 -------------------------------------------------------
+// slots 0 = W, 1 = N, 2 = E, 3 = S; each entry = (neighbour map coord, the slot THIS tile occupies for it).
+// Sphere: the map is an unfolded icosahedron strip of 5 x 2 square blocks (block_w = map_w / 5 = map_h / 2);
+// block edges wrap onto other blocks, some with a quarter turn (slot numbers change).
 void compute_map_neighbors(const gswt_wang& w, int x, int y, Neighbor out[4])
 {
     for (int k = 0; k < 4; k++) out[k] = Neighbor{};
+    if (w.user.surface_type == SURFACE_SPHERE) {
+        const int map_w = w.map_w, map_h = w.map_h, block_w = map_w / 5;
+        const int bidx = 5 * x / map_w, bidy = 2 * y / map_h;
+        const int bx = x - bidx * block_w, by = y - bidy * block_w;
+        if (bx > 0) out[0] = {true, x - 1, y, 2};
+        else if (bidy == 0) out[0] = {true, (map_w + x - 1) % map_w, y + block_w, 2};
+        else out[0] = {true, (map_w + x - by - 1) % map_w, map_h - 1, 1};
+        if (bx < block_w - 1) out[2] = {true, x + 1, y, 0};
+        else if (bidy == 0) out[2] = {true, (x + block_w - by) % map_w, 0, 3};
+        else out[2] = {true, (x + 1) % map_w, y - block_w, 0};
+        if (y > 0) out[3] = {true, x, y - 1, 1};
+        else out[3] = {true, (map_w + bidx * block_w - 1) % map_w, block_w - 1 - bx, 2};
+        if (y < map_h - 1) out[1] = {true, x, y + 1, 3};
+        else out[1] = {true, (bidx * block_w + block_w) % map_w, 2 * block_w - 1 - bx, 0};
+        return;
+    }
     if (x > 0) out[0] = {true, x - 1, y, 2};                 // west
     if (x < w.map_w - 1) out[2] = {true, x + 1, y, 0};       // east
     if (y > 0) out[3] = {true, x, y - 1, 1};                 // south
@@ -718,14 +737,92 @@ void map_fetch_bilinear_aux(const gswt_wang& w, float u, float v, float dt, floa
     res[4] = bil(tx, ty - dy);
 }
 
-// ---- WangTile::surface_mapping, wangtile.rs:1352-1494 (None / HeightMap) -------------------
-void surface_mapping(const gswt_wang& w, V3 pos, bool to_world, V3& new_pos, M3& transform)
+// Canonical sin / cos: Rust's f32::sin / cos are platform libm calls, so their last bits are
+// unpinnable; the host uses the one sequence the device kernels use (k = rint(x 2/pi), three-term Cody-Waite with
+// fmaf, Cephes minimax polynomials), so tile centres / corners agree with the GPU's sphere mapping.
+void csincosf(float x, float& sn, float& cs)
+{
+    const float kf = std::rint(x * 0.636619772367581343f);
+    float r = std::fmaf(kf, -1.5703125f, x);
+    r = std::fmaf(kf, -4.837512969970703125e-4f, r);
+    r = std::fmaf(kf, -7.54978995489188216e-8f, r);
+    const float z = r * r;
+    float ps = std::fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    ps = std::fmaf(ps, z, -1.6666654611e-1f);
+    const float s = std::fmaf(ps * z, r, r);
+    float pc = std::fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    pc = std::fmaf(pc, z, 4.166664568298827e-2f);
+    const float c = std::fmaf(pc * z, z, std::fmaf(-0.5f, z, 1.0f));
+    const int q = (int)kf & 3;
+    float so = (q & 1) ? c : s, co = (q & 1) ? s : c;
+    if (q == 2 || q == 3) so = -so;
+    if (q == 1 || q == 2) co = -co;
+    sn = so; cs = co;
+}
+
+// get_uv + uv_to_pos closures of surface_mapping, wangtile.rs:1410-1461
+V3 sphere_point(float block_w, float bidx, float bidy, float bx, float by)
+{
+    const float PI = 3.14159265358979323846f;
+    float u, v;
+    if (bidy == 0.0f) {
+        if (by < bx) {
+            if (bx - by == block_w) u = 0.0f;
+            else u = (by / (block_w - (bx - by)) + bidx) / 5.0f;
+            v = ((block_w - (bx - by)) / block_w) / 3.0f;
+        } else {
+            u = (bx / block_w + bidx) / 5.0f + ((by - bx) / block_w) * 0.1f;
+            v = ((by - bx) / block_w) / 3.0f + (1.0f / 3.0f);
+        }
+    } else {
+        if (by < bx) {
+            u = (bx / block_w + bidx) / 5.0f + ((block_w - (bx - by)) / block_w) * 0.1f;
+            v = ((block_w - (bx - by)) / block_w) / 3.0f + (1.0f / 3.0f);
+        } else {
+            if (by - bx == block_w) u = 0.0f;
+            else u = (bx / (block_w - (by - bx)) + bidx) / 5.0f + 0.1f;
+            v = ((by - bx) / block_w) / 3.0f + (2.0f / 3.0f);
+        }
+    }
+    u = u + 0.5f * std::floor(v);
+    u = u * (2.0f * PI);
+    v = (v - 0.5f) * PI;
+    float su, cu, sv, cv;
+    csincosf(u, su, cu);
+    csincosf(v, sv, cv);
+    return V3{cv * cu, cv * su, sv};
+}
+
+// ---- WangTile::surface_mapping, wangtile.rs:1352-1494 --------------------------------------
+void surface_mapping(const gswt_wang& w, int mcx, int mcy, V3 pos, bool to_world, V3& new_pos, M3& transform)
 {
     new_pos = pos;
     transform = M3{};
-    if (w.user.surface_type != SURFACE_HEIGHTMAP) return;
     const float DELTA = 0.001f;
     const float tw = w.user.tile_width;
+    if (w.user.surface_type == SURFACE_SPHERE) {
+        const float xmax = (float)w.map_w * tw, ymax = (float)w.map_h * tw;
+        const float block_w = xmax / 5.0f;
+        int c0x, c0y;
+        w.map_to_coord(0, 0, c0x, c0y);
+        new_pos = new_pos - w.coord_to_pos(c0x, c0y);
+        const float bidx = (float)(5 * mcx / w.map_w), bidy = (float)(2 * mcy / w.map_h);
+        const float bx = new_pos.x - bidx * block_w, by = new_pos.y - bidy * block_w;
+        const V3 lz = sphere_point(block_w, bidx, bidy, bx, by);
+        const float r = w.user.sphere_radius;
+        new_pos = lz * r;
+        const float dt = DELTA * ymax;
+        const V3 pr = sphere_point(block_w, bidx, bidy, bx + dt, by) * r;
+        const V3 pl = sphere_point(block_w, bidx, bidy, bx - dt, by) * r;
+        const V3 pu = sphere_point(block_w, bidx, bidy, bx, by + dt) * r;
+        const V3 pd = sphere_point(block_w, bidx, bidy, bx, by - dt) * r;
+        const V3 lx = (pr - pl) / (2.0f * dt), ly = (pu - pd) / (2.0f * dt);
+        M3 l2w = from_cols(lx, ly, lz);
+        new_pos = new_pos + l2w * V3{0.0f, 0.0f, pos.z};
+        transform = to_world ? l2w : invert(l2w);
+        return;
+    }
+    if (w.user.surface_type != SURFACE_HEIGHTMAP) return;
     float xr = ((float)w.map_w * tw) * w.user.height_map_scale[0];
     float yr = ((float)w.map_h * tw) * w.user.height_map_scale[1];
     float u = (pos.x + (float)w.user.tile_map_half_wh[0] * tw) / xr;
@@ -766,7 +863,7 @@ bool compute_corner_edge(const gswt_wang& w, int x, int y, float tile_center_z, 
             int cx, cy;
             w.map_to_coord(x + dco[ci][0], y + dco[ci][1], cx, cy);
             V3 cpos = w.coord_to_pos(cx, cy) + V3{0, 0, 1} * tile_center_z;
-            surface_mapping(w, cpos, true, corner[ci].pos, corner[ci].to_world);
+            surface_mapping(w, x, y, cpos, true, corner[ci].pos, corner[ci].to_world);
         }
     }
     for (int ei = 0; ei < 4; ei++) {
@@ -807,7 +904,7 @@ void lod_select_spatial(const gswt_wang& w, int x, int y, V3 cam, size_t& lod_ou
         float mn = -1.0f, mx = -1.0f;
         for (int k = 0; k < npts; k++) {
             V3 q; M3 tr;
-            surface_mapping(w, pts[k] + pos_offset, true, q, tr);
+            surface_mapping(w, x, y, pts[k] + pos_offset, true, q, tr);
             float d = distance(q, cam);
             if (mn < 0.0f || d < mn) mn = d;
             if (mx < 0.0f || d > mx) mx = d;
@@ -853,6 +950,8 @@ void tile_id_to_color(size_t tid, int c[4])
 void update_tile_map(gswt_wang& w, V3 cam)
 {
     w.camera_pos = cam;
+    if (w.user.surface_type == SURFACE_SPHERE) { w.center_x = 0; w.center_y = 0; }      // the sphere map never shifts, :1721-1723
+    else {
     int prev_cx = w.center_x, prev_cy = w.center_y;
     w.center_x = (int)std::floor(cam.x / w.user.tile_width);
     w.center_y = (int)std::floor(cam.y / w.user.tile_width);
@@ -874,6 +973,7 @@ void update_tile_map(gswt_wang& w, V3 cam)
             }
         }
     w.tile_map = std::move(new_map);
+    }
     for (int i = 0; i < w.map_w; i++)
         for (int j = 0; j < w.map_h; j++) {
             if (w.at(i, j)) continue;
@@ -897,7 +997,7 @@ void update_tile_map(gswt_wang& w, V3 cam)
             ti->map_index = w.map_to_index(i, j);
             ti->mx = i; ti->my = j;
             V3 base_center = w.tile_center[tile_id];
-            surface_mapping(w, base_center + tile_offset, false, ti->tile_center, ti->to_local);
+            surface_mapping(w, i, j, base_center + tile_offset, false, ti->tile_center, ti->to_local);
             ti->has_corner = compute_corner_edge(w, i, j, base_center.z, ti->corner, ti->edge);
             w.tile_map[(size_t)i * w.map_h + j] = std::move(ti);
         }
@@ -1016,6 +1116,19 @@ void selective_merge_axis(gswt_wang& w, V3 cam, const float* vp)
 {
     int cmx = w.center_x - w.center_x + (int)w.user.tile_map_half_wh[0];   // coord_to_map(center_coord)
     int cmy = w.center_y - w.center_y + (int)w.user.tile_map_half_wh[1];
+    if (w.user.surface_type == SURFACE_SPHERE) {                            // nearest not-MergedTo tile, :725-740
+        float min_dist = -1.0f;
+        cmx = cmy = 0;
+        for (size_t idx = 0; idx < (size_t)w.map_w * w.map_h; idx++) {
+            int x, y;
+            w.index_to_map(idx, x, y);
+            const TileInstance* t = w.at(x, y);
+            if (t->merge == MS_TO) continue;
+            const V3 dv = cam - t->tile_center;
+            const float d2 = dot(dv, dv);
+            if (min_dist < 0.0f || d2 < min_dist) { min_dist = d2; cmx = x; cmy = y; }
+        }
+    }
     float best = 0.0f;
     int merge_dir = -1;
     V3 cam_dir = normalize(V3{vp[2], vp[6], vp[10]});
@@ -1223,7 +1336,8 @@ std::string cache_key(size_t view_id, const std::vector<std::pair<size_t, size_t
 
 int check_user(const gswt_user_data& u)
 {
-    if (u.surface_type == SURFACE_SPHERE) return fail(GSWT_ERR_BAD_ARG, "WangTile::configure: Sphere surface is not built yet (SURVEY 8f rank 4)");
+    if (u.surface_type == SURFACE_SPHERE && (u.tile_map_half_wh[0] == 0 || u.tile_map_half_wh[0] * 2 * 2 != u.tile_map_half_wh[1] * 2 * 5))
+        return fail(GSWT_ERR_BAD_ARG, "WangTile::configure: assertion failed: tile_map_wh.x * 2 == tile_map_wh.y * 5 (Sphere maps are 5 : 2)");
     if (u.surface_type > 2 || u.tile_sort_type > 3 || u.merge_type > 2 || u.height_map_type > 4) return fail(GSWT_ERR_BAD_ARG, "WangTile::configure: enum out of range");
     if (!(u.tile_width > 0.0f)) return fail(GSWT_ERR_BAD_ARG, "WangTile::configure: tile_width must be positive");
     if (u.center_option == 0) return fail(GSWT_ERR_BAD_ARG, "WangTile::configure: center_option must be >= 1");
@@ -1460,8 +1574,9 @@ int gswt_wang_configure(gswt_wang* w, const gswt_user_data* user, gswt_configure
         w->user.height_tex = w->height_tex_copy.data();
     } else { w->height_tex_copy.clear(); w->user.height_tex = nullptr; }
     if (w->user.reset_rng) w->rng.reseed(0);
-    w->map_w = (int)w->user.tile_map_half_wh[0] * 2 + 1;
-    w->map_h = (int)w->user.tile_map_half_wh[1] * 2 + 1;
+    const int odd = w->user.surface_type == SURFACE_SPHERE ? 0 : 1;          // wangtile.rs:356-361
+    w->map_w = (int)w->user.tile_map_half_wh[0] * 2 + odd;
+    w->map_h = (int)w->user.tile_map_half_wh[1] * 2 + odd;
     w->tile_map.clear();
     w->tile_map.resize((size_t)w->map_w * w->map_h);
     w->neighbor_map.assign((size_t)w->map_w * w->map_h * 4, Neighbor{});
@@ -1594,7 +1709,7 @@ int gswt_wang_set_tile_ids(gswt_wang* w, const uint32_t* ids, size_t n)
             TileInstance* ti = w->at(i, j);
             ti->tile = ids[w->map_to_index(i, j)];
             V3 base_center = w->tile_center[ti->tile];
-            surface_mapping(*w, base_center + ti->tile_offset, false, ti->tile_center, ti->to_local);
+            surface_mapping(*w, i, j, base_center + ti->tile_offset, false, ti->tile_center, ti->to_local);
             ti->has_corner = compute_corner_edge(*w, i, j, base_center.z, ti->corner, ti->edge);
         }
     update_lod(*w, w->camera_pos);

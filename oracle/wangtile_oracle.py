@@ -391,8 +391,31 @@ class WangTile:
         w, h = self.user.tile_map_wh
         x, y = mc
         nb = [None, None, None, None]
-        if self.user.surface_type == SURFACE_SPHERE:
-            raise NotImplementedError("sphere topology: SURVEY 8f rank 4")
+        if self.user.surface_type == SURFACE_SPHERE:                     # :260-319, 5 x 2 icosahedral-strip blocks
+            block_w = w // 5
+            bidx, bidy = 5 * x // w, 2 * y // h
+            bx, by = x - bidx * block_w, y - bidy * block_w
+            if bx > 0:
+                nb[0] = ((x - 1, y), 2)
+            elif bidy == 0:
+                nb[0] = (((w + x - 1) % w, y + block_w), 2)
+            else:
+                nb[0] = (((w + x - by - 1) % w, h - 1), 1)
+            if bx < block_w - 1:
+                nb[2] = ((x + 1, y), 0)
+            elif bidy == 0:
+                nb[2] = (((x + block_w - by) % w, 0), 3)
+            else:
+                nb[2] = (((x + 1) % w, y - block_w), 0)
+            if y > 0:
+                nb[3] = ((x, y - 1), 1)
+            else:
+                nb[3] = (((w + bidx * block_w - 1) % w, block_w - 1 - bx), 2)
+            if y < h - 1:
+                nb[1] = ((x, y + 1), 3)
+            else:
+                nb[1] = (((bidx * block_w + block_w) % w, 2 * block_w - 1 - bx), 0)
+            return nb
         if x > 0:
             nb[0] = ((x - 1, y), 2)
         if x < w - 1:
@@ -518,7 +541,7 @@ class WangTile:
         if u.surface_type == SURFACE_NONE:
             return pos.copy(), mat3_identity()
         if u.surface_type == SURFACE_SPHERE:
-            raise NotImplementedError("sphere surface: SURVEY 8f rank 4")
+            return self._surface_mapping_sphere(map_coord, pos, to_world)
         DELTA = f32(0.001)
         tw = f32(u.tile_width)
         xr = f32(f32(f32(u.tile_map_wh[0]) * tw) * f32(u.height_map_scale[0]))
@@ -533,6 +556,76 @@ class WangTile:
         lx = v3(1.0, 0.0, f32(f32(h_r - h_l) / f32(f32(f32(2.0) * DELTA) * xr)))
         ly = v3(0.0, 1.0, f32(f32(h_u - h_d) / f32(f32(f32(2.0) * DELTA) * yr)))
         lz = normalize3(cross3(lx, ly))
+        l2w = mat3_cols(lx, ly, lz)
+        new_pos = (new_pos + mat3_vec(l2w, v3(0.0, 0.0, pos[2]))).astype(f32)
+        return new_pos, (l2w if to_world else mat3_invert(l2w))
+
+    @staticmethod
+    def _sincos(x):
+        """The canonical sin / cos of DESIGN.md section 4 (Rust's f32::sin / cos are platform libm calls whose
+        last bits are unpinnable); evaluated by the C oracle so that every side shares one implementation."""
+        import ctypes as C
+        lib = orc.lib()
+        lib.orc_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.orc_sincosf.restype = None
+        sn, cs = C.c_float(), C.c_float()
+        lib.orc_sincosf(C.c_float(float(x)), C.byref(sn), C.byref(cs))
+        return f32(sn.value), f32(cs.value)
+
+    def _sphere_point(self, block_w, bidx, bidy, bx, by):
+        """get_uv + uv_to_pos closures, wangtile.rs:1410-1461"""
+        PI = f32(math.pi)
+        five, three = f32(5.0), f32(3.0)
+        if bidy == 0.0:
+            if by < bx:
+                if f32(bx - by) == block_w:
+                    u = f32(0.0)
+                else:
+                    u = f32(f32(f32(by / f32(block_w - f32(bx - by))) + bidx) / five)
+                v = f32(f32(f32(block_w - f32(bx - by)) / block_w) / three)
+            else:
+                u = f32(f32(f32(f32(bx / block_w) + bidx) / five) + f32(f32(f32(by - bx) / block_w) * f32(0.1)))
+                v = f32(f32(f32(f32(by - bx) / block_w) / three) + f32(f32(1.0) / three))
+        else:
+            if by < bx:
+                u = f32(f32(f32(f32(bx / block_w) + bidx) / five) + f32(f32(f32(block_w - f32(bx - by)) / block_w) * f32(0.1)))
+                v = f32(f32(f32(f32(block_w - f32(bx - by)) / block_w) / three) + f32(f32(1.0) / three))
+            else:
+                if f32(by - bx) == block_w:
+                    u = f32(0.0)
+                else:
+                    u = f32(f32(f32(f32(bx / f32(block_w - f32(by - bx))) + bidx) / five) + f32(0.1))
+                v = f32(f32(f32(f32(by - bx) / block_w) / three) + f32(f32(2.0) / three))
+        u = f32(u + f32(f32(0.5) * f32(np.floor(v))))
+        u = f32(u * f32(f32(2.0) * PI))
+        v = f32(f32(v - f32(0.5)) * PI)
+        su, cu = self._sincos(u)
+        sv, cv = self._sincos(v)
+        return v3(f32(cv * cu), f32(cv * su), sv)
+
+    def _surface_mapping_sphere(self, map_coord, pos, to_world):
+        """wangtile.rs:1406-1488"""
+        u = self.user
+        DELTA = f32(0.001)
+        tw = f32(u.tile_width)
+        xmax, ymax = f32(f32(u.tile_map_wh[0]) * tw), f32(f32(u.tile_map_wh[1]) * tw)
+        block_w = f32(xmax / f32(5.0))
+        new_pos = (pos - self.coord_to_pos(self.map_to_coord((0, 0)))).astype(f32)
+        bidx = f32(5 * map_coord[0] // u.tile_map_wh[0])
+        bidy = f32(2 * map_coord[1] // u.tile_map_wh[1])
+        bx = f32(new_pos[0] - f32(bidx * block_w))
+        by = f32(new_pos[1] - f32(bidy * block_w))
+        lz = self._sphere_point(block_w, bidx, bidy, bx, by)
+        r = f32(u.sphere_radius)
+        new_pos = (lz * r).astype(f32)
+        dt = f32(DELTA * ymax)
+        pr = (self._sphere_point(block_w, bidx, bidy, f32(bx + dt), by) * r).astype(f32)
+        pl = (self._sphere_point(block_w, bidx, bidy, f32(bx - dt), by) * r).astype(f32)
+        pu = (self._sphere_point(block_w, bidx, bidy, bx, f32(by + dt)) * r).astype(f32)
+        pd = (self._sphere_point(block_w, bidx, bidy, bx, f32(by - dt)) * r).astype(f32)
+        two_dt = f32(f32(2.0) * dt)
+        lx = ((pr - pl).astype(f32) / two_dt).astype(f32)
+        ly = ((pu - pd).astype(f32) / two_dt).astype(f32)
         l2w = mat3_cols(lx, ly, lz)
         new_pos = (new_pos + mat3_vec(l2w, v3(0.0, 0.0, pos[2]))).astype(f32)
         return new_pos, (l2w if to_world else mat3_invert(l2w))
@@ -616,9 +709,12 @@ class WangTile:
         xmax, ymax = u.tile_map_wh
         self.camera_pos = np.asarray(camera_pos, dtype=f32)
         prev_center = self.center_coord
-        self.center_coord = self.pos_to_coord(self.camera_pos)
+        if u.surface_type == SURFACE_SPHERE:                              # the sphere map never shifts, :1721-1723
+            self.center_coord = (0, 0)
+        else:
+            self.center_coord = self.pos_to_coord(self.camera_pos)
         new_map = [[None] * ymax for _ in range(xmax)]
-        for i in range(xmax):
+        for i in range(xmax if u.surface_type != SURFACE_SPHERE else 0):
             for j in range(ymax):
                 px = i + self.center_coord[0] - prev_center[0]
                 py = j + self.center_coord[1] - prev_center[1]
@@ -629,7 +725,8 @@ class WangTile:
                                                      (i, j), prev.tile_center, ("none",), ("none",), prev.to_local,
                                                      None if prev.corner_data is None else [(p.copy(), m.copy()) for p, m in prev.corner_data],
                                                      None if prev.edge_data is None else [(p.copy(), n.copy()) for p, n in prev.edge_data])
-        self.tile_map = new_map
+        if u.surface_type != SURFACE_SPHERE:
+            self.tile_map = new_map
         for i in range(xmax):
             for j in range(ymax):
                 if self.tile_map[i][j] is not None:
@@ -867,6 +964,16 @@ class WangTile:
         """wangtile.rs:722-825 (plane / height map)"""
         u = self.user
         center_mc = self.coord_to_map(self.center_coord)
+        if u.surface_type == SURFACE_SPHERE:                               # nearest not-MergedTo tile, :725-740
+            min_dist, center_mc = f32(-1.0), (0, 0)
+            for idx in range(u.tile_map_wh[0] * u.tile_map_wh[1]):
+                mc = self.index_to_map(idx)
+                ti = self.tile_map[mc[0]][mc[1]]
+                if ti.merge_status[0] == "to":
+                    continue
+                d = dist2_3(ti.tile_center, np.asarray(camera_pos, dtype=f32))
+                if min_dist < 0.0 or d < min_dist:
+                    min_dist, center_mc = d, mc
         nbs = self.neighbor_map[center_mc[0]][center_mc[1]]
         best, merge_dir = f32(0.0), -1
         cam_dir = normalize3(v3(view_proj[2], view_proj[6], view_proj[10]))

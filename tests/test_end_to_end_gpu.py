@@ -229,3 +229,14 @@ def test_debug_draw_mode_with_point_cloud_and_depth(renderer):
     img, ref, kinds, st = _run_case(renderer, cfg, ((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)), 256, 160, bg=True,
                                     render_config=dict(draw_mode=3, point_cloud_radius=0.002))
     assert H.max_abs_diff(img, ref) <= TOL
+
+
+@pytest.mark.parametrize("cam", [((3.0, -19.0, 6.0), (0.0, 0.0, 0.0)), ((-14.0, 9.0, -8.0), (0.0, 0.0, 1.0))])
+def test_sphere_surface_end_to_end(renderer, cam):
+    """Sphere surface through the whole path: sphere topology + CPU mapping in the worker (tile centres, corners, LOD
+    rings, Edge merging across block seams), sphere mapping per splat on the device."""
+    cfg = dict(tile_map_half_wh=(5, 2), surface_type=2, sphere_radius=6.5, lod_max_dist=60.0, tile_sort_type=3, merge_type=2)
+    img, ref, kinds, st = _run_case(renderer, cfg, cam, 320, 240, lod0=700)
+    assert kinds["plain"] > 0 and kinds["blend"] + kinds["merged"] > 0, kinds
+    assert st["n_visible"] > 3000
+    assert H.max_abs_diff(img, ref) <= TOL

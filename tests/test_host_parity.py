@@ -122,8 +122,45 @@ CAMS = [((0, 0, 5), (0, 1, 5)), ((0.5, 0.3, 5), (1, 1, 4.5)), ((4.2, 1.0, 3), (5
         ((-7.9, -4.1, 2), (-9, -9, 1.5))]
 
 
+SPHERE_CONFIGS = [
+    dict(tile_map_half_wh=(5, 2), surface_type=2, sphere_radius=6.5, lod_max_dist=5.0, tile_sort_type=3, merge_type=2),
+    dict(tile_map_half_wh=(5, 2), surface_type=2, sphere_radius=5.0, lod_max_dist=4.0, tile_sort_type=3, merge_type=1, merge_tile_dist=(0, 2)),
+    dict(tile_map_half_wh=(10, 4), surface_type=2, sphere_radius=13.0, lod_max_dist=6.0, tile_sort_type=2, merge_type=2,
+         lod_bbox_check=False),
+]
+SPHERE_CAMS = [((3.0, -19.0, 6.0), (0, 0, 0)), ((3.5, -18.0, 6.0), (0, 0, 0.5)), ((-14.0, 9.0, -8.0), (0, 0, 1)), ((0.5, 0.5, 21.0), (0, 0.1, 0))]
+
+
+@pytest.mark.parametrize("cfg", SPHERE_CONFIGS)
+def test_wangtile_worker_sphere_bit_exact(tiles, cfg):
+    """Sphere topology (5 x 2 icosahedral-strip blocks, wrapped neighbour slots), the CPU sphere mapping through the
+    canonical sin / cos, the static map (never shifts) and the nearest-tile merge centre."""
+    _check_worker(tiles, cfg, SPHERE_CAMS)
+
+
+def test_sphere_neighbours_are_mutual(tiles):
+    """Every neighbour link of the sphere topology points back: nb(a, slot) = (b, s) implies nb(b, s) = (a, slot)
+    (this is what makes Wang edge colours well defined across block seams)."""
+    verts, _, pp = tiles
+    ow = wo.WangTile(pp)
+    ow.configure(wo.UserData(tile_map_half_wh=(10, 4), surface_type=2, sphere_radius=13.0, lod_max_dist=6.0))
+    w, h = ow.user.tile_map_wh
+    assert (w, h) == (20, 8)
+    for x in range(w):
+        for y in range(h):
+            for slot, nb in enumerate(ow.neighbor_map[x][y]):
+                assert nb is not None
+                (bx, by), s = nb
+                back = ow.neighbor_map[bx][by][s]
+                assert back is not None and back[0] == (x, y) and back[1] == slot, (x, y, slot, nb, back)
+
+
 @pytest.mark.parametrize("cfg", CONFIGS)
 def test_wangtile_worker_bit_exact(tiles, cfg):
+    _check_worker(tiles, cfg, CAMS)
+
+
+def _check_worker(tiles, cfg, cams):
     verts, _, pp = tiles
     w = host.WangTile(host.TileSet.from_vertices(verts))
     conf = w.configure(host.user_data(**cfg))
@@ -134,7 +171,7 @@ def test_wangtile_worker_bit_exact(tiles, cfg):
     if cfg["surface_type"] == 1:
         assert np.array_equal(w.height_map().ravel(), ou.height_map)
     with np.errstate(all="ignore"):
-        for pos, tgt in CAMS:
+        for pos, tgt in cams:
             cu, vp = host.camera_uniforms(pos, tgt, (0, 0, 1), 45.0, 0.1, 2400.0, 320, 240)
             upd = w.check_update(pos)
             assert upd == bool(ow.check_update(pos))
