@@ -89,6 +89,15 @@ assert C.sizeof(CameraUniforms) == 176 and C.sizeof(SceneUniforms) == 160 and C.
 
 # every symbol include/gswt_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+class ProxyUniforms(C.Structure):
+    """proxy.wgsl Uniforms / proxy.rs:470-511 (224 B)."""
+    _fields_ = [("height_offset", C.c_float), ("tile_width", C.c_float), ("surface_type", C.c_uint32), ("width_scale", C.c_float),
+                ("map_proxy", C.c_uint32), ("use_clip", C.c_uint32), ("clip_height", C.c_float), ("brightness", C.c_float),
+                ("black_background", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("view", C.c_float * 16), ("projection", C.c_float * 16),
+                ("map_half_wh", C.c_uint32 * 2), ("center_coord", C.c_int32 * 2), ("height_map_scale", C.c_float * 4),
+                ("cam_pos", C.c_float * 4)]
+
+
 SYMBOLS = {
     "gswt_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "gswt_destroy": (None, [_P]),
@@ -105,6 +114,10 @@ SYMBOLS = {
     "gswt_render_async": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
     "gswt_render_wait": (C.c_int, [_P, C.c_int]),
     "gswt_render_fence": (C.c_int, [_P, C.c_int]),
+    "gswt_skybox_configure": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "gswt_skybox_render": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "gswt_proxy_configure": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
+    "gswt_proxy_render": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "gswt_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "gswt_shard_rows_padded": (C.c_int, [C.c_int, C.c_int]),
     "gswt_unshard": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),

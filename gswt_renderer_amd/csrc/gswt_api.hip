@@ -40,6 +40,9 @@ void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long l
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint2*, float4*, hipEvent_t, hipEvent_t);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
+void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
+void launch_proxy(hipStream_t, const ProxyArgs&, const float*, const float4*, float4*, float*);
+void launch_fill_f32(hipStream_t, float*, size_t, float);
 }  // namespace gswt
 
 using namespace gswt;
@@ -128,6 +131,12 @@ struct gswt_ctx {
     bool scene_ready = false;
     DevBuf<float> hmap;
     int hm_w = 0, hm_h = 0;
+    // background passes
+    DevBuf<float4> sky_faces;
+    int sky_size = 0, sky_equi = 0;
+    DevBuf<float4> proxy_tex;
+    int proxy_size = 0, proxy_mips = 0, proxy_grid_dim = 2048;
+    uint32_t proxy_mip_off[16] = {};
     // draws
     DevBuf<DrawDev> draws;
     DevBuf<uint2> chunk_tab;
@@ -233,7 +242,7 @@ void gswt_destroy(gswt_ctx* c)
     sync_all(c);
     c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release();
     c->merged_list.release(); c->merged_map.release(); c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release();
-    c->mg_ws.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
+    c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
     for (auto& sl : c->slots) {
         sl.release_buffers();
         for (auto& e : sl.ev) if (e) hipEventDestroy(e);
@@ -838,6 +847,95 @@ int gswt_render_fence(gswt_ctx* c, int ticket)
     if (!sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render_fence: ticket %d is not in flight", ticket);
     hipSetDevice(c->device);
     HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.ev[9], 0));
+    return GSWT_OK;
+}
+
+int gswt_skybox_configure(gswt_ctx* c, const float* faces_rgba, int face_size, int equirectangular)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    if (!faces_rgba || face_size <= 0 || face_size > 16384) return fail(c, GSWT_ERR_BAD_ARG, "gswt_skybox_configure: bad cube map");
+    hipSetDevice(c->device);
+    HIP_TRY(c, sync_all(c));
+    const size_t n = (size_t)6 * face_size * face_size;
+    HIP_TRY(c, c->sky_faces.ensure(n));
+    HIP_TRY(c, hipMemcpy(c->sky_faces.p, faces_rgba, n * 16, hipMemcpyHostToDevice));
+    c->sky_size = face_size; c->sky_equi = equirectangular ? 1 : 0;
+    return GSWT_OK;
+}
+
+int gswt_skybox_render(gswt_ctx* c, const gswt_camera_uniforms* cam, int width, int height, float* out_rgba_dev)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    if (!cam || !out_rgba_dev || width <= 0 || height <= 0) return fail(c, GSWT_ERR_BAD_ARG, "gswt_skybox_render: bad argument");
+    if (c->sky_size == 0) return fail(c, GSWT_ERR_STATE, "gswt_skybox_render before gswt_skybox_configure");
+    if (cam->projection[0] == 0.0f || cam->projection[5] == 0.0f) return fail(c, GSWT_ERR_BAD_ARG, "gswt_skybox_render: singular projection");
+    hipSetDevice(c->device);
+    launch_skybox(c->stream, cam->view, cam->projection[0], cam->projection[5], width, height, c->sky_size, c->sky_equi, c->sky_faces.p,
+                  reinterpret_cast<float4*>(out_rgba_dev));
+    HIP_TRY(c, hipGetLastError());
+    return GSWT_OK;
+}
+
+int gswt_proxy_configure(gswt_ctx* c, const float* const* mips, int tex_size, int n_mips, int grid_dim)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    if (!mips || tex_size <= 0 || n_mips <= 0 || n_mips > 16 || (tex_size >> (n_mips - 1)) < 1 || grid_dim <= 0 || grid_dim > 32768)
+        return fail(c, GSWT_ERR_BAD_ARG, "gswt_proxy_configure: bad mip chain / grid");
+    hipSetDevice(c->device);
+    HIP_TRY(c, sync_all(c));
+    size_t total = 0;
+    for (int l = 0; l < n_mips; l++) {
+        if (!mips[l]) return fail(c, GSWT_ERR_BAD_ARG, "gswt_proxy_configure: mip %d is null", l);
+        c->proxy_mip_off[l] = (uint32_t)total;
+        total += (size_t)(tex_size >> l) * (tex_size >> l);
+    }
+    if (total >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_proxy_configure: texture too large");
+    HIP_TRY(c, c->proxy_tex.ensure(total));
+    for (int l = 0; l < n_mips; l++)
+        HIP_TRY(c, hipMemcpy(c->proxy_tex.p + c->proxy_mip_off[l], mips[l], (size_t)(tex_size >> l) * (tex_size >> l) * 16, hipMemcpyHostToDevice));
+    c->proxy_size = tex_size; c->proxy_mips = n_mips; c->proxy_grid_dim = grid_dim;
+    return GSWT_OK;
+}
+
+int gswt_proxy_render(gswt_ctx* c, const gswt_proxy_uniforms* u, int width, int height, float* rgba_dev, float* depth_dev, int clear_depth)
+{
+    if (!c) return GSWT_ERR_BAD_ARG;
+    if (!u || !rgba_dev || !depth_dev || width <= 0 || height <= 0) return fail(c, GSWT_ERR_BAD_ARG, "gswt_proxy_render: bad argument");
+    if (c->proxy_size == 0 && !u->black_background) return fail(c, GSWT_ERR_STATE, "gswt_proxy_render before gswt_proxy_configure");
+    if (u->surface_type == 1u && (c->hm_w == 0 || c->hm_h == 0)) return fail(c, GSWT_ERR_STATE, "gswt_proxy_render: HeightMap surface without gswt_configure height map");
+    if (!(u->tile_width > 0.0f) || (!u->map_proxy && !(u->width_scale > 0.0f))) return fail(c, GSWT_ERR_BAD_ARG, "gswt_proxy_render: cell size must be positive");
+    if (u->projection[0] == 0.0f || u->projection[5] == 0.0f) return fail(c, GSWT_ERR_BAD_ARG, "gswt_proxy_render: singular projection");
+    hipSetDevice(c->device);
+    ProxyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.height_offset = u->height_offset; a.tile_width = u->tile_width; a.width_scale = u->width_scale; a.clip_height = u->clip_height;
+    a.brightness = u->brightness; a.surface_type = u->surface_type; a.use_clip = u->use_clip; a.black_background = u->black_background;
+    memcpy(a.V, u->view, 64);
+    for (int cc = 0; cc < 4; cc++) {          // opengl_to_wgpu * projection, proxy.wgsl:84-91
+        const float* P = u->projection;
+        a.GP[4 * cc + 0] = P[4 * cc + 0]; a.GP[4 * cc + 1] = P[4 * cc + 1];
+        a.GP[4 * cc + 2] = 0.5f * P[4 * cc + 2] + 0.5f * P[4 * cc + 3]; a.GP[4 * cc + 3] = P[4 * cc + 3];
+    }
+    a.p00 = u->projection[0]; a.p11 = u->projection[5];
+    for (int k = 0; k < 3; k++) { a.cam[k] = u->cam_pos[k]; a.height_map_scale[k] = u->height_map_scale[k]; }
+    a.map_half_wh[0] = u->map_half_wh[0]; a.map_half_wh[1] = u->map_half_wh[1];
+    const float tw = u->tile_width;
+    if (u->map_proxy == 1u) {                 // proxy.rs:219-251 + proxy.wgsl:51
+        a.nx = 2 * (int)u->map_half_wh[0] + 1; a.ny = 2 * (int)u->map_half_wh[1] + 1; a.cs = tw;
+        a.gx0 = (float)(-(int)u->map_half_wh[0]) * tw + (float)u->center_coord[0] * tw;
+        a.gy0 = (float)(-(int)u->map_half_wh[1]) * tw + (float)u->center_coord[1] * tw;
+    } else {                                  // proxy.rs:136-163 + proxy.wgsl:66-68
+        const int g = c->proxy_grid_dim;
+        a.nx = a.ny = g; a.cs = u->width_scale;
+        a.gx0 = (float)(-(g / 2)) * u->width_scale + floorf((float)u->center_coord[0] * tw / u->width_scale) * u->width_scale;
+        a.gy0 = (float)(-(g / 2)) * u->width_scale + floorf((float)u->center_coord[1] * tw / u->width_scale) * u->width_scale;
+    }
+    a.hm_w = c->hm_w; a.hm_h = c->hm_h; a.tex_size = c->proxy_size > 0 ? c->proxy_size : 1; a.n_mips = c->proxy_mips > 0 ? c->proxy_mips : 1;
+    memcpy(a.mip_off, c->proxy_mip_off, sizeof(a.mip_off));
+    a.width = width; a.height = height;
+    if (clear_depth) launch_fill_f32(c->stream, depth_dev, (size_t)width * height, 1.0f);
+    launch_proxy(c->stream, a, c->hmap.p, c->proxy_tex.p, reinterpret_cast<float4*>(rgba_dev), depth_dev);
+    HIP_TRY(c, hipGetLastError());
     return GSWT_OK;
 }
 

@@ -91,4 +91,29 @@ struct Varyings {
     float rgba[4];
 };
 
+// Kernel arguments of the background passes (gswt_passes.hip)
+struct SkyArgs {
+    float V[16];          // view (only its rotation is used: skybox.wgsl:41-47 removes the translation)
+    float p00, p11;       // projection[0][0], projection[1][1] (symmetric perspective, camera.rs:94)
+    int width, height, face_size, equirectangular;
+};
+
+struct ProxyArgs {
+    // proxy.wgsl Uniforms
+    float height_offset, tile_width, width_scale, clip_height, brightness;
+    uint32_t surface_type, use_clip, black_background;
+    float V[16], GP[16];
+    float p00, p11;
+    float cam[3];
+    uint32_t map_half_wh[2];
+    float height_map_scale[3];
+    // grid
+    int nx, ny;
+    float cs, gx0, gy0;
+    // resources
+    int hm_w, hm_h, tex_size, n_mips;
+    uint32_t mip_off[16];          // float4 offsets of the mip levels
+    int width, height;
+};
+
 }  // namespace gswt

@@ -181,6 +181,30 @@ class GSWTRenderer:
         """Device-side: work submitted to the ctx stream afterwards waits for this frame."""
         self._check(self._lib.gswt_render_fence(self._h, ticket))
 
+    # -- background passes (state.rs:384-392) ------------------------------------------
+    def skybox_configure(self, faces: np.ndarray, equirectangular: bool = False):
+        """Skybox::configure (skybox.rs:341): faces [6, n, n, 4] f32, +X -X +Y -Y +Z -Z."""
+        f = np.ascontiguousarray(faces, dtype=np.float32)
+        assert f.ndim == 4 and f.shape[0] == 6 and f.shape[1] == f.shape[2] and f.shape[3] == 4
+        self._check(self._lib.gswt_skybox_configure(self._h, _ptr(f), f.shape[1], 1 if equirectangular else 0))
+
+    def skybox_render(self, camera, width: int, height: int, out_device_ptr: int):
+        """Skybox::render (skybox.rs:457) into a device RGBA f32 buffer."""
+        cam = (C.c_char * 176).from_buffer_copy(bytes(camera))
+        self._check(self._lib.gswt_skybox_render(self._h, cam, width, height, C.c_void_p(out_device_ptr)))
+
+    def proxy_configure(self, mips, grid_dim: int = 2048):
+        """Proxy::configure (proxy.rs:208): mip chain [level][n >> level, n >> level, 4] f32."""
+        ms = [np.ascontiguousarray(m, dtype=np.float32) for m in mips]
+        arr = (C.c_void_p * len(ms))(*[m.ctypes.data for m in ms])
+        self._check(self._lib.gswt_proxy_configure(self._h, arr, ms[0].shape[0], len(ms), grid_dim))
+
+    def proxy_render(self, uniforms, width: int, height: int, rgba_device_ptr: int, depth_device_ptr: int, clear_depth: bool):
+        """One draw of Proxy::render (proxy.rs:366); uniforms: 224-byte proxy.wgsl Uniforms block."""
+        u = (C.c_char * 224).from_buffer_copy(bytes(uniforms))
+        self._check(self._lib.gswt_proxy_render(self._h, u, width, height, C.c_void_p(rgba_device_ptr), C.c_void_p(depth_device_ptr),
+                                                1 if clear_depth else 0))
+
     def shard_rows_padded(self, height: int, shard_count: int) -> int:
         return int(self._lib.gswt_shard_rows_padded(height, shard_count))
 

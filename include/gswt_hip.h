@@ -246,6 +246,48 @@ GSWT_API int gswt_render_async(gswt_ctx *ctx, const gswt_camera_uniforms *camera
 GSWT_API int gswt_render_wait(gswt_ctx *ctx, int ticket);
 GSWT_API int gswt_render_fence(gswt_ctx *ctx, int ticket);
 
+/* ---- background passes (state.rs:384-392) -------------------------------------------------------
+ * State::render runs Skybox::render and Proxy::render before GSWTRenderer::render; their colour /
+ * depth targets are what gswt_render takes as bg_rgba / bg_depth.  Here they are per-pixel compute
+ * passes on the ctx stream (a following gswt_render / gswt_render_async is ordered after them). */
+
+/* proxy.wgsl `Uniforms` / proxy.rs:470-511, byte-exact (224 B) */
+typedef struct gswt_proxy_uniforms {
+    float height_offset;            /*   0 */
+    float tile_width;               /*   4 */
+    uint32_t surface_type;          /*   8 */
+    float width_scale;              /*  12 */
+    uint32_t map_proxy;             /*  16 */
+    uint32_t use_clip;              /*  20 */
+    float clip_height;              /*  24 */
+    float brightness;               /*  28 */
+    uint32_t black_background;      /*  32 */
+    uint32_t _pad0[3];              /*  36 */
+    float view[16];                 /*  48 */
+    float projection[16];           /* 112 */
+    uint32_t map_half_wh[2];        /* 176 */
+    int32_t center_coord[2];        /* 184 */
+    float height_map_scale[4];      /* 192 */
+    float cam_pos[4];               /* 208 */
+} gswt_proxy_uniforms;              /* 224 */
+
+/* Skybox::configure (skybox.rs:341-455): the cube map, 6 faces (+X -X +Y -Y +Z -Z) of face_size^2 RGBA f32 texels
+ * (host pointer).  `equirectangular` is Skybox.is_equi (skybox.wgsl:35-38). */
+GSWT_API int gswt_skybox_configure(gswt_ctx *ctx, const float *faces_rgba, int face_size, int equirectangular);
+/* Skybox::render (skybox.rs:457-488): LoadOp::Clear + the cube drawn at depth 1 = every pixel of out_rgba_dev
+ * (W*H*4 f32, device) is overwritten with (cube rgb, 1). */
+GSWT_API int gswt_skybox_render(gswt_ctx *ctx, const gswt_camera_uniforms *camera, int width, int height, float *out_rgba_dev);
+/* Proxy::configure (proxy.rs:208-364): the mip chain of the proxy texture (square, tex_size >> level, RGBA f32, host
+ * pointers) and the grid dimension of the "full" proxy (Proxy::GRID_DIM = 2048, proxy.rs:29).  The height map is the one
+ * given to gswt_configure. */
+GSWT_API int gswt_proxy_configure(gswt_ctx *ctx, const float *const *mips, int tex_size, int n_mips, int grid_dim);
+/* ONE draw of Proxy::render (proxy.rs:366-447): u->map_proxy selects the GRID_DIM grid (0, `proxy_full`) or the tile-map
+ * grid (1, `proxy_map`).  rgba_dev (W*H*4) and depth_dev (W*H) are device buffers updated in place: colour LoadOp::Load,
+ * depth test Less with depth write.  clear_depth != 0 first fills depth_dev with 1.0 (the pass's LoadOp::Clear(1.0)). */
+GSWT_API int gswt_proxy_render(gswt_ctx *ctx, const gswt_proxy_uniforms *u, int width, int height, float *rgba_dev, float *depth_dev,
+                               int clear_depth);
+
+
 /* Number of pixel rows the shard (index, count) owns for a frame of `height` rows. */
 GSWT_API int gswt_shard_rows(int height, int shard_index, int shard_count);
 /* Scatter `shard_count` gathered shard images (concatenated in shard order, as an

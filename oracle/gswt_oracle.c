@@ -924,6 +924,275 @@ ORC_API int orc_project_draws(const orc_camera *cam, const orc_scene *scene, con
     return 0;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Background passes State::render runs before the splats (state.rs:384-392),  */
+/* restated per pixel: skybox (skybox.wgsl + skybox.rs:457-488) and proxy        */
+/* (proxy.wgsl + proxy.rs:366-447).  A rasterised fragment's interpolated        */
+/* attributes are functions of the pixel's view ray alone, so each pixel is      */
+/* evaluated by casting that ray: the cube-map lookup vector is the ray          */
+/* direction, and the visible proxy fragment (depth test Less, depth write on,   */
+/* no culling, blend None) is the nearest ray / height-field-mesh intersection   */
+/* whose depth lies in [0, 1].                                                   */
+/* ------------------------------------------------------------------------- */
+static void pixel_ray(const float *V, float p00, float p11, int x, int y, int W, int H, float d[3])
+{
+    float nx = ((float)x + 0.5f) / (float)W * 2.0f - 1.0f;
+    float ny = 1.0f - ((float)y + 0.5f) / (float)H * 2.0f;
+    float vx = nx / p00, vy = ny / p11, vz = -1.0f;
+    d[0] = (V[0] * vx + V[1] * vy) + V[2] * vz;
+    d[1] = (V[4] * vx + V[5] * vy) + V[6] * vz;
+    d[2] = (V[8] * vx + V[9] * vy) + V[10] * vz;
+}
+
+/* cube face order +X -X +Y -Y +Z -Z, bilinear inside the face, clamp to edge */
+static void sample_cube(const float *faces, int n, float tx, float ty, float tz, float out[4])
+{
+    float ax = fabsf(tx), ay = fabsf(ty), az = fabsf(tz);
+    int face; float sc, tc, ma;
+    if (az >= ax && az >= ay) { face = tz < 0.0f ? 5 : 4; sc = tz < 0.0f ? -tx : tx; tc = -ty; ma = az; }
+    else if (ay >= ax) { face = ty < 0.0f ? 3 : 2; sc = tx; tc = ty < 0.0f ? -tz : tz; ma = ay; }
+    else { face = tx < 0.0f ? 1 : 0; sc = tx < 0.0f ? tz : -tz; tc = -ty; ma = ax; }
+    float s = 0.5f * (sc / ma + 1.0f), t = 0.5f * (tc / ma + 1.0f);
+    float x = s * (float)n - 0.5f, y = t * (float)n - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float wx = x - fx0, wy = y - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = x0 < 0 ? 0 : (x0 > n - 1 ? n - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > n - 1 ? n - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 > n - 1 ? n - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > n - 1 ? n - 1 : y1);
+    const float *f = faces + (size_t)face * n * n * 4;
+    for (int k = 0; k < 3; k++) {
+        float c00 = f[((size_t)y0 * n + x0) * 4 + k], c10 = f[((size_t)y0 * n + x1) * 4 + k];
+        float c01 = f[((size_t)y1 * n + x0) * 4 + k], c11 = f[((size_t)y1 * n + x1) * 4 + k];
+        out[k] = (c00 * (1.0f - wx) + c10 * wx) * (1.0f - wy) + (c01 * (1.0f - wx) + c11 * wx) * wy;
+    }
+    out[3] = 1.0f;
+}
+
+/* skybox.wgsl vs_main / fs_main: lookup vector = (x, -z, y) of the world ray, y negated for a cube map */
+ORC_API void orc_skybox(const float *view16, float p00, float p11, int equirectangular, const float *faces, int face_size,
+                        int W, int H, float *out_rgba)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float d[3];
+            pixel_ray(view16, p00, p11, x, y, W, H, d);
+            float tx = d[0], ty = -d[2], tz = d[1];
+            if (!equirectangular) ty = -ty;
+            sample_cube(faces, face_size, tx, ty, tz, out_rgba + ((size_t)y * W + x) * 4);
+        }
+}
+
+/* proxy.wgsl Uniforms (224 B) */
+typedef struct {
+    float height_offset, tile_width; uint32_t surface_type; float width_scale;
+    uint32_t map_proxy, use_clip; float clip_height, brightness;
+    uint32_t black_background, _pad0[3];
+    float view[16], projection[16];
+    uint32_t map_half_wh[2]; int32_t center_coord[2];
+    float height_map_scale[4], cam_pos[4];
+} orc_proxy_uniforms;
+
+typedef struct {
+    const orc_proxy_uniforms *u;
+    const float *hmap; int hw, hh;
+    const float *const *mips; int tex_size, n_mips;
+    int nx, ny; float cs, gx0, gy0;          /* grid: cells, cell size, world xy of vertex (0, 0) */
+    float GP[16];
+} proxy_ctx;
+
+static float proxy_vertex_mapped_height(const proxy_ctx *c, float rx, float ry)
+{
+    const orc_proxy_uniforms *u = c->u;
+    if (u->surface_type != 1u) return 0.0f;
+    float xr = (2.0f * (float)u->map_half_wh[0] + 1.0f) * u->tile_width * u->height_map_scale[0];
+    float yr = (2.0f * (float)u->map_half_wh[1] + 1.0f) * u->tile_width * u->height_map_scale[1];
+    float h_u = (rx + (float)u->map_half_wh[0] * u->tile_width) / xr;
+    float h_v = (ry + (float)u->map_half_wh[1] * u->tile_width) / yr;
+    return sample_height(c->hmap, c->hw, c->hh, h_u, h_v) * u->height_map_scale[2];
+}
+
+static void proxy_tex_bilinear(const float *lvl, int n, float u, float v, float out[3])
+{
+    float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float wx = x - fx0, wy = y - fy0;
+    long x0 = (long)fx0, y0 = (long)fy0;
+    long xa = ((x0 % n) + n) % n, xb = (((x0 + 1) % n) + n) % n;
+    long ya = ((y0 % n) + n) % n, yb = (((y0 + 1) % n) + n) % n;
+    for (int k = 0; k < 3; k++) {
+        float c00 = lvl[(ya * n + xa) * 4 + k], c10 = lvl[(ya * n + xb) * 4 + k];
+        float c01 = lvl[(yb * n + xa) * 4 + k], c11 = lvl[(yb * n + xb) * 4 + k];
+        out[k] = (c00 * (1.0f - wx) + c10 * wx) * (1.0f - wy) + (c01 * (1.0f - wx) + c11 * wx) * wy;
+    }
+}
+
+/* One triangle (a, b, c with mapped heights ma, mb, mc): Moeller-Trumbore, then the fragment tests.
+ * Returns 1 and fills t / depth / mapped height / plane normal when the fragment exists and t < *best_t. */
+static int proxy_tri(const proxy_ctx *c, const float o[3], const float d[3], const float a[3], const float b[3], const float cc[3],
+                     float ma, float mb, float mc, float *best_t, float *depth_out, float nrm[3], float a_out[3])
+{
+    float e1[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] }, e2[3] = { cc[0] - a[0], cc[1] - a[1], cc[2] - a[2] };
+    float pv[3] = { d[1] * e2[2] - d[2] * e2[1], d[2] * e2[0] - d[0] * e2[2], d[0] * e2[1] - d[1] * e2[0] };
+    float det = (e1[0] * pv[0] + e1[1] * pv[1]) + e1[2] * pv[2];
+    if (det == 0.0f) return 0;
+    float tv[3] = { o[0] - a[0], o[1] - a[1], o[2] - a[2] };
+    float bu = ((tv[0] * pv[0] + tv[1] * pv[1]) + tv[2] * pv[2]) / det;
+    if (!(bu >= 0.0f && bu <= 1.0f)) return 0;
+    float qv[3] = { tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0] };
+    float bv = ((d[0] * qv[0] + d[1] * qv[1]) + d[2] * qv[2]) / det;
+    if (!(bv >= 0.0f && bu + bv <= 1.0f)) return 0;
+    float t = ((e2[0] * qv[0] + e2[1] * qv[1]) + e2[2] * qv[2]) / det;
+    if (!(t > 0.0f && t < *best_t)) return 0;
+    float mh = (ma + bu * (mb - ma)) + bv * (mc - ma);
+    if (c->u->use_clip == 1u && mh < c->u->clip_height) return 0;                 /* fs_main discard */
+    float hp[3] = { o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2] };
+    const float *V = c->u->view, *GP = c->GP;
+    float cv[4], q[4];
+    for (int r = 0; r < 4; r++) cv[r] = ((V[r] * hp[0] + V[4 + r] * hp[1]) + V[8 + r] * hp[2]) + V[12 + r];
+    for (int r = 0; r < 4; r++) q[r] = ((GP[r] * cv[0] + GP[4 + r] * cv[1]) + GP[8 + r] * cv[2]) + GP[12 + r] * cv[3];
+    float depth = q[2] / q[3];
+    if (!(q[3] > 0.0f && depth >= 0.0f && depth <= 1.0f)) return 0;             /* near / far clip */
+    *best_t = t; *depth_out = depth;
+    nrm[0] = e1[1] * e2[2] - e1[2] * e2[1]; nrm[1] = e1[2] * e2[0] - e1[0] * e2[2]; nrm[2] = e1[0] * e2[1] - e1[1] * e2[0];
+    a_out[0] = a[0]; a_out[1] = a[1]; a_out[2] = a[2];
+    return 1;
+}
+
+static void proxy_cell_vertices(const proxy_ctx *c, int i, int j, float v[4][3], float m[4])
+{
+    /* vertex k = (i + (k & 1), j + (k >> 1)) */
+    for (int k = 0; k < 4; k++) {
+        int vi = i + (k & 1), vj = j + (k >> 1);
+        float rx = c->gx0 + (float)vi * c->cs, ry = c->gy0 + (float)vj * c->cs;
+        m[k] = proxy_vertex_mapped_height(c, rx, ry);
+        v[k][0] = rx; v[k][1] = ry; v[k][2] = c->u->height_offset + m[k];
+    }
+}
+
+/* uv of the point where the ray of pixel (x, y) meets the plane (a, nrm) */
+static void proxy_plane_uv(const proxy_ctx *c, const float o[3], const float d[3], const float a[3], const float nrm[3], float uv[2])
+{
+    float num = (nrm[0] * (a[0] - o[0]) + nrm[1] * (a[1] - o[1])) + nrm[2] * (a[2] - o[2]);
+    float den = (nrm[0] * d[0] + nrm[1] * d[1]) + nrm[2] * d[2];
+    float t = num / den;
+    uv[0] = (o[0] + t * d[0]) / c->u->tile_width / 4.0f;
+    uv[1] = (o[1] + t * d[1]) / c->u->tile_width / 4.0f;
+}
+
+/* proxy.rs:366-447 for one draw (map_proxy = 0: the GRID_DIM grid, 1: the tile-map grid).  rgba / depth are read-modify-write:
+ * colour LoadOp::Load, depth test Less against what is there (the caller clears depth to 1.0 before the first draw). */
+ORC_API void orc_proxy(const orc_proxy_uniforms *u, int grid_dim, const float *hmap, int hw, int hh,
+                       const float *const *mips, int tex_size, int n_mips, int W, int H, float *rgba, float *depth)
+{
+    proxy_ctx c;
+    memset(&c, 0, sizeof(c));
+    c.u = u; c.hmap = hmap; c.hw = hw; c.hh = hh; c.mips = mips; c.tex_size = tex_size; c.n_mips = n_mips;
+    const float tw = u->tile_width;
+    if (u->map_proxy == 1u) {
+        c.nx = 2 * (int)u->map_half_wh[0] + 1; c.ny = 2 * (int)u->map_half_wh[1] + 1; c.cs = tw;
+        c.gx0 = (float)(-(int)u->map_half_wh[0]) * tw + (float)u->center_coord[0] * tw;
+        c.gy0 = (float)(-(int)u->map_half_wh[1]) * tw + (float)u->center_coord[1] * tw;
+    } else {
+        c.nx = c.ny = grid_dim; c.cs = u->width_scale;
+        c.gx0 = (float)(-(grid_dim / 2)) * u->width_scale + floorf((float)u->center_coord[0] * tw / u->width_scale) * u->width_scale;
+        c.gy0 = (float)(-(grid_dim / 2)) * u->width_scale + floorf((float)u->center_coord[1] * tw / u->width_scale) * u->width_scale;
+    }
+    for (int cc = 0; cc < 4; cc++) {
+        const float *P = u->projection;
+        c.GP[4 * cc + 0] = P[4 * cc + 0]; c.GP[4 * cc + 1] = P[4 * cc + 1];
+        c.GP[4 * cc + 2] = 0.5f * P[4 * cc + 2] + 0.5f * P[4 * cc + 3]; c.GP[4 * cc + 3] = P[4 * cc + 3];
+    }
+    const float p00 = u->projection[0], p11 = u->projection[5];
+    const float o[3] = { u->cam_pos[0], u->cam_pos[1], u->cam_pos[2] };
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            float d[3];
+            pixel_ray(u->view, p00, p11, x, y, W, H, d);
+            float best_t = 3.0e38f, dep = 1.0f, nrm[3] = { 0, 0, 1 }, pa[3] = { 0, 0, 0 };
+            int hit = 0;
+            /* the ray against the grid's xy rectangle, in cell units */
+            float ogx = (o[0] - c.gx0) / c.cs, ogy = (o[1] - c.gy0) / c.cs;
+            float dgx = d[0] / c.cs, dgy = d[1] / c.cs;
+            float t0 = 0.0f, t1 = 3.0e38f;
+            int ok = 1;
+            if (dgx != 0.0f) {
+                float ta = (0.0f - ogx) / dgx, tb = ((float)c.nx - ogx) / dgx;
+                t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+            } else if (!(ogx >= 0.0f && ogx <= (float)c.nx)) ok = 0;
+            if (dgy != 0.0f) {
+                float ta = (0.0f - ogy) / dgy, tb = ((float)c.ny - ogy) / dgy;
+                t0 = fmaxf(t0, fminf(ta, tb)); t1 = fminf(t1, fmaxf(ta, tb));
+            } else if (!(ogy >= 0.0f && ogy <= (float)c.ny)) ok = 0;
+            if (ok && t0 <= t1) {
+                if (u->surface_type != 1u) {
+                    /* flat grid: every triangle lies in z = height_offset; one plane hit inside the rectangle */
+                    float tz = (u->height_offset - o[2]) / d[2];
+                    float hx = o[0] + tz * d[0], hy = o[1] + tz * d[1];
+                    float cxf = (hx - c.gx0) / c.cs, cyf = (hy - c.gy0) / c.cs;
+                    if (d[2] != 0.0f && tz > 0.0f && cxf >= 0.0f && cxf <= (float)c.nx && cyf >= 0.0f && cyf <= (float)c.ny &&
+                        !(u->use_clip == 1u && 0.0f < u->clip_height)) {
+                        float hp[3] = { hx, hy, o[2] + tz * d[2] };
+                        const float *V = u->view, *GP = c.GP;
+                        float cv[4], q[4];
+                        for (int r = 0; r < 4; r++) cv[r] = ((V[r] * hp[0] + V[4 + r] * hp[1]) + V[8 + r] * hp[2]) + V[12 + r];
+                        for (int r = 0; r < 4; r++) q[r] = ((GP[r] * cv[0] + GP[4 + r] * cv[1]) + GP[8 + r] * cv[2]) + GP[12 + r] * cv[3];
+                        float dz = q[2] / q[3];
+                        if (q[3] > 0.0f && dz >= 0.0f && dz <= 1.0f) {
+                            hit = 1; dep = dz; best_t = tz;
+                            nrm[0] = 0.0f; nrm[1] = 0.0f; nrm[2] = 1.0f;
+                            pa[0] = c.gx0; pa[1] = c.gy0; pa[2] = u->height_offset;
+                        }
+                    }
+                } else {
+                    /* 2-D DDA over the cells in ray order; the first cell with a fragment holds the nearest one */
+                    float ex = ogx + t0 * dgx, ey = ogy + t0 * dgy;
+                    int ci = (int)floorf(ex), cj = (int)floorf(ey);
+                    ci = ci < 0 ? 0 : (ci > c.nx - 1 ? c.nx - 1 : ci); cj = cj < 0 ? 0 : (cj > c.ny - 1 ? c.ny - 1 : cj);
+                    int sx = dgx > 0.0f ? 1 : -1, sy = dgy > 0.0f ? 1 : -1;
+                    float tmx = dgx != 0.0f ? ((float)(ci + (sx > 0 ? 1 : 0)) - ogx) / dgx : 3.0e38f;
+                    float tmy = dgy != 0.0f ? ((float)(cj + (sy > 0 ? 1 : 0)) - ogy) / dgy : 3.0e38f;
+                    float tdx = dgx != 0.0f ? fabsf(1.0f / dgx) : 3.0e38f, tdy = dgy != 0.0f ? fabsf(1.0f / dgy) : 3.0e38f;
+                    for (int step = 0; step < c.nx + c.ny + 2; step++) {
+                        float v[4][3], m[4];
+                        proxy_cell_vertices(&c, ci, cj, v, m);
+                        hit |= proxy_tri(&c, o, d, v[0], v[1], v[2], m[0], m[1], m[2], &best_t, &dep, nrm, pa);
+                        hit |= proxy_tri(&c, o, d, v[1], v[3], v[2], m[1], m[3], m[2], &best_t, &dep, nrm, pa);
+                        if (hit) break;
+                        if (tmx < tmy) { ci += sx; tmx += tdx; } else { cj += sy; tmy += tdy; }
+                        if (ci < 0 || ci >= c.nx || cj < 0 || cj >= c.ny) break;
+                    }
+                }
+            }
+            size_t pi = (size_t)y * W + x;
+            if (!hit || !(dep < depth[pi])) continue;                               /* CompareFunction::Less */
+            depth[pi] = dep;
+            float *px = rgba + pi * 4;
+            if (u->black_background == 1u) { px[0] = 0.0f; px[1] = 0.0f; px[2] = 0.0f; px[3] = 1.0f; continue; }
+            /* textureSample: implicit LOD from the uv differences to the right / lower pixel on the fragment's plane */
+            float uv[2], uvx[2], uvy[2], dxr[3], dyr[3];
+            proxy_plane_uv(&c, o, d, pa, nrm, uv);
+            pixel_ray(u->view, p00, p11, x + 1, y, W, H, dxr);
+            pixel_ray(u->view, p00, p11, x, y + 1, W, H, dyr);
+            proxy_plane_uv(&c, o, dxr, pa, nrm, uvx);
+            proxy_plane_uv(&c, o, dyr, pa, nrm, uvy);
+            float sz = (float)c.tex_size;
+            float ax = (uvx[0] - uv[0]) * sz, ay = (uvx[1] - uv[1]) * sz, bx = (uvy[0] - uv[0]) * sz, by = (uvy[1] - uv[1]) * sz;
+            float rho = fmaxf(sqrtf(ax * ax + ay * ay), sqrtf(bx * bx + by * by));
+            float lod = log2f(rho);
+            if (!(lod > 0.0f)) lod = 0.0f;                                          /* also catches NaN */
+            if (lod > (float)(c.n_mips - 1)) lod = (float)(c.n_mips - 1);
+            int l0 = (int)floorf(lod), l1 = l0 + 1 > c.n_mips - 1 ? c.n_mips - 1 : l0 + 1;
+            float fl = lod - (float)l0;
+            float c0[3], c1[3];
+            proxy_tex_bilinear(c.mips[l0], c.tex_size >> l0, uv[0], uv[1], c0);
+            proxy_tex_bilinear(c.mips[l1], c.tex_size >> l1, uv[0], uv[1], c1);
+            for (int k = 0; k < 3; k++) px[k] = (c0[k] * (1.0f - fl) + c1[k] * fl) * u->brightness;
+            px[3] = 1.0f;
+        }
+}
+
 ORC_API int orc_num_threads(void)
 {
 #ifdef _OPENMP

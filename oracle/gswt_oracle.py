@@ -560,6 +560,62 @@ def project_draws(cam: Camera176, scene: Scene160, tex: np.ndarray, draws, *, he
     return out[:n]
 
 
+class Proxy224(C.Structure):
+    """proxy.wgsl Uniforms / proxy.rs:470-511 (224 B)."""
+    _fields_ = [("height_offset", C.c_float), ("tile_width", C.c_float), ("surface_type", C.c_uint32), ("width_scale", C.c_float),
+                ("map_proxy", C.c_uint32), ("use_clip", C.c_uint32), ("clip_height", C.c_float), ("brightness", C.c_float),
+                ("black_background", C.c_uint32), ("_pad0", C.c_uint32 * 3), ("view", C.c_float * 16), ("projection", C.c_float * 16),
+                ("map_half_wh", C.c_uint32 * 2), ("center_coord", C.c_int32 * 2), ("height_map_scale", C.c_float * 4),
+                ("cam_pos", C.c_float * 4)]
+
+
+assert C.sizeof(Proxy224) == 224
+
+
+def proxy_uniforms(cam: "Camera", *, map_proxy=1, height_offset=-0.5, tile_width=4.0, surface_type=0, width_scale=4.0, use_clip=0,
+                   clip_height=0.0, brightness=1.0, black_background=0, map_half_wh=(0, 0), center_coord=(0, 0),
+                   height_map_scale=(1.0, 1.0, 0.0)) -> Proxy224:
+    """Uniforms::new, proxy.rs:489-511"""
+    u = Proxy224()
+    u.height_offset, u.tile_width, u.surface_type, u.width_scale = height_offset, tile_width, int(surface_type), width_scale
+    u.map_proxy, u.use_clip, u.clip_height, u.brightness = int(map_proxy), int(use_clip), clip_height, brightness
+    u.black_background = int(black_background)
+    u.view[:] = [float(x) for x in cam.view]
+    u.projection[:] = [float(x) for x in cam.projection]
+    u.map_half_wh[:] = [int(map_half_wh[0]), int(map_half_wh[1])]
+    u.center_coord[:] = [int(center_coord[0]), int(center_coord[1])]
+    u.height_map_scale[:] = [float(height_map_scale[0]), float(height_map_scale[1]), float(height_map_scale[2]), 0.0]
+    u.cam_pos[:] = [float(cam.position[0]), float(cam.position[1]), float(cam.position[2]), 0.0]
+    return u
+
+
+def skybox_render(cam: "Camera", faces: np.ndarray, width: int, height: int, equirectangular: int = 0) -> np.ndarray:
+    """Skybox::render, skybox.rs:457-488.  faces [6, n, n, 4] f32 (+X -X +Y -Y +Z -Z)."""
+    faces = np.ascontiguousarray(faces, dtype=np.float32)
+    out = np.zeros((height, width, 4), dtype=np.float32)
+    view = np.ascontiguousarray(cam.view, dtype=np.float32)
+    L = lib()
+    L.orc_skybox.restype = None
+    L.orc_skybox.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_skybox(_ptr(view), float(cam.projection[0]), float(cam.projection[5]), int(equirectangular), _ptr(faces), faces.shape[1],
+                 width, height, _ptr(out))
+    return out
+
+
+def proxy_render(u: Proxy224, width: int, height: int, rgba: np.ndarray, depth: np.ndarray, mips, *, height_map=None, grid_dim=2048):
+    """Proxy::render for ONE draw, proxy.rs:366-447; rgba / depth are updated in place (depth must start at 1.0)."""
+    L = lib()
+    L.orc_proxy.restype = None
+    L.orc_proxy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                            C.c_void_p, C.c_void_p]
+    mips = [np.ascontiguousarray(m, dtype=np.float32) for m in mips]
+    arr = (C.c_void_p * len(mips))(*[m.ctypes.data for m in mips])
+    hm = np.ascontiguousarray(height_map, dtype=np.float32) if height_map is not None else None
+    assert rgba.dtype == np.float32 and depth.dtype == np.float32 and rgba.flags.c_contiguous and depth.flags.c_contiguous
+    L.orc_proxy(C.byref(u), int(grid_dim), _ptr(hm), hm.shape[1] if hm is not None else 0, hm.shape[0] if hm is not None else 0,
+                arr, mips[0].shape[0], len(mips), width, height, _ptr(rgba), _ptr(depth))
+
+
 def num_threads() -> int:
     return int(lib().orc_num_threads())
 
