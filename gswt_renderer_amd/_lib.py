@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgswt_hip.so")
+LIB_PATH = os.environ.get("GSWT_HIP_LIB") or os.path.join(_HERE, "lib", "libgswt_hip.so")   # env override: kernel-variant sweeps
 
 GSWT_OK = 0
 GSWT_ERR_BAD_ARG = -1

@@ -208,7 +208,14 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
 // One workgroup = one 256-entry chunk of one draw, in composite (front-to-back) order:
 // slot = slot_base + r, r-th entry from the END of the draw's list.
 // ------------------------------------------------------------------------------------
-template <bool DEBUG>
+// FULL = false is the lean variant the normal frame runs (surface None / HeightMap, draw_mode 0); the Sphere mapping
+// (five sin / cos pairs per splat) and the debug recolouring live only in FULL = true.
+// Measured and dropped (c3, isolated 103 us): (1) a persistent grid over a device-compacted chunk list -- static striding
+// loses the dispatcher's dynamic balance (-8 % frames/s), a shared work counter serialises on one L2 address (230 us);
+// (2) culling on the host and launching over the surviving chunks only -- the 20 k empty workgroups cost nothing
+// measurable once two frames overlap (3519 vs 3517 frames/s); (3) four chunks per workgroup with all list / record
+// loads issued up front (88 VGPRs, 123 us).
+template <bool DEBUG, bool FULL>
 __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256) void k_project(
                 c1 = c1 + F[7] * z;
                 c2 = nz + F[8] * z;
                 mapped_z = nz;
-            } else if (f.surface_type == 2u) {
+            } else if (FULL && f.surface_type == 2u) {
                 // surface_mapping, gswt.wgsl:600-623 (icosahedral-strip parametrisation, 5 x 2 blocks)
                 const float DELTA = 0.001f;
                 const float xmax = ((float)f.map_half_wh[0] * 2.0f) * f.tile_width;
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(256) void k_project(
             float cg = (float)((w1.w >> 8) & 0xFFu) / 255.0f;
             float cb = (float)((w1.w >> 16) & 0xFFu) / 255.0f;
             float ca = (float)((w1.w >> 24) & 0xFFu) / 255.0f;
-            if (f.draw_mode != 0u) debug_draw_color(f, d, u2f(w0.x), u2f(w0.y), lod_id, t_ratio, cr, cg, cb);   // :268-399
+            if (FULL && f.draw_mode != 0u) debug_draw_color(f, d, u2f(w0.x), u2f(w0.y), lod_id, t_ratio, cr, cg, cb);   // :268-399
             if (d.changing == 1u) {
                 if (lod_id != higher_lod) ca = ca * t_ratio;
                 else ca = ca * (1.0f - t_ratio);
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(256) void k_project(
                     reinterpret_cast<float4*>(dst)[0] = make_float4(r_iux, r_iuy, cxp, ca);
                     reinterpret_cast<float4*>(dst)[1] = make_float4(r_ivx, r_ivy, cyp, depth);
                     reinterpret_cast<float4*>(dst)[2] = make_float4(__uint_as_float(w1.w), hx, hy, 0.0f);
-                    if (f.draw_mode != 0u) col_f[slot] = make_float4(cr, cg, cb, 0.0f);   // debug colours are not bytes
+                    if (FULL && f.draw_mode != 0u) col_f[slot] = make_float4(cr, cg, cb, 0.0f);   // debug colours are not bytes
                 }
             }
         } while (0);
@@ -647,7 +654,7 @@ __device__ __forceinline__ uint32_t clamped_count(const unsigned long long* n_pt
     return (uint32_t)n;
 }
 
-constexpr int kSortItems = 16;   // per thread
+constexpr int kSortItems = 16;   // per thread (c3 sweep of the sort stage: 4 -> 139 us, 8 -> 97.5, 16 -> 95, 32 -> 109)
 constexpr int kSortBlock = 256 * kSortItems;
 
 // Per pass: k_radix_hist leaves, for every digit d, the per-workgroup counts ghist[d][blk], the sums over
@@ -1236,12 +1243,15 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
 {
     if (n_chunks == 0) return;
     const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs x n_super][visible x n_super], zeroed by the caller
-    if (debug)
-        hipLaunchKernelGGL(k_project<true>, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,
-                           merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg, col_f);
-    else
-        hipLaunchKernelGGL(k_project<false>, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,
-                           merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg, col_f);
+    const bool full = f.surface_type == 2u || f.draw_mode != 0u;
+#define GSWT_LAUNCH_PROJECT(D, F)                                                                                              \
+    hipLaunchKernelGGL((k_project<D, F>), dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,        \
+                       merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg, col_f)
+    if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
+    else if (debug) { GSWT_LAUNCH_PROJECT(true, false); }
+    else if (full) { GSWT_LAUNCH_PROJECT(false, true); }
+    else { GSWT_LAUNCH_PROJECT(false, false); }
+#undef GSWT_LAUNCH_PROJECT
     hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters);
 }
 

@@ -57,6 +57,16 @@ for K in (1, 2, 3):
 
 # ablations on one context (serial frames)
 r, st, outs = ctxs[0]
+r.set_option(L.GSWT_OPT_TIMING, 2)
+acc = {}
+for i in range(30):
+    r.render_wait(r.render_async(cu, su, W, H, outs[0].data_ptr(), transmittance_eps=1e-5))
+    if i >= 10:
+        for k, v in r.timings().items():
+            if k.startswith("ms_"):
+                acc.setdefault(k, []).append(v)
+print("serial stage times (us):", {k: round(float(np.median(v)) * 1e3, 1) for k, v in acc.items()}, flush=True)
+r.set_option(L.GSWT_OPT_TIMING, 1)
 for flags, name in [(0, "full"), (1, "no walk"), (2, "stage only"), (4, "no staging (fixed)")]:
     r.set_option(L.GSWT_OPT_DEBUG_FLAGS, flags)
     ts = []
