@@ -47,7 +47,7 @@ def build_workload(name: str, lod0_override: int | None = None):
     return w, wang, cu, vp, sort
 
 
-def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0):
+def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None):
     """Times the CPU oracle (oracle/gswt_oracle.c, OpenMP) on ONE frame of the same workload."""
     from oracle import gswt_oracle as orc
     tex, gi, li = wang.preload()
@@ -76,7 +76,15 @@ def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0):
     # the GPU box gives one GPU's job a 16-core CPU share; the oracle's OpenMP team is sized to that
     n_threads = int(os.environ.get("GSWT_CPU_BASELINE_THREADS", str(min(16, os.cpu_count() or 1))))
     t0 = time.perf_counter()
-    img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads)
+    bg = bgd = None
+    if passes is not None:          # the oracle's skybox + proxy restatements feed the splat pass (state.rs:384-402)
+        faces, mips, pu = passes
+        cam = type("Cam", (), {})()
+        cam.view = np.array(ocu.view[:], dtype=np.float32); cam.projection = np.array(ocu.projection[:], dtype=np.float32)
+        bg = orc.skybox_render(cam, faces, W, H)
+        bgd = np.ones((H, W), np.float32)
+        orc.proxy_render(orc.Proxy224.from_buffer_copy(bytes(pu)), W, H, bg, bgd, mips)
+    img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads, bg_rgba=bg, bg_depth=bgd)
     dt = time.perf_counter() - t0
     return img, st, dt, n_threads
 
@@ -90,9 +98,16 @@ def main():
     ap.add_argument("--lod0", type=int, default=0, help="override LOD0 splats per tile (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--t-eps", type=float, default=1e-5, help="front-to-back early-out threshold")
+    ap.add_argument("--passes", type=int, default=-1, help="1: run the skybox + proxy compute passes before the splats each frame "
+                    "(BASELINE config 5); default: on for c5, off otherwise")
     ap.add_argument("--timing", type=int, default=1, help="hipEvent level: 1 = frame + k_composite (roofline), 2 = every stage")
     args = ap.parse_args()
 
+    # Only the final JSON line may reach stdout (RCCL prints a version banner there): park the real stdout and point
+    # fd 1 at stderr for the rest of the run.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     force_dist = os.environ.get("GSWT_BENCH_FORCE_DIST") == "1"      # exercise the all-gather plumbing with one rank
     rank = int(os.environ.get("RANK", "0"))
@@ -134,6 +149,44 @@ def main():
     gathered = torch.empty((world * rows, W, 4), dtype=torch.float32, device=dev) if use_dist else None
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if use_dist else None
 
+    use_passes = args.passes == 1 or (args.passes < 0 and args.workload == "c5")
+    bgs = depths = None
+    pu = None
+    if use_passes:
+        # synthetic sky cube (smooth in direction) and proxy texture (checker mip chain); proxy_map grid at z = -0.5
+        n = 256
+        faces = np.zeros((6, n, n, 4), np.float32)
+        tt, ss = np.meshgrid((np.arange(n) + .5) / n * 2 - 1, (np.arange(n) + .5) / n * 2 - 1, indexing="ij")
+        one = np.ones_like(ss)
+        dirs = {0: (one, -tt, -ss), 1: (-one, -tt, ss), 2: (ss, one, tt), 3: (ss, -one, -tt), 4: (ss, -tt, one), 5: (-ss, -tt, -one)}
+        for fi in range(6):
+            dv = np.stack(dirs[fi], -1)
+            dv /= np.linalg.norm(dv, axis=-1, keepdims=True)
+            faces[fi, ..., :3] = 0.5 + 0.4 * dv
+            faces[fi, ..., 3] = 1.0
+        ts = 512
+        yy, xx = np.mgrid[0:ts, 0:ts]
+        cur = np.zeros((ts, ts, 4), np.float32)
+        cur[..., 0] = ((xx // 32 + yy // 32) % 2) * 0.6 + 0.2
+        cur[..., 1] = 0.35; cur[..., 2] = 0.25; cur[..., 3] = 1.0
+        mips = []
+        while True:
+            mips.append(cur.copy())
+            if cur.shape[0] == 1:
+                break
+            cur = cur.reshape(cur.shape[0] // 2, 2, cur.shape[1] // 2, 2, 4).mean((1, 3)).astype(np.float32)
+        r.skybox_configure(faces)
+        r.proxy_configure(mips)
+        pu = L.ProxyUniforms()
+        pu.height_offset, pu.tile_width, pu.surface_type, pu.width_scale = -0.5, su.tile_width, 0, 4.0
+        pu.map_proxy, pu.use_clip, pu.clip_height, pu.brightness, pu.black_background = 1, 0, 0.0, 1.0, 0
+        pu.view[:] = cu.view[:]; pu.projection[:] = cu.projection[:]
+        pu.map_half_wh[:] = su.map_half_wh[:]; pu.center_coord[:] = su.center_coord[:]
+        pu.height_map_scale[:] = su.height_map_scale[:]; pu.cam_pos[:] = cu.cam_pos[:]
+        bgs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        depths = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+
     comp_ms, total_ms, pairs = [], [], []
     inflight = []
     last = [None]
@@ -142,7 +195,12 @@ def main():
         # the frame runs on its slot's own stream (two frames overlap on the GPU); the all-gather of frame i is
         # queued on the ctx stream behind a device-side fence, AFTER frame i+1 has been submitted
         o = outs[i % 2]
-        ticket = r.render_async(cu, su, W, H, o.data_ptr(), transmittance_eps=args.t_eps, shard=shard)
+        bgp = dpp = 0
+        if use_passes:      # state.rs:384-392: skybox, then proxy (colour + depth), then the splats over them
+            bgp, dpp = bgs[i % 2].data_ptr(), depths[i % 2].data_ptr()
+            r.skybox_render(cu, W, H, bgp)
+            r.proxy_render(pu, W, H, bgp, dpp, True)
+        ticket = r.render_async(cu, su, W, H, o.data_ptr(), transmittance_eps=args.t_eps, shard=shard, bg_rgba_ptr=bgp, bg_depth_ptr=dpp)
         inflight.append((ticket, o))
 
     def collect():
@@ -184,13 +242,38 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # A few frames one at a time (outside the timed region): the compositing kernel without another frame's kernels
+    # sharing the chip.  `roofline` itself comes from the timed region, where two frames overlap.
+    iso = []
+    for i in range(6):
+        r.render_wait(r.render_async(cu, su, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, shard=shard,
+                                     bg_rgba_ptr=bgs[0].data_ptr() if use_passes else 0, bg_depth_ptr=depths[0].data_ptr() if use_passes else 0))
+        iso.append(r.timings()["ms_composite_kernel"])
+    iso_ms = float(np.median(iso[2:]))
+    if dist:
+        dist.barrier()
+
     if rank == 0:
         fps = args.steps / dt
         P = float(np.mean(pairs))
         comp = float(np.mean(comp_ms)) * 1e-3
         n_px = (rows if world > 1 else H) * W
-        algo_bytes = 52.0 * P + 16.0 * n_px                     # (4 + 48) B per pair + 16 B per pixel
+        algo_bytes = 52.0 * P + (36.0 if use_passes else 16.0) * n_px   # (4 + 48) B per pair + 16 B per pixel (+ 20 B read with bg colour + depth)
         achieved = algo_bytes / comp / 1e9 if comp > 0 else 0.0
+        # HBM bytes per launch of k_composite from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate passes; profiles/): raw counter bytes.  MI355X_MICROARCH's x2 rule is for wide coalesced
+        # streams; these reads are 48-B gathers (uncalibrated), so the raw sum is reported and the x2 figure kept beside it.
+        traffic, traffic_note = None, "no PMC summary for this workload under profiles/"
+        pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload}_s2.json")
+        if world == 1 and os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                k = next(v for n, v in pmc.items() if "k_composite" in n)
+                traffic = (k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+                traffic_note = (f"{os.path.basename(pmc_path)}: FETCH_SIZE {k['FETCH_SIZE'] / 1024:.1f} MiB + WRITE_SIZE {k['WRITE_SIZE'] / 1024:.1f} MiB raw per launch; "
+                                f"with the gfx950 x2 wide-read rule the reads would be {2 * k['FETCH_SIZE'] / 1024:.1f} MiB (48-B gathers: uncalibrated)")
+            except Exception as e:      # the summary is evidence, not a dependency
+                traffic_note = f"could not read {pmc_path}: {e}"
         res = {
             "metric": "frames/sec @1920x1080, 32x32 Wang-tile grid" if args.workload == "c3" else f"frames/sec ({args.workload})",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,23 +282,26 @@ def main():
             "config": {"workload": f"{args.workload}: {w['desc']}", "map": [2 * w["half"][0] + 1, 2 * w["half"][1] + 1],
                        "width": W, "height": H, "n_draws": int(last["n_draws"]), "n_instanced": int(last["n_instanced"]),
                        "n_visible": int(last["n_visible"]), "n_pairs": int(last["n_pairs"]), "order": "reference",
-                       "transmittance_eps": args.t_eps,
+                       "transmittance_eps": args.t_eps, "skybox_proxy_passes": bool(use_passes),
                        "parallelism": f"screen-tile-rows x{world} + RCCL all-gather" if world > 1 else "single GPU"},
             "stage_ms": {k: float(last[k]) for k in ("ms_project", "ms_emit", "ms_sort", "ms_ranges", "ms_composite", "ms_composite_kernel", "ms_total")},
             "frames_in_flight": 2,
             "roofline": {"bound": "hbm", "kernel": "k_composite", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": comp * 1e3},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": comp * 1e3,
+                         "kernel_ms_isolated": iso_ms, "frac_isolated": (algo_bytes / (iso_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if iso_ms > 0 else None,
+                         "traffic_note": traffic_note},
         }
         if use_dist:
             res["dist_check_max_abs_diff"] = float((frame - (out if world == 1 else frame)).abs().max().item())
         if world == 1 and not args.no_cpu_baseline:
-            img_cpu, st, cdt, nthr = cpu_baseline(wang, sort, cu, vp, su, W, H)
+            img_cpu, st, cdt, nthr = cpu_baseline(wang, sort, cu, vp, su, W, H, passes=(faces, mips, pu) if use_passes else None)
             gpu_img = out.cpu().numpy()
             res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": nthr, "kind": "port",
                                    "sample": "1 frame of the same workload (oracle/gswt_oracle.c, OpenMP over 16-row bands)",
                                    "max_abs_diff_vs_gpu": float(np.max(np.abs(gpu_img.astype(np.float64) - img_cpu.astype(np.float64))))}
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if dist:
         dist.destroy_process_group()
 
