@@ -38,7 +38,7 @@ void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*);
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint2*, float4*, hipEvent_t, hipEvent_t);
+                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
 void launch_proxy(hipStream_t, const ProxyArgs&, const float*, const float4*, float4*, float*);
@@ -103,7 +103,7 @@ struct FrameSlot {
     DevBuf<uint32_t> block_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
     DevBuf<uint2> ranges;
     DevBuf<uint32_t> item_base;
-    DevBuf<uint2> item_tab;
+    DevBuf<uint4> item_tab;
     DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x n_slots key/val ping-pong + per-block counts
     DevBuf<float4> partials;
     DevBuf<float4> col_f;                  // debug draw modes: float colours per slot

@@ -248,6 +248,8 @@ __global__ __launch_bounds__(256) void k_project(
         const uint32_t j = d.count - 1u - r;
         const uint32_t* list = d.merged ? merged_list : static_list;
         const uint32_t entry = list[d.list_base + j];
+        // the map id of a merged draw rides along with the list word (one round trip, not a third dependent one)
+        const uint32_t map_id_m = d.single_draw == 1u ? merged_map[d.list_base + j] : 0u;
         const uint32_t gs_index = entry & kIdxMask;
         const uint32_t lod_id = entry >> kLodShift;
         do {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void k_project(
             // A3 :52-65
             float ox = d.off[0], oy = d.off[1], oz = d.off[2];
             if (d.single_draw == 1u) {
-                const uint32_t map_id = merged_map[d.list_base + j];
+                const uint32_t map_id = map_id_m;
                 uint32_t map_wh_y = 2u * f.map_half_wh[1];
                 if (f.surface_type != 2u) map_wh_y += 1u;
                 ox = (float)((int32_t)(map_id / map_wh_y - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void k_project(
                 float bidy = (float)(2u * d.map_coord[1] / (f.map_half_wh[1] * 2u));
                 if (d.single_draw == 1u) {
                     const uint32_t map_height = 2u * f.map_half_wh[1];
-                    const uint32_t map_id = merged_map[d.list_base + j];
+                    const uint32_t map_id = map_id_m;
                     bidx = (float)(5u * (map_id / map_height) / (f.map_half_wh[0] * 2u));
                     bidy = (float)(2u * (map_id % map_height) / (f.map_half_wh[1] * 2u));
                 }
@@ -604,18 +606,24 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
 {
     __shared__ uint32_t s_w[4];
     const uint32_t c = blockIdx.x;
-    if (block_sums[c] == 0u) return;
+    // All loads are issued together with clamped indices (masked loads are waited for one at a time):
+    // this chunk's pair count, the two-level sums in front of it, and the tile rect of this thread's slot.
+    const uint32_t sup = c >> 8;
+    const uint32_t cj = (sup << 8) + threadIdx.x;
+    const uint32_t slot = c * 256u + threadIdx.x;
+    const uint32_t my_sum = block_sums[c];
+    const uint32_t bs = block_sums[min(cj, c)];
+    const uint32_t ss = super_sums[min(threadIdx.x, sup)];          // sup <= n_chunks / 256: one word per thread covers 65 k chunks
+    const uint2 rc = rects[slot];                                    // only meaningful when my_sum != 0 (k_project wrote it then)
+    if (my_sum == 0u) return;
     // first pair of this chunk = sum of all earlier chunks' pair counts, from the two-level sums
     // k_project left behind (super_sums[j] = sum over chunks 256 j .. 256 j + 255): no scan kernel
     uint32_t part = 0;
-    const uint32_t sup = c >> 8;
-    for (uint32_t j = threadIdx.x; j < sup; j += 256u) part += super_sums[j];
-    const uint32_t cj = (sup << 8) + threadIdx.x;
-    if (cj < c) part += block_sums[cj];
+    if (threadIdx.x < sup) part += ss;
+    for (uint32_t j = threadIdx.x + 256u; j < sup; j += 256u) part += super_sums[j];
+    if (cj < c) part += bs;
     uint32_t chunk_base;
     (void)block_excl_scan(part, s_w, &chunk_base);
-    const uint32_t slot = c * 256u + threadIdx.x;
-    const uint2 rc = rects[slot];
     const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
     uint32_t count = 0;
     if (tx1 >= tx0) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
@@ -674,9 +682,15 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__
     __syncthreads();
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t base = blockIdx.x * kSortBlock + w * (64 * kSortItems);
-    for (int k = 0; k < kSortItems; k++) {
-        uint32_t i = base + k * 64 + lane;
-        if (i < n) atomicAdd(&s_h[(keys[i] >> shift) & mask], 1u);
+    if (base < n) {                               // wave-uniform
+        // all loads first, with clamped indices (a load under a lane mask is waited for on the spot, which made
+        // the 16 loads of a lane 16 dependent round trips)
+        uint32_t key[kSortItems];
+#pragma unroll
+        for (int k = 0; k < kSortItems; k++) key[k] = keys[min(base + (uint32_t)k * 64u + lane, n - 1u)];
+#pragma unroll
+        for (int k = 0; k < kSortItems; k++)
+            if (base + (uint32_t)k * 64u + lane < n) atomicAdd(&s_h[(key[k] >> shift) & mask], 1u);
     }
     __syncthreads();
     const uint32_t cnt = s_h[threadIdx.x];
@@ -705,23 +719,41 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
     __syncthreads();
     const uint32_t base = blockIdx.x * kSortBlock + w * (64 * kSortItems);
     uint32_t key[kSortItems], val[kSortItems];
+    // every load of the workgroup is issued before anything is consumed: clamped indices instead of lane masks
+    // (masked loads were waited for one by one: 16 + ~30 dependent round trips per wave, the whole 31 us of this kernel)
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
-        uint32_t i = base + k * 64 + lane;
-        if (i < n) {
-            key[k] = keys_in[i];
-            val[k] = vals_in[i];
-            atomicAdd(&s_h[w][(key[k] >> shift) & mask], 1u);
-        }
+        const uint32_t i = min(base + (uint32_t)k * 64u + lane, n - 1u);      // n > 0 here
+        key[k] = keys_in[i];
+        val[k] = vals_in[i];
     }
-    {   // digit = threadIdx.x: global base of this workgroup's first item with that digit
-        const uint32_t d = threadIdx.x;
+    // digit = threadIdx.x: global base of this workgroup's first item with that digit = items with a smaller digit
+    // + the same digit in earlier groups of 32 workgroups (gsup) + in earlier workgroups of this group (ghist)
+    const uint32_t d = threadIdx.x;
+    const uint32_t sb = blockIdx.x >> kSupShift;
+    uint32_t pre = 0;
+    {
+        const uint32_t g_tot = gtot[d];
+        uint32_t t[32];
+#pragma unroll
+        for (uint32_t u = 0; u < 32u; u++) {                                     // <= 31 earlier workgroups of this group
+            const uint32_t j = (sb << kSupShift) + u;
+            t[u] = ghist[min(j, nblk - 1u) * 256u + d];
+        }
+        for (uint32_t j0 = 0; j0 < sb; j0 += 16u) {                              // earlier groups, 16 loads in flight
+            uint32_t g[16];
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; u++) g[u] = gsup[min(j0 + u, nsup - 1u) * 256u + d];
+#pragma unroll
+            for (uint32_t u = 0; u < 16u; u++) if (j0 + u < sb) pre += g[u];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 32u; u++) if ((sb << kSupShift) + u < blockIdx.x) pre += t[u];
+#pragma unroll
+        for (int k = 0; k < kSortItems; k++)
+            if (base + (uint32_t)k * 64u + lane < n) atomicAdd(&s_h[w][(key[k] >> shift) & mask], 1u);
         uint32_t tot;
-        uint32_t b = block_excl_scan(gtot[d], s_w, &tot);               // items with a smaller digit (includes a barrier)
-        const uint32_t sb = blockIdx.x >> kSupShift;
-        for (uint32_t j = 0; j < sb; j++) b += gsup[j * 256u + d];       // earlier groups of 32 workgroups
-        for (uint32_t j = sb << kSupShift; j < blockIdx.x; j++) b += ghist[j * 256u + d];   // earlier workgroups of this group
-        (void)nblk; (void)nsup;
+        uint32_t b = block_excl_scan(g_tot, s_w, &tot) + pre;                    // (includes a barrier: the LDS counts are complete)
         for (int k = 0; k < 4; k++) { uint32_t c = s_h[k][d]; s_h[k][d] = b; b += c; }      // per-wave bases
     }
     __syncthreads();
@@ -920,9 +952,9 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
     const uint32_t n = clamped_count(n_ptr, n_cap);
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    uint32_t k = keys[i];
-    if (i == 0 || keys[i - 1] != k) ranges[k].x = i;
-    if (i == n - 1 || keys[i + 1] != k) ranges[k].y = i + 1;
+    const uint32_t k = keys[i], kp = keys[i == 0 ? 0 : i - 1], kn = keys[min(i + 1, n - 1)];   // three loads in flight together
+    if (i == 0 || kp != k) ranges[k].x = i;
+    if (i == n - 1 || kn != k) ranges[k].y = i + 1;
 }
 
 // ------------------------------------------------------------------------------------
@@ -941,10 +973,10 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 // Work items: a tile's pair list is cut into segments of `seg` pairs; item = (tile, segment).
 // seg_count[t] = max(1, ceil(len / seg)) so empty tiles still get one item (they write the background).
 // item_base[t] = exclusive scan of seg_count, item_base[n_tiles] = number of items; item_tab[item] =
-// (tile, segment << 1 | tile has several segments).  Single workgroup (n_tiles is a few thousand to a few
+// (tile, segment << 1 | tile has several segments, first pair, end pair): everything k_composite needs in one load.  Single workgroup (n_tiles is a few thousand to a few
 // tens of thousands): one launch instead of count + 3 scan launches.
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
-                                                uint32_t* __restrict__ item_base, uint2* __restrict__ item_tab, uint32_t max_items)
+                                                uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items)
 {
     __shared__ uint32_t s_w[16];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -952,8 +984,9 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
     for (int base = 0; base < n_tiles; base += 1024) {
         const int t = base + (int)threadIdx.x;
         uint32_t cnt = 0;
+        uint2 r = make_uint2(0u, 0u);
         if (t < n_tiles) {
-            const uint2 r = ranges[t];
+            r = ranges[t];
             const uint32_t len = r.y - r.x;
             cnt = len == 0 ? 1u : (len + seg - 1u) / seg;
         }
@@ -966,7 +999,10 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
             const uint32_t first = carry + wbase + inc - cnt;
             item_base[t] = first;
             const uint32_t multi = cnt > 1u ? 1u : 0u;
-            for (uint32_t k = 0; k < cnt && first + k < max_items; k++) item_tab[first + k] = make_uint2((uint32_t)t, (k << 1) | multi);
+            for (uint32_t k = 0; k < cnt && first + k < max_items; k++) {
+                const uint32_t a = r.x + k * seg;
+                item_tab[first + k] = make_uint4((uint32_t)t, (k << 1) | multi, a, min(r.y, a + seg));
+            }
         }
         carry += tot;
         __syncthreads();
@@ -991,7 +1027,7 @@ __device__ unsigned long long g_stats[8];
 // COLF (debug draw modes only): colours are floats from the side buffer col_f[slot], staged into a third LDS word.
 template <bool EARLY, bool DEPTH, bool COLF>
 __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
-                                                   const uint32_t* __restrict__ item_base, const uint2* __restrict__ item_tab,
+                                                   const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
                                                    uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
                                                    const float4* __restrict__ col_f,
                                                    const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
@@ -1005,10 +1041,10 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
     // work item -> (tile, segment) through the table k_items left behind.  Consecutive items are dealt
     // round-robin over the 8 XCDs by the dispatcher, which balances the skewed tile-list lengths.
     const uint32_t item = blockIdx.x;
-    if (item >= item_base[n_tiles]) return;
-    const uint2 it = item_tab[item];
+    const uint32_t n_items = item_base[n_tiles];
+    const uint4 it = item_tab[item];                 // (in flight together with n_items; garbage past n_items, unused)
+    if (item >= n_items) return;
     const int tile = (int)it.x;
-    const uint32_t seg_idx = it.y >> 1;
     const bool multi_seg = (it.y & 1u) != 0u;
     const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
@@ -1027,9 +1063,7 @@ __global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* _
     const float yt0 = (float)qy + 0.5f, yt1 = (float)qy + 3.5f, yb0 = (float)qy + 4.5f, yb1 = (float)qy + 7.5f;
     uint8_t* const wlist = &s_list[wave][0][0];
     const uint8_t* const my_list = &s_list[wave][grp][0];
-    uint2 rg = ranges[tile];
-    rg.x += seg_idx * seg;
-    rg.y = min(rg.y, rg.x + seg);
+    const uint2 rg = make_uint2(it.z, it.w);         // this item's slice of the tile's pair list
     // Transmittance doubles as the "still active" state: a lane is live while T >= t_eps.  Pixels
     // outside the target start at T = 0 when early-out is on (never live); with t_eps = 0 they just
     // accumulate and are never stored.
@@ -1356,7 +1390,7 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const un
 // k_composite over an upper bound of items -> k_combine.
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
                       const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
-                      uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint2* item_tab, float4* partials,
+                      uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
                       hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     if (n_tiles == 0) return;
