@@ -1026,7 +1026,7 @@ __device__ unsigned long long g_stats[8];
 // unpacked by v_cvt_f32_ubyteN in the blend; the accumulators run in 0..255 units and are scaled once at the end.
 // COLF (debug draw modes only): colours are floats from the side buffer col_f[slot], staged into a third LDS word.
 template <bool EARLY, bool DEPTH, bool COLF>
-__global__ __launch_bounds__(256) void k_composite(const Frame f, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
                                                    uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
                                                    const float4* __restrict__ col_f,
