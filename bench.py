@@ -47,7 +47,7 @@ def build_workload(name: str, lod0_override: int | None = None):
     return w, wang, cu, vp, sort
 
 
-def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None):
+def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, height_map=None):
     """Times the CPU oracle (oracle/gswt_oracle.c, OpenMP) on ONE frame of the same workload."""
     from oracle import gswt_oracle as orc
     tex, gi, li = wang.preload()
@@ -84,7 +84,7 @@ def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None):
         bg = orc.skybox_render(cam, faces, W, H)
         bgd = np.ones((H, W), np.float32)
         orc.proxy_render(orc.Proxy224.from_buffer_copy(bytes(pu)), W, H, bg, bgd, mips)
-    img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads, bg_rgba=bg, bg_depth=bgd)
+    img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads, bg_rgba=bg, bg_depth=bgd, height_map=height_map)
     dt = time.perf_counter() - t0
     return img, st, dt, n_threads
 
@@ -136,7 +136,8 @@ def main():
     from gswt_renderer_amd import _lib as L
     r.set_option(L.GSWT_OPT_TIMING, args.timing)
     wang.upload_to(r)
-    r.configure(None)
+    hmap = wang.height_map() if int(wang.user.surface_type) == 1 else None
+    r.configure(hmap)
     r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
     su = wang.scene_uniforms()
     use_dist = world > 1 or force_dist
@@ -295,7 +296,7 @@ def main():
         if use_dist:
             res["dist_check_max_abs_diff"] = float((frame - (out if world == 1 else frame)).abs().max().item())
         if world == 1 and not args.no_cpu_baseline:
-            img_cpu, st, cdt, nthr = cpu_baseline(wang, sort, cu, vp, su, W, H, passes=(faces, mips, pu) if use_passes else None)
+            img_cpu, st, cdt, nthr = cpu_baseline(wang, sort, cu, vp, su, W, H, passes=(faces, mips, pu) if use_passes else None, height_map=hmap)
             gpu_img = out.cpu().numpy()
             res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": nthr, "kind": "port",
                                    "sample": "1 frame of the same workload (oracle/gswt_oracle.c, OpenMP over 16-row bands)",

@@ -32,6 +32,27 @@ __device__ __forceinline__ float half_decode(uint32_t h)
     return u2f(s | ((e + 112u) << 23) | (f << 13));
 }
 
+// x mod w for the repeat sampler, identical to ((x % w) + w) % w in integer arithmetic but without the 64-bit
+// division sequences (5 samples x 4 wraps per splat made the HeightMap path ~3000 instructions): the quotient is
+// estimated in float (exact operands below 2^23, so it is off by at most one) and fixed up with two compares.
+__device__ __noinline__ int wrap_repeat_slow(float fx, int w)
+{
+    const long xl = (long)fx;
+    return (int)(((xl % w) + w) % w);
+}
+
+__device__ __forceinline__ int wrap_repeat(float fx, int w)
+{
+    if (fabsf(fx) < 8388608.0f && w < 8388608) {
+        const int x = (int)fx;
+        int r = x - w * (int)floorf((float)x / (float)w);
+        if (r < 0) r += w;
+        if (r >= w) r -= w;
+        return r;
+    }
+    return wrap_repeat_slow(fx, w);                 // far outside any real map: the exact 64-bit path, out of line
+}
+
 // WebGPU bilinear sample, R32Float, repeat addressing, level 0 (renderer.rs:376-388).
 __device__ __forceinline__ float sample_height(const float* __restrict__ hm, int w, int h, float u, float v)
 {
@@ -39,9 +60,8 @@ __device__ __forceinline__ float sample_height(const float* __restrict__ hm, int
     float y = v * (float)h - 0.5f;
     float fx0 = floorf(x), fy0 = floorf(y);
     float tx = x - fx0, ty = y - fy0;
-    long x0 = (long)fx0, y0 = (long)fy0;
-    long xa = ((x0 % w) + w) % w, xb = (((x0 + 1) % w) + w) % w;
-    long ya = ((y0 % h) + h) % h, yb = (((y0 + 1) % h) + h) % h;
+    const int xa = wrap_repeat(fx0, w), ya = wrap_repeat(fy0, h);
+    const int xb = xa + 1 == w ? 0 : xa + 1, yb = ya + 1 == h ? 0 : ya + 1;
     float i00 = hm[ya * w + xa], i10 = hm[ya * w + xb];
     float i01 = hm[yb * w + xa], i11 = hm[yb * w + xb];
     float i0 = i00 * (1.0f - tx) + i10 * tx;

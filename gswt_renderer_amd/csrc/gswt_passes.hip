@@ -75,15 +75,33 @@ void launch_skybox(hipStream_t s, const float* view16, float p00, float p11, int
 // ---- proxy -----------------------------------------------------------------------------------------
 
 
+// x mod w of the repeat samplers without 64-bit division (see gswt_kernels.hip): float quotient + two fix-ups
+__device__ __noinline__ int p_wrap_repeat_slow(float fx, int w)
+{
+    const long xl = (long)fx;
+    return (int)(((xl % w) + w) % w);
+}
+
+__device__ __forceinline__ int p_wrap_repeat(float fx, int w)
+{
+    if (fabsf(fx) < 8388608.0f && w < 8388608) {
+        const int x = (int)fx;
+        int r = x - w * (int)floorf((float)x / (float)w);
+        if (r < 0) r += w;
+        if (r >= w) r -= w;
+        return r;
+    }
+    return p_wrap_repeat_slow(fx, w);
+}
+
 // WebGPU bilinear, R32Float, repeat (same sampler as the splat kernel's height map)
 __device__ __forceinline__ float p_sample_height(const float* __restrict__ hm, int w, int h, float u, float v)
 {
     float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
     float fx0 = floorf(x), fy0 = floorf(y);
     float tx = x - fx0, ty = y - fy0;
-    long x0 = (long)fx0, y0 = (long)fy0;
-    long xa = ((x0 % w) + w) % w, xb = (((x0 + 1) % w) + w) % w;
-    long ya = ((y0 % h) + h) % h, yb = (((y0 + 1) % h) + h) % h;
+    const int xa = p_wrap_repeat(fx0, w), ya = p_wrap_repeat(fy0, h);
+    const int xb = xa + 1 == w ? 0 : xa + 1, yb = ya + 1 == h ? 0 : ya + 1;
     float i00 = hm[ya * w + xa], i10 = hm[ya * w + xb];
     float i01 = hm[yb * w + xa], i11 = hm[yb * w + xb];
     float i0 = i00 * (1.0f - tx) + i10 * tx;
@@ -163,9 +181,8 @@ __device__ __forceinline__ void proxy_tex_bilinear(const float4* __restrict__ lv
     const float x = u * (float)n - 0.5f, y = v * (float)n - 0.5f;
     const float fx0 = floorf(x), fy0 = floorf(y);
     const float wx = x - fx0, wy = y - fy0;
-    const long x0 = (long)fx0, y0 = (long)fy0;
-    const long xa = ((x0 % n) + n) % n, xb = (((x0 + 1) % n) + n) % n;
-    const long ya = ((y0 % n) + n) % n, yb = (((y0 + 1) % n) + n) % n;
+    const int xa = p_wrap_repeat(fx0, n), ya = p_wrap_repeat(fy0, n);
+    const int xb = xa + 1 == n ? 0 : xa + 1, yb = ya + 1 == n ? 0 : ya + 1;
     const float4 c00 = lvl[ya * n + xa], c10 = lvl[ya * n + xb], c01 = lvl[yb * n + xa], c11 = lvl[yb * n + xb];
     out[0] = (c00.x * (1.0f - wx) + c10.x * wx) * (1.0f - wy) + (c01.x * (1.0f - wx) + c11.x * wx) * wy;
     out[1] = (c00.y * (1.0f - wx) + c10.y * wx) * (1.0f - wy) + (c01.y * (1.0f - wx) + c11.y * wx) * wy;

@@ -26,6 +26,13 @@ WORKLOADS = {
                user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
                          lod_blending=True, lod_transition_width_ratio=0.05, merge_topk=100, merge_dot_threshold=0.2,
                          lod_max_dist=64.0 * 4.0)),
+    # c3 on the GUI's default surface (HeightMap, random 10x10 map resized to 1024^2, structure.rs:121-137): five bilinear
+    # height samples + frame transform per splat in k_project
+    "c3h": dict(desc="c3 on the HeightMap surface (GUI default): 33x33 map, ~10M instanced Gaussians, 1920x1080",
+                half=(16, 16), lod0=9800, n_lod=3, width=1920, height=1080,
+                user=dict(surface_type=host.SURFACE_HEIGHTMAP, height_map_scale=(1.0, 1.0, 0.25), tile_sort_type=host.SORT_GRAPH,
+                          merge_type=host.MERGE_EDGE, lod_blending=True, lod_transition_width_ratio=0.05, merge_topk=100,
+                          merge_dot_threshold=0.2, lod_max_dist=64.0 * 4.0)),
     "c5": dict(desc="129x129 map (128x128 grid nearest valid), ~100M instanced Gaussians, 3840x2160, full LOD",
                half=(64, 64), lod0=6100, n_lod=3, width=3840, height=2160,
                user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
