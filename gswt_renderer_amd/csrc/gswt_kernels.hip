@@ -234,7 +234,8 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
 // loses the dispatcher's dynamic balance (-8 % frames/s), a shared work counter serialises on one L2 address (230 us);
 // (2) culling on the host and launching over the surviving chunks only -- the 20 k empty workgroups cost nothing
 // measurable once two frames overlap (3519 vs 3517 frames/s); (3) four chunks per workgroup with all list / record
-// loads issued up front (88 VGPRs, 123 us).
+// loads issued up front (88 VGPRs, 123 us); (4) a per-chunk copy of the draw record + per-chunk cull flag to shorten the
+// scalar chain chunk table -> draw -> flag: those were L2 hits, the 5.6 MB of copies are HBM misses (106 -> 113 us).
 template <bool DEBUG, bool FULL>
 __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
