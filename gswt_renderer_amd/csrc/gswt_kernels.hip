@@ -1046,96 +1046,25 @@ __device__ unsigned long long g_stats[8];
 // alpha rides in the exponent (B = 2^(-r2 log2 e + log2 alpha): one fma + v_exp), the colour stays packed and is
 // unpacked by v_cvt_f32_ubyteN in the blend; the accumulators run in 0..255 units and are scaled once at the end.
 // COLF (debug draw modes only): colours are floats from the side buffer col_f[slot], staged into a third LDS word.
+// Lane geometry of the compositor: wave w owns the 8x8 quadrant, 16-lane group g the 4x4 sub-block.
+struct CompLane {
+    float lx, ly;                 // tile-local pixel centre of this lane
+    float xl0, xl1, xr0, xr1;     // pixel-centre ranges of the left / right halves of the wave's quadrant
+    float yt0, yt1, yb0, yb1;     // ... top / bottom halves
+    uint32_t lane, grp;
+};
+
+// bin + walk of one staged batch (n pairs in LDS) for one wave; updates the lane's (T, colour) state
 template <bool EARLY, bool DEPTH, bool COLF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
-                                                   const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
-                                                   uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
-                                                   const float4* __restrict__ col_f,
-                                                   const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
-                                                   float4* __restrict__ out, float4* __restrict__ partials,
-                                                   int n_tiles, int out_rows)
+__device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLane& g, uint32_t n, const float4* s_q0, const float4* s_q1,
+                                                   const float4* s_q2, const float4* s_bb, const float* s_dep, uint8_t* wlist,
+                                                   float dbuf, float t_eps, float& T, float& ar, float& ag, float& ab, bool& wave_live)
 {
-    __shared__ float4 s_q0[256], s_q1[256], s_bb[256];
-    __shared__ float4 s_q2[COLF ? 256 : 1];
-    __shared__ float s_dep[DEPTH ? 256 : 1];
-    __shared__ uint8_t s_list[4][4][260];         // [wave][sub-block][i] -> index of the i-th hit in the batch (+4: prefetch overrun)
-    // work item -> (tile, segment) through the table k_items left behind.  Consecutive items are dealt
-    // round-robin over the 8 XCDs by the dispatcher, which balances the skewed tile-list lengths (DESIGN.md section 6).
-    const uint32_t item = blockIdx.x;
-    const uint32_t n_items = item_base[n_tiles];
-    const uint4 it = item_tab[item];                 // (in flight together with n_items; garbage past n_items, unused)
-    if (item >= n_items) return;
-    const int tile = (int)it.x;
-    const bool multi_seg = (it.y & 1u) != 0u;
-    const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
-    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
-    const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
-    const int bx = tx * kTile, by = ty * kTile;
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const int qx = (int)(wave & 1u) * 8, qy = (int)(wave >> 1) * 8;
-    const uint32_t grp = lane >> 4, gi = lane & 15u;                 // 16-lane group = 4x4 sub-block
-    const int lxi = qx + (int)(grp & 1u) * 4 + (int)(gi & 3u), lyi = qy + (int)(grp >> 1) * 4 + (int)(gi >> 2);
-    const int px = bx + lxi, py = by + lyi;
-    const bool inside = px < f.width && py < f.height;
-    const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
-    const float fbx = (float)bx, fby = (float)by;
-    // pixel-centre ranges (tile-local) of the left/right and top/bottom halves of this wave's quadrant
-    const float xl0 = (float)qx + 0.5f, xl1 = (float)qx + 3.5f, xr0 = (float)qx + 4.5f, xr1 = (float)qx + 7.5f;
-    const float yt0 = (float)qy + 0.5f, yt1 = (float)qy + 3.5f, yb0 = (float)qy + 4.5f, yb1 = (float)qy + 7.5f;
-    uint8_t* const wlist = &s_list[wave][0][0];
-    const uint8_t* const my_list = &s_list[wave][grp][0];
-    const uint2 rg = make_uint2(it.z, it.w);         // this item's slice of the tile's pair list
-    // Transmittance doubles as the "still active" state: a lane is live while T >= t_eps.  Pixels
-    // outside the target start at T = 0 when early-out is on (never live); with t_eps = 0 they just
-    // accumulate and are never stored.
-    float T = (EARLY && !inside) ? 0.0f : 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
-    float dbuf = 1.0f;
-    if (DEPTH && inside) dbuf = bg_depth[(size_t)py * f.width + px];
-    const float t_eps = f.t_eps;
-    bool wave_live = true;
-    // Masked walk steps (past a sub-block list's end) still read a record through a stale list byte; the
-    // blend is predicated with a zero weight, and 0 * x is only harmless for finite x.  So every LDS record a
-    // stale index can name must hold finite data: zero-fill once (each lane its own entry; staging overwrites).
-    s_q0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (DEPTH) s_dep[tid] = 0.0f;
-    if (COLF) s_q2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    // Software-pipelined gather: the records of batch b+1 and the slot indices of batch b+2 are in flight
-    // while batch b is binned and walked (two dependent HBM latencies per batch otherwise sit between barriers).
-    // The loads are unconditional with clamped indices (lanes past the end re-read the last pair and never stage
-    // it): a load under a lane mask would be merged back through register copies that wait for it on the spot.
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
-    uint32_t slot_nxt = 0;
-    const uint32_t last_pair = rg.y - 1u;
-    if (rg.x < rg.y && !(f.dbg_flags & 4)) {
-        const uint32_t slot0 = vals[min(rg.x + tid, last_pair)];
-        const float4* rp = reinterpret_cast<const float4*>(recs + slot0);
-        ra = rp[0]; rb = rp[1]; rc = rp[2];
-        if (COLF) rd = col_f[slot0];
-        slot_nxt = vals[min(rg.x + 256u + tid, last_pair)];
-    }
-    for (uint32_t base = rg.x; base < rg.y; base += 256u) {
-        const uint32_t n = min(256u, rg.y - base);
-        if (f.dbg_flags & 4) break;                       // ablation: no staging at all
-        if (tid < n) {
-            // F3: per-(splat, tile) constants
-            const float ox = ra.z - fbx, oy = rb.z - fby;
-            const float nku = -fmaf(ra.x, ox, ra.y * oy);
-            const float nkv = -fmaf(rb.x, ox, rb.y * oy);
-            s_q0[tid] = make_float4(ra.x, ra.y, nku, __builtin_amdgcn_logf(ra.w));   // v_log_f32 = log2; log2(0) = -inf -> B = 0
-            s_q1[tid] = make_float4(rb.x, rb.y, nkv, rc.x);
-            s_bb[tid] = make_float4(ox - rc.y, ox + rc.y, oy - rc.z, oy + rc.z);     // pixel bbox, tile-local
-            if (DEPTH) s_dep[tid] = rb.w;
-            if (COLF) s_q2[tid] = rd;
-        }
-        __syncthreads();
-        {
-            const float4* rp = reinterpret_cast<const float4*>(recs + slot_nxt);
-            ra = rp[0]; rb = rp[1]; rc = rp[2];
-            if (COLF) rd = col_f[slot_nxt];
-            slot_nxt = vals[min(base + 512u + tid, last_pair)];
-        }
-        if (wave_live && !(f.dbg_flags & 2)) {             // ablation bit 2: stage only
+    const uint32_t lane = g.lane, grp = g.grp;
+    const float lx = g.lx, ly = g.ly;
+    const float xl0 = g.xl0, xl1 = g.xl1, xr0 = g.xr0, xr1 = g.xr1, yt0 = g.yt0, yt1 = g.yt1, yb0 = g.yb0, yb1 = g.yb1;
+    const uint8_t* const my_list = wlist + grp * 260u;
+             // ablation bit 2: stage only
             // bin: append this batch's hits to the four sub-block lists (list order preserved)
             uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
 #pragma unroll
@@ -1209,6 +1138,106 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #undef GSWT_STEP
             if (EARLY && __ballot(T >= t_eps) == 0ull) wave_live = false;   // whole wave saturated
         }
+
+// Measured and dropped: the same compositor as a PERSISTENT grid (one workgroup walks many items, the gathers of the next
+// item's first batch in flight during the current item's walk; items dealt by weight class, boustrophedon, so that the
+// busiest workgroup is 3 % above the mean).  Bit-identical output, 142 us against 114 us: the time goes with the number
+// of resident workgroups (2 / 4 / 6 per CU: 262 / 167 / 143 us), i.e. the kernel is bound by the walk's per-wave
+// progress (VALU 50 us + LDS 53 us + SALU 42 us of issue that do not overlap perfectly, two barriers per batch), and
+// the gather latency was already covered by the other workgroups of the CU.  "stage-only 58 us" in the ablation is
+// what staging costs with nothing to hide behind, not a serial share of the full kernel.
+
+template <bool EARLY, bool DEPTH, bool COLF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
+                                                   const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
+                                                   uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
+                                                   const float4* __restrict__ col_f,
+                                                   const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
+                                                   float4* __restrict__ out, float4* __restrict__ partials,
+                                                   int n_tiles, int out_rows)
+{
+    __shared__ float4 s_q0[256], s_q1[256], s_bb[256];
+    __shared__ float4 s_q2[COLF ? 256 : 1];
+    __shared__ float s_dep[DEPTH ? 256 : 1];
+    __shared__ uint8_t s_list[4][4][260];         // [wave][sub-block][i] -> index of the i-th hit in the batch (+4: prefetch overrun)
+    // work item -> (tile, segment) through the table k_items left behind.  Consecutive items are dealt
+    // round-robin over the 8 XCDs by the dispatcher, which balances the skewed tile-list lengths (DESIGN.md section 6).
+    const uint32_t item = blockIdx.x;
+    const uint32_t n_items = item_base[n_tiles];
+    const uint4 it = item_tab[item];                 // (in flight together with n_items; garbage past n_items, unused)
+    if (item >= n_items) return;
+    const int tile = (int)it.x;
+    const bool multi_seg = (it.y & 1u) != 0u;
+    const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
+    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
+    const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
+    const int bx = tx * kTile, by = ty * kTile;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const int qx = (int)(wave & 1u) * 8, qy = (int)(wave >> 1) * 8;
+    const uint32_t grp = lane >> 4, gi = lane & 15u;                 // 16-lane group = 4x4 sub-block
+    const int lxi = qx + (int)(grp & 1u) * 4 + (int)(gi & 3u), lyi = qy + (int)(grp >> 1) * 4 + (int)(gi >> 2);
+    const int px = bx + lxi, py = by + lyi;
+    const bool inside = px < f.width && py < f.height;
+    const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
+    const float fbx = (float)bx, fby = (float)by;
+    // pixel-centre ranges (tile-local) of the left/right and top/bottom halves of this wave's quadrant
+    const float xl0 = (float)qx + 0.5f, xl1 = (float)qx + 3.5f, xr0 = (float)qx + 4.5f, xr1 = (float)qx + 7.5f;
+    const float yt0 = (float)qy + 0.5f, yt1 = (float)qy + 3.5f, yb0 = (float)qy + 4.5f, yb1 = (float)qy + 7.5f;
+    uint8_t* const wlist = &s_list[wave][0][0];
+    const CompLane cl = {lx, ly, xl0, xl1, xr0, xr1, yt0, yt1, yb0, yb1, lane, grp};
+    const uint2 rg = make_uint2(it.z, it.w);         // this item's slice of the tile's pair list
+    // Transmittance doubles as the "still active" state: a lane is live while T >= t_eps.  Pixels
+    // outside the target start at T = 0 when early-out is on (never live); with t_eps = 0 they just
+    // accumulate and are never stored.
+    float T = (EARLY && !inside) ? 0.0f : 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    float dbuf = 1.0f;
+    if (DEPTH && inside) dbuf = bg_depth[(size_t)py * f.width + px];
+    const float t_eps = f.t_eps;
+    bool wave_live = true;
+    // Masked walk steps (past a sub-block list's end) still read a record through a stale list byte; the
+    // blend is predicated with a zero weight, and 0 * x is only harmless for finite x.  So every LDS record a
+    // stale index can name must hold finite data: zero-fill once (each lane its own entry; staging overwrites).
+    s_q0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DEPTH) s_dep[tid] = 0.0f;
+    if (COLF) s_q2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Software-pipelined gather: the records of batch b+1 and the slot indices of batch b+2 are in flight
+    // while batch b is binned and walked (two dependent HBM latencies per batch otherwise sit between barriers).
+    // The loads are unconditional with clamped indices (lanes past the end re-read the last pair and never stage
+    // it): a load under a lane mask would be merged back through register copies that wait for it on the spot.
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
+    uint32_t slot_nxt = 0;
+    const uint32_t last_pair = rg.y - 1u;
+    if (rg.x < rg.y && !(f.dbg_flags & 4)) {
+        const uint32_t slot0 = vals[min(rg.x + tid, last_pair)];
+        const float4* rp = reinterpret_cast<const float4*>(recs + slot0);
+        ra = rp[0]; rb = rp[1]; rc = rp[2];
+        if (COLF) rd = col_f[slot0];
+        slot_nxt = vals[min(rg.x + 256u + tid, last_pair)];
+    }
+    for (uint32_t base = rg.x; base < rg.y; base += 256u) {
+        const uint32_t n = min(256u, rg.y - base);
+        if (f.dbg_flags & 4) break;                       // ablation: no staging at all
+        if (tid < n) {
+            // F3: per-(splat, tile) constants
+            const float ox = ra.z - fbx, oy = rb.z - fby;
+            const float nku = -fmaf(ra.x, ox, ra.y * oy);
+            const float nkv = -fmaf(rb.x, ox, rb.y * oy);
+            s_q0[tid] = make_float4(ra.x, ra.y, nku, __builtin_amdgcn_logf(ra.w));   // v_log_f32 = log2; log2(0) = -inf -> B = 0
+            s_q1[tid] = make_float4(rb.x, rb.y, nkv, rc.x);
+            s_bb[tid] = make_float4(ox - rc.y, ox + rc.y, oy - rc.z, oy + rc.z);     // pixel bbox, tile-local
+            if (DEPTH) s_dep[tid] = rb.w;
+            if (COLF) s_q2[tid] = rd;
+        }
+        __syncthreads();
+        {
+            const float4* rp = reinterpret_cast<const float4*>(recs + slot_nxt);
+            ra = rp[0]; rb = rp[1]; rc = rp[2];
+            if (COLF) rd = col_f[slot_nxt];
+            slot_nxt = vals[min(base + 512u + tid, last_pair)];
+        }
+        if (wave_live && !(f.dbg_flags & 2))               // ablation bit 2: stage only
+            composite_bin_walk<EARLY, DEPTH, COLF>(f, cl, n, s_q0, s_q1, s_q2, s_bb, s_dep, wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
         if (EARLY) { if (__syncthreads_and(wave_live ? 0 : 1)) break; }
         else __syncthreads();
     }
