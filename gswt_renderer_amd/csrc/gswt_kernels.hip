@@ -1049,95 +1049,117 @@ __device__ unsigned long long g_stats[8];
 // Lane geometry of the compositor: wave w owns the 8x8 quadrant, 16-lane group g the 4x4 sub-block.
 struct CompLane {
     float lx, ly;                 // tile-local pixel centre of this lane
-    float xl0, xl1, xr0, xr1;     // pixel-centre ranges of the left / right halves of the wave's quadrant
-    float yt0, yt1, yb0, yb1;     // ... top / bottom halves
+    float y0, y1;                 // pixel-centre range (tile-local) of the wave's 16 x 4 strip
     uint32_t lane, grp;
 };
 
-// bin + walk of one staged batch (n pairs in LDS) for one wave; updates the lane's (T, colour) state
+constexpr uint32_t kListStride = 264u;     // u16 entries per sub-block list: 256 hits + padding to an even count + 2 of prefetch overrun
+constexpr uint32_t kNullRec = 256u;        // LDS record no pixel is ever inside (list padding)
+
+// bin + walk of one staged batch (n pairs in LDS) for one wave; updates the lane's (T, colour) state.
+// Wave w owns the 16 x 4 pixel strip of rows 4w .. 4w+3, its 16-lane group g the 4 x 4 sub-block of columns 4g .. 4g+3
+// (rows, not quadrants: the splat density varies down the screen, so the four lists of a strip are alike and the
+// longest one -- which paces the wave -- is close to their mean: 1.98 M wave-steps against 2.28 M on the c3 frame).
+// List entries are LDS byte offsets of the records (u16), padded to an even length with the offset of a null record
+// whose r^2 is +inf: the walk needs neither a shift nor an `i < n` test nor a mid-pair exit.
 template <bool EARLY, bool DEPTH, bool COLF>
 __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLane& g, uint32_t n, const float4* s_q0, const float4* s_q1,
-                                                   const float4* s_q2, const float4* s_bb, const float* s_dep, uint8_t* wlist,
+                                                   const float4* s_q2, const float4* s_bb, const float* s_dep, uint16_t* wlist,
                                                    float dbuf, float t_eps, float& T, float& ar, float& ag, float& ab, bool& wave_live)
 {
     const uint32_t lane = g.lane, grp = g.grp;
     const float lx = g.lx, ly = g.ly;
-    const float xl0 = g.xl0, xl1 = g.xl1, xr0 = g.xr0, xr1 = g.xr1, yt0 = g.yt0, yt1 = g.yt1, yb0 = g.yb0, yb1 = g.yb1;
-    const uint8_t* const my_list = wlist + grp * 260u;
-             // ablation bit 2: stage only
-            // bin: append this batch's hits to the four sub-block lists (list order preserved)
-            uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+    uint16_t* const my_list = wlist + grp * kListStride;
+    // bin: append this batch's hits to the four sub-block lists (list order preserved)
+    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const uint32_t idx = (uint32_t)c * 64u + lane;
-                bool hl = false, hr = false, ht = false, hb = false;
-                if (idx < n) {
-                    const float4 bb = s_bb[idx];                     // (x_lo, x_hi, y_lo, y_hi) of the pixel-centre box
-                    hl = bb.y >= xl0 && bb.x <= xl1; hr = bb.y >= xr0 && bb.x <= xr1;
-                    ht = bb.w >= yt0 && bb.z <= yt1; hb = bb.w >= yb0 && bb.z <= yb1;
-                }
-                const bool h0 = hl && ht, h1 = hr && ht, h2 = hl && hb, h3 = hr && hb;
-                const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-#define GSWT_APPEND(H, M, CNT, G)                                                                                         \
-                if (M) {                                                                                                    \
-                    if (H) wlist[(G) * 260u + (CNT) + __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))] = (uint8_t)idx; \
-                    CNT += (uint32_t)__popcll(M);                                                                           \
-                }
-                GSWT_APPEND(h0, m0, cnt0, 0u) GSWT_APPEND(h1, m1, cnt1, 1u) GSWT_APPEND(h2, m2, cnt2, 2u) GSWT_APPEND(h3, m3, cnt3, 3u)
-#undef GSWT_APPEND
-            }
-            const uint32_t n_mine = grp == 0u ? cnt0 : grp == 1u ? cnt1 : grp == 2u ? cnt2 : cnt3;
-            const uint32_t n_max = max(max(cnt0, cnt1), max(cnt2, cnt3));
-            GSWT_STAT_BATCH(n_max, cnt0, cnt1, cnt2, cnt3)
-            // walk: one splat per 16-lane group per step.  Two-deep software pipeline, unrolled x2 so the
-            // two record register sets (A, B) never need copying: the list byte is fetched two steps
-            // ahead, the record one step ahead (entries past a list's end are stale but in-range; the
-            // step is masked by `i < n_mine`).
-#define GSWT_STEP(Q0, Q1, Q2, DV, I)                                                                    \
-            {                                                                                           \
-                const float pu_y = fmaf(Q0.y, ly, Q0.z);                                                \
-                const float pv_y = fmaf(Q1.y, ly, Q1.z);                                                \
-                const float ppx = fmaf(Q0.x, lx, pu_y);                                                 \
-                const float ppy = fmaf(Q1.x, lx, pv_y);                                                 \
-                const float r2 = fmaf(ppy, ppy, ppx * ppx);                                             \
-                bool cover = ((I) < n_mine) && r2 <= 4.0f;                                              \
-                if (DEPTH) cover = cover && DV < dbuf;                                                  \
-                if (EARLY) cover = cover && T >= t_eps;                                                 \
-                GSWT_STAT_STEP(cover)                                                                   \
-                if (__ballot(cover) != 0ull) { /* wave-uniform skip; lanes are predicated, not masked */ \
-                    const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q0.w));       \
-                    const float Bv = cover ? e : 0.0f;                                                  \
-                    const float wgt = T * Bv;                                                           \
-                    const uint32_t cw = __float_as_uint(Q1.w);                                          \
-                    ar = fmaf(wgt, COLF ? Q2.x : (float)(cw & 0xFFu), ar);                              \
-                    ag = fmaf(wgt, COLF ? Q2.y : (float)((cw >> 8) & 0xFFu), ag);                       \
-                    ab = fmaf(wgt, COLF ? Q2.z : (float)((cw >> 16) & 0xFFu), ab);                      \
-                    T = T - wgt;                                                                        \
-                }                                                                                       \
-            }
-            if (!(f.dbg_flags & 1) && n_max) {
-                uint32_t kA = my_list[0], kB = my_list[1];
-                float4 a0 = s_q0[kA], a1 = s_q1[kA];
-                float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a2;
-                if (COLF) a2 = s_q2[kA];
-                float da = DEPTH ? s_dep[kA] : 0.0f, db = 0.0f;
-                for (uint32_t i = 0; i < n_max; i += 2u) {
-                    const float4 b0 = s_q0[kB], b1 = s_q1[kB];                     // record of step i+1
-                    if (COLF) b2 = s_q2[kB];
-                    if (DEPTH) db = s_dep[kB];
-                    kA = my_list[i + 2u];                                          // index of step i+2
-                    GSWT_STEP(a0, a1, a2, da, i)
-                    if (i + 1u >= n_max) break;
-                    a0 = s_q0[kA]; a1 = s_q1[kA];                                  // record of step i+2
-                    if (COLF) a2 = s_q2[kA];
-                    if (DEPTH) da = s_dep[kA];
-                    kB = my_list[i + 3u];                                          // index of step i+3
-                    GSWT_STEP(b0, b1, b2, db, i + 1u)
-                }
-            }
-#undef GSWT_STEP
-            if (EARLY && __ballot(T >= t_eps) == 0ull) wave_live = false;   // whole wave saturated
+    for (int c = 0; c < 4; c++) {
+        const uint32_t idx = (uint32_t)c * 64u + lane;
+        bool h0 = false, h1 = false, h2 = false, h3 = false;
+        if (idx < n) {
+            const float4 bb = s_bb[idx];                     // (x_lo, x_hi, y_lo, y_hi) of the pixel-centre box
+            const bool hy = bb.w >= g.y0 && bb.z <= g.y1;
+            h0 = hy && bb.x <= 3.5f;                         // columns 0..3: centres 0.5 .. 3.5 (x_hi >= 0.5 always holds inside the tile)
+            h1 = hy && bb.y >= 4.5f && bb.x <= 7.5f;
+            h2 = hy && bb.y >= 8.5f && bb.x <= 11.5f;
+            h3 = hy && bb.y >= 12.5f;
+            h0 = h0 && bb.y >= 0.5f; h3 = h3 && bb.x <= 15.5f;
         }
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+#define GSWT_APPEND(H, M, CNT, G)                                                                                         \
+        if (M) {                                                                                                            \
+            if (H) wlist[(G) * kListStride + (CNT) + __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))] = (uint16_t)(idx * 16u); \
+            CNT += (uint32_t)__popcll(M);                                                                                   \
+        }
+        GSWT_APPEND(h0, m0, cnt0, 0u) GSWT_APPEND(h1, m1, cnt1, 1u) GSWT_APPEND(h2, m2, cnt2, 2u) GSWT_APPEND(h3, m3, cnt3, 3u)
+#undef GSWT_APPEND
+    }
+    const uint32_t n_mine = grp == 0u ? cnt0 : grp == 1u ? cnt1 : grp == 2u ? cnt2 : cnt3;
+    const uint32_t n_max = max(max(cnt0, cnt1), max(cnt2, cnt3));
+    GSWT_STAT_BATCH(n_max, cnt0, cnt1, cnt2, cnt3)
+    if ((f.dbg_flags & 1) || n_max == 0u) return;
+    // pad this group's list with the null record up to the wave's even step count (+2: the walk reads two entries ahead)
+    const uint32_t n_steps = (n_max + 1u) & ~1u;
+    for (uint32_t p = n_mine + (lane & 15u); p < n_steps + 2u; p += 16u) my_list[p] = (uint16_t)(kNullRec * 16u);
+    // walk: one splat per 16-lane group per step.  Two-deep software pipeline, unrolled x2 so the two record register
+    // sets (A, B) never need copying: the list entry is fetched two steps ahead, the record one step ahead.
+    const char* const q0b = reinterpret_cast<const char*>(s_q0);
+    const char* const q1b = reinterpret_cast<const char*>(s_q1);
+    const char* const q2b = reinterpret_cast<const char*>(s_q2);
+    const char* const dpb = reinterpret_cast<const char*>(s_dep);
+#define GSWT_REC0(O) (*reinterpret_cast<const float4*>(q0b + (O)))
+#define GSWT_REC1(O) (*reinterpret_cast<const float4*>(q1b + (O)))
+#define GSWT_REC2(O) (*reinterpret_cast<const float4*>(q2b + (O)))
+#define GSWT_RECD(O) (*reinterpret_cast<const float*>(dpb + ((O) >> 2)))
+#define GSWT_STEP(Q0, Q1, Q2, DV)                                                                   \
+    {                                                                                               \
+        const float pu_y = fmaf(Q0.y, ly, Q0.z);                                                    \
+        const float pv_y = fmaf(Q1.y, ly, Q1.z);                                                    \
+        const float ppx = fmaf(Q0.x, lx, pu_y);                                                     \
+        const float ppy = fmaf(Q1.x, lx, pv_y);                                                     \
+        const float r2 = fmaf(ppy, ppy, ppx * ppx);                                                 \
+        bool cover = r2 <= 4.0f;                                                                    \
+        if (DEPTH) cover = cover && DV < dbuf;                                                      \
+        GSWT_STAT_STEP(cover)                                                                       \
+        if (__ballot(cover) != 0ull) { /* wave-uniform skip; lanes are predicated, not masked */    \
+            const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q0.w));           \
+            const float Bv = cover ? e : 0.0f;                                                      \
+            const float wgt = T * Bv;                                                               \
+            const uint32_t cw = __float_as_uint(Q1.w);                                              \
+            ar = fmaf(wgt, COLF ? Q2.x : (float)(cw & 0xFFu), ar);                                  \
+            ag = fmaf(wgt, COLF ? Q2.y : (float)((cw >> 8) & 0xFFu), ag);                           \
+            ab = fmaf(wgt, COLF ? Q2.z : (float)((cw >> 16) & 0xFFu), ab);                          \
+            T = T - wgt;                                                                            \
+        }                                                                                           \
+    }
+    {
+        uint32_t kA = my_list[0], kB = my_list[1];
+        float4 a0 = GSWT_REC0(kA), a1 = GSWT_REC1(kA);
+        float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a2;
+        if (COLF) a2 = GSWT_REC2(kA);
+        float da = DEPTH ? GSWT_RECD(kA) : 0.0f, db = 0.0f;
+        for (uint32_t i = 0; i < n_steps; i += 2u) {
+            const float4 b0 = GSWT_REC0(kB), b1 = GSWT_REC1(kB);           // record of step i+1
+            if (COLF) b2 = GSWT_REC2(kB);
+            if (DEPTH) db = GSWT_RECD(kB);
+            kA = my_list[i + 2u];                                          // entry of step i+2
+            GSWT_STEP(a0, a1, a2, da)
+            a0 = GSWT_REC0(kA); a1 = GSWT_REC1(kA);                        // record of step i+2
+            if (COLF) a2 = GSWT_REC2(kA);
+            if (DEPTH) da = GSWT_RECD(kA);
+            kB = my_list[i + 3u];                                          // entry of step i+3
+            GSWT_STEP(b0, b1, b2, db)
+        }
+    }
+#undef GSWT_STEP
+#undef GSWT_REC0
+#undef GSWT_REC1
+#undef GSWT_REC2
+#undef GSWT_RECD
+    // Saturated pixels keep accumulating weights below t_eps (the oracle has no cut at all); the early-out is per wave
+    // and per batch: once no pixel of the strip has T >= t_eps the wave stops binning and walking.
+    if (EARLY && __ballot(T >= t_eps) == 0ull) wave_live = false;
+}
 
 // Measured and dropped: the same compositor as a PERSISTENT grid (one workgroup walks many items, the gathers of the next
 // item's first batch in flight during the current item's walk; items dealt by weight class, boustrophedon, so that the
@@ -1156,10 +1178,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                    float4* __restrict__ out, float4* __restrict__ partials,
                                                    int n_tiles, int out_rows)
 {
-    __shared__ float4 s_q0[256], s_q1[256], s_bb[256];
-    __shared__ float4 s_q2[COLF ? 256 : 1];
-    __shared__ float s_dep[DEPTH ? 256 : 1];
-    __shared__ uint8_t s_list[4][4][260];         // [wave][sub-block][i] -> index of the i-th hit in the batch (+4: prefetch overrun)
+    __shared__ float4 s_q0[257], s_q1[257], s_bb[256];          // [256] = the null record (list padding)
+    __shared__ float4 s_q2[COLF ? 257 : 1];
+    __shared__ float s_dep[DEPTH ? 257 : 1];
+    __shared__ uint16_t s_list[4][4][kListStride];     // [wave][sub-block][i] -> LDS byte offset of the i-th hit's record
     // work item -> (tile, segment) through the table k_items left behind.  Consecutive items are dealt
     // round-robin over the 8 XCDs by the dispatcher, which balances the skewed tile-list lengths.
     const uint32_t item = blockIdx.x;
@@ -1173,18 +1195,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
     const int bx = tx * kTile, by = ty * kTile;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const int qx = (int)(wave & 1u) * 8, qy = (int)(wave >> 1) * 8;
-    const uint32_t grp = lane >> 4, gi = lane & 15u;                 // 16-lane group = 4x4 sub-block
-    const int lxi = qx + (int)(grp & 1u) * 4 + (int)(gi & 3u), lyi = qy + (int)(grp >> 1) * 4 + (int)(gi >> 2);
+    const uint32_t grp = lane >> 4, gi = lane & 15u;                 // wave = 16 x 4 strip, 16-lane group = 4 x 4 sub-block
+    const int lxi = (int)grp * 4 + (int)(gi & 3u), lyi = (int)wave * 4 + (int)(gi >> 2);
     const int px = bx + lxi, py = by + lyi;
     const bool inside = px < f.width && py < f.height;
     const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
     const float fbx = (float)bx, fby = (float)by;
-    // pixel-centre ranges (tile-local) of the left/right and top/bottom halves of this wave's quadrant
-    const float xl0 = (float)qx + 0.5f, xl1 = (float)qx + 3.5f, xr0 = (float)qx + 4.5f, xr1 = (float)qx + 7.5f;
-    const float yt0 = (float)qy + 0.5f, yt1 = (float)qy + 3.5f, yb0 = (float)qy + 4.5f, yb1 = (float)qy + 7.5f;
-    uint8_t* const wlist = &s_list[wave][0][0];
-    const CompLane cl = {lx, ly, xl0, xl1, xr0, xr1, yt0, yt1, yb0, yb1, lane, grp};
+    uint16_t* const wlist = &s_list[wave][0][0];
+    const CompLane cl = {lx, ly, (float)(wave * 4u) + 0.5f, (float)(wave * 4u) + 3.5f, lane, grp};
     const uint2 rg = make_uint2(it.z, it.w);         // this item's slice of the tile's pair list
     // Transmittance doubles as the "still active" state: a lane is live while T >= t_eps.  Pixels
     // outside the target start at T = 0 when early-out is on (never live); with t_eps = 0 they just
@@ -1194,13 +1212,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (DEPTH && inside) dbuf = bg_depth[(size_t)py * f.width + px];
     const float t_eps = f.t_eps;
     bool wave_live = true;
-    // Masked walk steps (past a sub-block list's end) still read a record through a stale list byte; the
-    // blend is predicated with a zero weight, and 0 * x is only harmless for finite x.  So every LDS record a
-    // stale index can name must hold finite data: zero-fill once (each lane its own entry; staging overwrites).
-    s_q0[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s_q1[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (DEPTH) s_dep[tid] = 0.0f;
-    if (COLF) s_q2[tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the null record: p.x = +inf for every pixel (0 * l + inf), so r^2 = +inf and no pixel is ever inside
+    if (tid == 0) {
+        s_q0[kNullRec] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
+        s_q1[kNullRec] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DEPTH) s_dep[kNullRec] = 0.0f;
+        if (COLF) s_q2[kNullRec] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     // Software-pipelined gather: the records of batch b+1 and the slot indices of batch b+2 are in flight
     // while batch b is binned and walked (two dependent HBM latencies per batch otherwise sit between barriers).
     // The loads are unconditional with clamped indices (lanes past the end re-read the last pair and never stage
@@ -1275,8 +1293,8 @@ __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* 
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t grp = lane >> 4, gi = lane & 15u;      // same lane -> pixel map as k_composite
-    const int lxi = (int)(wave & 1u) * 8 + (int)(grp & 1u) * 4 + (int)(gi & 3u);
-    const int lyi = (int)(wave >> 1) * 8 + (int)(grp >> 1) * 4 + (int)(gi >> 2);
+    const int lxi = (int)grp * 4 + (int)(gi & 3u);
+    const int lyi = (int)wave * 4 + (int)(gi >> 2);
     const int px = tx * kTile + lxi, py = ty * kTile + lyi;
     if (px >= f.width || py >= f.height) return;
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
