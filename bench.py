@@ -265,7 +265,7 @@ def main():
         # WRITE_SIZE, separate passes; profiles/): raw counter bytes.  MI355X_MICROARCH's x2 rule is for wide coalesced
         # streams; these reads are 48-B gathers (uncalibrated), so the raw sum is reported and the x2 figure kept beside it.
         traffic, traffic_note = None, "no PMC summary for this workload under profiles/"
-        pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload}_s2.json")
+        pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload}.json")
         if world == 1 and os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
