@@ -4,9 +4,9 @@
 A "step" is one frame: gswt_render over the resident draw list of the workload (Wang-tile
 instancing -> projection -> pair emit -> tile sort -> compositing), inputs already in HBM.
 N=1 renders the whole frame on one GPU.  N>1 (launched by torch.distributed.run, one rank per
-GPU) shards the frame by interleaved 16-px screen-tile rows, every rank renders its rows and the
-final framebuffer is all-gathered over RCCL (torch.distributed backend "nccl") and de-interleaved
-on the device; total work is fixed, so scaling is "strong".
+GPU) shards the frame by contiguous bands of 16-px screen-tile columns: every rank projects only the draws that can
+reach its band, composites its band, and the final framebuffer is all-gathered over RCCL (torch.distributed backend
+"nccl") and re-assembled on the device; total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0) with `roofline` (composite kernel, algorithmic bytes / hipEvent
 time on the kernel's own stream) and, at N=1, `cpu_baseline` (the CPU oracle timed on the host
@@ -141,13 +141,14 @@ def main():
     r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
     su = wang.scene_uniforms()
     use_dist = world > 1 or force_dist
-    shard = (rank, world) if world > 1 else (0, 1)
-    rows = r.shard_rows_padded(H, world) if world > 1 else H
+    shard = (rank, world, "cols") if world > 1 else (0, 1)
+    rows = H
+    band_w = r.shard_cols_padded(W, world) if world > 1 else W
     # two frames in flight (gswt_render_async / gswt_render_wait): frame i+1 is queued on the stream while
     # frame i executes, so the host never idles the GPU between frames; frames alternate output buffers
-    outs = [torch.empty((rows, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    outs = [torch.empty((rows, band_w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
     out = outs[0]
-    gathered = torch.empty((world * rows, W, 4), dtype=torch.float32, device=dev) if use_dist else None
+    gathered = torch.empty((world * rows, band_w, 4), dtype=torch.float32, device=dev) if use_dist else None
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if use_dist else None
 
     use_passes = args.passes == 1 or (args.passes < 0 and args.workload == "c5")
@@ -210,7 +211,7 @@ def main():
             r.render_fence(ticket)
             with torch.cuda.stream(stream):
                 dist.all_gather_into_tensor(gathered, o)
-                r.unshard(gathered.data_ptr(), W, H, world, frame.data_ptr())
+                r.unshard_mode(gathered.data_ptr(), W, H, world, "cols", frame.data_ptr())
         r.render_wait(ticket)
         t = r.timings()
         comp_ms.append(t["ms_composite_kernel"]); total_ms.append(t["ms_total"]); pairs.append(t["n_pairs"])
@@ -258,7 +259,7 @@ def main():
         fps = args.steps / dt
         P = float(np.mean(pairs))
         comp = float(np.mean(comp_ms)) * 1e-3
-        n_px = (rows if world > 1 else H) * W
+        n_px = rows * band_w
         algo_bytes = 52.0 * P + (36.0 if use_passes else 16.0) * n_px   # (4 + 48) B per pair + 16 B per pixel (+ 20 B read with bg colour + depth)
         achieved = algo_bytes / comp / 1e9 if comp > 0 else 0.0
         # HBM bytes per launch of k_composite from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
@@ -284,7 +285,7 @@ def main():
                        "width": W, "height": H, "n_draws": int(last["n_draws"]), "n_instanced": int(last["n_instanced"]),
                        "n_visible": int(last["n_visible"]), "n_pairs": int(last["n_pairs"]), "order": "reference",
                        "transmittance_eps": args.t_eps, "skybox_proxy_passes": bool(use_passes),
-                       "parallelism": f"screen-tile-rows x{world} + RCCL all-gather" if world > 1 else "single GPU"},
+                       "parallelism": f"screen-tile-column bands x{world} (projection culled per band) + RCCL all-gather" if world > 1 else "single GPU"},
             "stage_ms": {k: float(last[k]) for k in ("ms_project", "ms_emit", "ms_sort", "ms_ranges", "ms_composite", "ms_composite_kernel", "ms_total")},
             "frames_in_flight": 2,
             "roofline": {"bound": "hbm", "kernel": "k_composite", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -24,6 +24,8 @@ GSWT_OPT_DEBUG_VARYINGS = 2
 GSWT_OPT_SEGMENT = 3
 GSWT_OPT_DEBUG_FLAGS = 4
 GSWT_OPT_TIMING = 5
+GSWT_SHARD_ROWS = 0
+GSWT_SHARD_COLUMNS = 1
 
 
 class CameraUniforms(C.Structure):
@@ -74,7 +76,7 @@ class MergeMember(C.Structure):
 class RenderConfig(C.Structure):
     _fields_ = [("culling_dist", C.c_float), ("lod_enable_mask", C.c_uint32), ("order_mode", C.c_int32),
                 ("transmittance_eps", C.c_float), ("shard_index", C.c_int32), ("shard_count", C.c_int32),
-                ("_pad", C.c_uint32 * 2)]
+                ("shard_mode", C.c_int32), ("_pad", C.c_uint32)]
 
 
 class Timings(C.Structure):
@@ -121,6 +123,8 @@ SYMBOLS = {
     "gswt_shard_rows": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "gswt_shard_rows_padded": (C.c_int, [C.c_int, C.c_int]),
     "gswt_unshard": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "gswt_unshard_mode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "gswt_shard_cols_padded": (C.c_int, [C.c_int, C.c_int]),
     "gswt_synchronize": (C.c_int, [_P]),
     "gswt_last_timings": (C.c_int, [_P, _P]),
     "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -22,7 +22,9 @@
 #include <vector>
 
 namespace gswt {
-void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t);
+void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, const DrawBounds*, uint32_t*, uint32_t, uint32_t*, uint32_t);
+void launch_draw_bounds(hipStream_t, const Frame&, const DrawDev*, uint32_t, const uint2*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
+                        const uint4*, DrawBounds*);
 size_t radix_ws_words(uint32_t, int);
 void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long long*, const uint2*, const Rec*, const uint32_t*,
                        uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
@@ -39,7 +41,7 @@ int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t);
-void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int);
+void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
 void launch_proxy(hipStream_t, const ProxyArgs&, const float*, const float4*, float4*, float*);
 void launch_fill_f32(hipStream_t, float*, size_t, float);
@@ -149,6 +151,9 @@ struct gswt_ctx {
     DevBuf<MergeSeg> mg_segs;
     DevBuf<MergeGroup> mg_groups;
     DevBuf<uint32_t> mg_ws;
+    DevBuf<DrawBounds> draw_bounds;        // per draw, for the band cull of column-sharded frames
+    bool bounds_valid = false;             // false after every gswt_set_draws*
+    uint32_t bounds_key[6] = {};           // map_half_wh, center_coord, tile_width bits, surface_type the merged offsets were formed with
     uint32_t n_draws = 0, n_chunks = 0;
     uint64_t n_entries = 0;
     bool draws_ready = false;
@@ -240,7 +245,7 @@ void gswt_destroy(gswt_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     sync_all(c);
-    c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release();
+    c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release(); c->draw_bounds.release();
     c->merged_list.release(); c->merged_map.release(); c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release();
     c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
     for (auto& sl : c->slots) {
@@ -431,6 +436,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     }
     c->n_draws = (uint32_t)n_draws;
     c->n_chunks = (uint32_t)chunks.size();
+    c->bounds_valid = false;
     c->n_entries = entries;
     c->draws_ready = true;       // the per-frame buffers are sized by enqueue_frame, per slot
     return GSWT_OK;
@@ -558,6 +564,13 @@ int gswt_shard_rows_padded(int height, int shard_count)
     return ((tiles_y + sc - 1) / sc) * kTile;
 }
 
+int gswt_shard_cols_padded(int width, int shard_count)
+{
+    int tiles_x = (width + kTile - 1) / kTile;
+    int sc = shard_count <= 1 ? 1 : shard_count;
+    return ((tiles_x + sc - 1) / sc) * kTile;
+}
+
 int gswt_shard_rows(int height, int shard_index, int shard_count)
 {
     int sc = shard_count <= 1 ? 1 : shard_count;
@@ -590,6 +603,7 @@ static int validate_frame(gswt_ctx* c, const gswt_camera_uniforms* cam, const gs
         return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: unknown order mode %d", cfg->order_mode);
     const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
     if (sc > 1 && (cfg->shard_index < 0 || cfg->shard_index >= sc)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: bad shard index");
+    if (cfg->shard_mode != GSWT_SHARD_ROWS && cfg->shard_mode != GSWT_SHARD_COLUMNS) return fail(c, GSWT_ERR_BAD_ARG, "gswt_render: unknown shard mode %d", cfg->shard_mode);
     return GSWT_OK;
 }
 
@@ -642,21 +656,34 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     f.culling_dist = cfg->culling_dist; f.lod_enable_mask = cfg->lod_enable_mask; f.t_eps = cfg->transmittance_eps;
     f.has_depth = a.d_bgd ? 1 : 0;
     f.width = width; f.height = height;
-    f.tiles_x = (width + kTile - 1) / kTile; f.tiles_y = (height + kTile - 1) / kTile;
-    f.shard_index = sc > 1 ? cfg->shard_index : 0; f.shard_count = sc;
+    const int tiles_x_full = (width + kTile - 1) / kTile;
+    const bool cols = sc > 1 && cfg->shard_mode == GSWT_SHARD_COLUMNS;
+    f.tiles_x = tiles_x_full; f.tiles_y = (height + kTile - 1) / kTile;
+    f.col0 = 0; f.col1 = tiles_x_full; f.out_w = width; f.out_x0 = 0; f.band_cull = 0;
+    f.shard_index = sc > 1 && !cols ? cfg->shard_index : 0; f.shard_count = cols ? 1 : sc;
+    if (cols) {                                   // contiguous band of tile columns, equal width on every rank
+        const int band_tiles = (tiles_x_full + sc - 1) / sc;
+        f.col0 = std::min(cfg->shard_index * band_tiles, tiles_x_full);
+        f.col1 = std::min(f.col0 + band_tiles, tiles_x_full);
+        f.tiles_x = f.col1 - f.col0;
+        f.out_w = band_tiles * kTile; f.out_x0 = cfg->shard_index * band_tiles * kTile;
+        // band culling needs positions that are the list positions: no surface mapping, no point-cloud covariance
+        f.band_cull = (su->surface_type == 0u && !(su->point_cloud_radius > 0.0f)) ? 1 : 0;
+    }
     f.hm_w = c->hm_w; f.hm_h = c->hm_h;
     f.dbg_flags = c->opt_dbg_flags;
 
-    const int tiles_y_local = sc > 1 ? (f.tiles_y - f.shard_index + sc - 1) / sc : f.tiles_y;
+    const int rsc = f.shard_count;                                  // row-shard count (1 in column mode)
+    const int tiles_y_local = rsc > 1 ? (f.tiles_y - f.shard_index + rsc - 1) / rsc : f.tiles_y;
     const int n_tiles = f.tiles_x * (tiles_y_local > 0 ? tiles_y_local : 0);
-    const int out_rows = sc > 1 ? gswt_shard_rows_padded(height, sc) : height;
-    const size_t out_px = (size_t)out_rows * width;
+    const int out_rows = rsc > 1 ? gswt_shard_rows_padded(height, rsc) : height;
+    const size_t out_px = (size_t)out_rows * f.out_w;
     sl.n_tiles = n_tiles;
     float4* const d_out = a.d_out;
     HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1));
     const bool dbg = c->opt_debug_varyings != 0;
     if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)c->n_entries + 1));
-    if (sc > 1 && out_rows * width > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
+    if (sc > 1 && out_px > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
 
     // The pair count P is only known on the device.  Everything downstream of k_project is launched
     // for a capacity `pair_cap` (blocks past the real P do nothing), so a frame needs no host round
@@ -692,7 +719,22 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     hipEvent_t* ev = sl.ev;
     // ---- cull (+ clears the frame's accumulators) + project
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
-    launch_cull(s, f, c->draws.p, c->n_draws, sl.draw_culled.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
+    if (f.band_cull) {
+        // bounds of every draw's splat centres: per sort event, and again when the uniforms that place merged members move
+        uint32_t key[6] = {su->map_half_wh[0], su->map_half_wh[1], (uint32_t)su->center_coord[0], (uint32_t)su->center_coord[1], 0u, su->surface_type};
+        memcpy(&key[4], &su->tile_width, 4);
+        if (!c->bounds_valid || memcmp(key, c->bounds_key, sizeof(key)) != 0) {
+            for (auto& other : c->slots)                       // the other slot's frame may still be reading the old bounds
+                if (&other != &sl && other.stream) HIP_TRY(c, hipStreamSynchronize(other.stream));
+            HIP_TRY(c, c->draw_bounds.ensure((size_t)c->n_draws + 1));
+            launch_draw_bounds(s, f, c->draws.p, c->n_draws, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
+                               c->tex.p, c->draw_bounds.p);
+            HIP_TRY(c, hipStreamSynchronize(s));               // the other slot may enqueue right after us on its own stream
+            memcpy(c->bounds_key, key, sizeof(key));
+            c->bounds_valid = true;
+        }
+    }
+    launch_cull(s, f, c->draws.p, c->n_draws, sl.draw_culled.p, c->draw_bounds.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
     launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, sl.block_sums.p, d_super,
@@ -784,8 +826,9 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     for (auto& sl : c->slots)                      // collect anything still in flight from the async API
         if (sl.pending) { sl.pending = false; rc = finish_frame(c, sl); if (rc != GSWT_OK) return rc; }
     const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
-    const int out_rows = sc > 1 ? gswt_shard_rows_padded(height, sc) : height;
-    const size_t out_px = (size_t)out_rows * width, npx = (size_t)width * height;
+    const bool cols = sc > 1 && cfg->shard_mode == GSWT_SHARD_COLUMNS;
+    const int out_rows = sc > 1 && !cols ? gswt_shard_rows_padded(height, sc) : height;
+    const size_t out_px = (size_t)out_rows * (cols ? gswt_shard_cols_padded(width, sc) : width), npx = (size_t)width * height;
     const float4* d_bg = nullptr; const float* d_bgd = nullptr; float4* d_out = nullptr;
     if (bg_rgba) {
         if (bg_on_device) d_bg = reinterpret_cast<const float4*>(bg_rgba);
@@ -941,10 +984,17 @@ int gswt_proxy_render(gswt_ctx* c, const gswt_proxy_uniforms* u, int width, int 
 
 int gswt_unshard(gswt_ctx* c, const float* gathered, int width, int height, int shard_count, float* out_rgba)
 {
+    return gswt_unshard_mode(c, gathered, width, height, shard_count, GSWT_SHARD_ROWS, out_rgba);
+}
+
+int gswt_unshard_mode(gswt_ctx* c, const float* gathered, int width, int height, int shard_count, int shard_mode, float* out_rgba)
+{
     if (!c || !gathered || !out_rgba || width <= 0 || height <= 0 || shard_count < 1) return GSWT_ERR_BAD_ARG;
+    if (shard_mode != GSWT_SHARD_ROWS && shard_mode != GSWT_SHARD_COLUMNS) return GSWT_ERR_BAD_ARG;
     hipSetDevice(c->device);
     launch_unshard(c->stream, reinterpret_cast<const float4*>(gathered), reinterpret_cast<float4*>(out_rgba), width, height,
-                   shard_count, gswt_shard_rows_padded(height, shard_count));
+                   shard_count, gswt_shard_rows_padded(height, shard_count),
+                   shard_mode == GSWT_SHARD_COLUMNS ? gswt_shard_cols_padded(width, shard_count) : 0);
     HIP_TRY(c, hipGetLastError());
     return GSWT_OK;
 }

@@ -57,9 +57,22 @@ struct Frame {
     int32_t has_depth;       // proxy depth buffer bound
     // screen tiling / sharding
     int32_t width, height, tiles_x, tiles_y;
-    int32_t shard_index, shard_count;
+    int32_t shard_index, shard_count;      // interleaved tile-row sharding (count 1 = off)
+    // contiguous tile-column band (off: col0 = 0, col1 = all columns).  tiles_x is the number of columns THIS ctx composites.
+    int32_t col0, col1;
+    int32_t out_w, out_x0;                 // width of the output image in pixels and the frame pixel column of its column 0
+    int32_t band_cull;                     // 1: k_cull drops draws whose splats cannot reach the band (needs draw bounds)
     int32_t hm_w, hm_h;
     int32_t dbg_flags;       // profiling ablations (GSWT_OPT_DEBUG_FLAGS); 0 in normal operation
+};
+
+// Per-draw bounds for band culling (computed on the device by k_draw_bounds, not part of the ABI): AABB of the splat
+// centres in the space of `pos + offset` (before scene_scale) and the largest trace of a stored covariance (>= its
+// largest eigenvalue).  Stored as order-preserving integers so that integer atomic min / max apply.
+struct DrawBounds {
+    int32_t lo[3], hi[3];
+    int32_t max_trace;
+    int32_t _pad;
 };
 
 // Projected splat record consumed by the compositor (48 B, three 16-B words).

@@ -190,12 +190,72 @@ __device__ __forceinline__ int owned_rows(int ty0, int ty1, int index, int count
     return (ty1 - first) / count + 1;
 }
 
+// float <-> int with the same ordering (for integer atomicMin / atomicMax on floats)
+__device__ __forceinline__ int32_t f2ord(float x) { const int32_t i = __float_as_int(x); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float ord2f(int32_t i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+// Bounds of every draw's splat centres (pos + instancing offset, before scene_scale) and the largest covariance trace:
+// what the band cull of a column-sharded frame needs to drop, per rank, the draws whose splats cannot reach its band.
+// Per sort event (and when the merged-offset uniforms change), not per frame.  One workgroup per 256-entry chunk.
+__global__ __launch_bounds__(256) void k_draw_bounds(const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
+                                                     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
+                                                     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
+                                                     DrawBounds* __restrict__ bounds)
+{
+    __shared__ int32_t s_lo[3], s_hi[3], s_tr;
+    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0x7FFFFFFF; s_hi[threadIdx.x] = (int32_t)0x80000000; }
+    if (threadIdx.x == 3) s_tr = (int32_t)0x80000000;
+    __syncthreads();
+    const uint2 ct = chunk_tab[blockIdx.x];
+    const DrawDev& d = draws[ct.x];
+    const uint32_t r = ct.y + threadIdx.x;
+    if (r < d.count) {
+        const uint32_t j = d.count - 1u - r;
+        const uint32_t* list = d.merged ? merged_list : static_list;
+        const uint32_t entry = list[d.list_base + j];
+        const uint32_t gs_index = entry & kIdxMask;
+        const uint4 w0 = tex[2 * (size_t)gs_index];
+        const uint4 w1 = tex[2 * (size_t)gs_index + 1];
+        float ox = d.off[0], oy = d.off[1], oz = d.off[2];
+        if (d.single_draw == 1u) {                 // gswt.wgsl:52-63, same expression as k_project
+            const uint32_t map_id = merged_map[d.list_base + j];
+            uint32_t map_wh_y = 2u * f.map_half_wh[1];
+            if (f.surface_type != 2u) map_wh_y += 1u;
+            ox = (float)((int32_t)(map_id / map_wh_y - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
+            oy = (float)((int32_t)(map_id % map_wh_y - f.map_half_wh[1]) + f.center_coord[1]) * f.tile_width;
+            oz = 0.0f;
+        }
+        const float px = u2f(w0.x) + ox, py = u2f(w0.y) + oy, pz = u2f(w0.z) + oz;
+        const float tr = (half_decode(w1.x & 0xFFFFu) + half_decode(w1.y >> 16)) + half_decode(w1.z >> 16);   // xx + yy + zz
+        atomicMin(&s_lo[0], f2ord(px)); atomicMax(&s_hi[0], f2ord(px));
+        atomicMin(&s_lo[1], f2ord(py)); atomicMax(&s_hi[1], f2ord(py));
+        atomicMin(&s_lo[2], f2ord(pz)); atomicMax(&s_hi[2], f2ord(pz));
+        atomicMax(&s_tr, f2ord(tr == tr ? tr : __builtin_inff()));
+    }
+    __syncthreads();
+    DrawBounds* b = bounds + ct.x;
+    if (threadIdx.x < 3) { atomicMin(&b->lo[threadIdx.x], s_lo[threadIdx.x]); atomicMax(&b->hi[threadIdx.x], s_hi[threadIdx.x]); }
+    if (threadIdx.x == 3) atomicMax(&b->max_trace, s_tr);
+}
+
+__global__ __launch_bounds__(256) void k_draw_bounds_init(DrawBounds* __restrict__ bounds, uint32_t n_draws)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_draws) return;
+    DrawBounds b;
+    b.lo[0] = b.lo[1] = b.lo[2] = 0x7FFFFFFF;
+    b.hi[0] = b.hi[1] = b.hi[2] = (int32_t)0x80000000;
+    b.max_trace = (int32_t)0x80000000; b._pad = 0;
+    bounds[i] = b;
+}
+
 // ------------------------------------------------------------------------------------
 // k_cull: the CPU viewport culling + lod_enable skip of renderer.rs:472-497, one thread per draw.
 // ------------------------------------------------------------------------------------
 // Also clears the per-frame accumulators (first kernel of the frame; saves three memset launches).
 __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __restrict__ draws, uint32_t n_draws,
-                                              uint32_t* __restrict__ draw_culled, uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
+                                              uint32_t* __restrict__ draw_culled, const DrawBounds* __restrict__ bounds,
+                                              uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
                                               uint32_t* __restrict__ zero_b, uint32_t n_zero_b)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -220,6 +280,34 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
         if (mz < -clip || mx > clip || my > clip) culled = 1;
     }
     if (!((f.lod_enable_mask >> (d.lod & 31u)) & 1u)) culled = 1;
+    // Column-band sharding: drop the draw when none of its splats can touch this rank's pixel columns.  Conservative:
+    // the centres lie in the convex hull of the 8 projected bound corners (all in front of the camera, else keep), and a
+    // splat's pixel half extent is <= 2 s sqrt(lambda1) with lambda1 <= |J|_F^2 max(scene_scale)^2 trace(Vrk) at the
+    // nearest depth, capped by the 1024-px axis clamp (gswt.wgsl:257-258); 25 % + 2 px of slack on top.
+    if (!culled && f.band_cull && d.count) {
+        const DrawBounds b = bounds[i];
+        const float lo[3] = {ord2f(b.lo[0]), ord2f(b.lo[1]), ord2f(b.lo[2])}, hi[3] = {ord2f(b.hi[0]), ord2f(b.hi[1]), ord2f(b.hi[2])};
+        float xmin = 3.402823466e+38f, xmax = -3.402823466e+38f, wmin = 3.402823466e+38f;
+        for (int k = 0; k < 8; k++) {
+            const float px = ((k & 1) ? hi[0] : lo[0]) * f.scene_scale[0];
+            const float py = ((k & 2) ? hi[1] : lo[1]) * f.scene_scale[1];
+            const float pz = ((k & 4) ? hi[2] : lo[2]) * f.scene_scale[2];
+            const float cx = ((f.VP[0] * px + f.VP[4] * py) + f.VP[8] * pz) + f.VP[12];
+            const float cw = ((f.VP[3] * px + f.VP[7] * py) + f.VP[11] * pz) + f.VP[15];
+            wmin = fminf(wmin, cw);
+            const float xp = (0.5f * (cx / cw) + 0.5f) * f.W;
+            xmin = fminf(xmin, xp); xmax = fmaxf(xmax, xp);
+        }
+        if (wmin > 1e-6f && xmin == xmin && xmax == xmax) {
+            const float smax = fmaxf(fabsf(f.scene_scale[0]), fmaxf(fabsf(f.scene_scale[1]), fabsf(f.scene_scale[2])));
+            const float hx = 1.3f * f.htan[0], hy = 1.3f * f.htan[1];
+            const float jn2 = (f.focal[0] * f.focal[0] * (1.0f + hx * hx) + f.focal[1] * f.focal[1] * (1.0f + hy * hy)) / (wmin * wmin);
+            const float lam = jn2 * smax * smax * fmaxf(ord2f(b.max_trace), 0.0f);
+            const float ss = fabsf(f.splat_scale);
+            const float rad = fminf(2.0f * ss * sqrtf(lam), 1448.2f * ss) * 1.25f + 2.0f;
+            if (!(rad == rad) || xmax + rad < (float)(f.col0 * kTile) || xmin - rad >= (float)(f.col1 * kTile)) { if (rad == rad) culled = 1; }
+        }
+    }
     draw_culled[i] = culled;
 }
 
@@ -495,8 +583,9 @@ __global__ __launch_bounds__(256) void k_project(
                 int x0 = fx0 < 0.0f ? 0 : (int)fx0, x1 = fx1 > f.W - 1.0f ? f.width - 1 : (int)fx1;
                 int y0 = fy0 < 0.0f ? 0 : (int)fy0, y1 = fy1 > f.H - 1.0f ? f.height - 1 : (int)fy1;
                 int tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
+                tx0 = max(tx0, f.col0); tx1 = min(tx1, f.col1 - 1);          // column band of this ctx (the whole frame when off)
                 int rows = owned_rows(ty0, ty1, f.shard_index, f.shard_count);
-                count = (uint32_t)((tx1 - tx0 + 1) * rows);
+                count = tx1 >= tx0 ? (uint32_t)((tx1 - tx0 + 1) * rows) : 0u;
                 if (f.dbg_flags & 8) count = 0;        // ablation: no record / rect stores, no pairs
                 if (count) {
                     my_rect = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
@@ -661,7 +750,7 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
     for (; ty <= ty1; ty += sc) {
         const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
         for (int tx = tx0; tx <= tx1; tx++) {
-            keys[off] = row + (uint32_t)tx;
+            keys[off] = row + (uint32_t)(tx - f.col0);
             vals[off] = slot;
             off++;
         }
@@ -871,7 +960,7 @@ __global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* _
     for (; ty <= ty1; ty += sc) {
         const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
         for (int tx = tx0; tx <= tx1; tx++) {
-            keys[off] = row + (uint32_t)tx;
+            keys[off] = row + (uint32_t)(tx - f.col0);
             vals[off] = slot;
             off++;
         }
@@ -1193,7 +1282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
-    const int bx = tx * kTile, by = ty * kTile;
+    const int bx = (tx + f.col0) * kTile, by = ty * kTile;
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t grp = lane >> 4, gi = lane & 15u;                 // wave = 16 x 4 strip, 16-lane group = 4 x 4 sub-block
     const int lxi = (int)grp * 4 + (int)(gi & 3u), lyi = (int)wave * 4 + (int)(gi >> 2);
@@ -1275,7 +1364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         o.z = fmaf(T, bg.z, ab);
         o.w = fmaf(T, bg.w, 1.0f - T);
         const int orow = tyl * kTile + lyi;      // compacted row inside the shard image
-        if (orow < out_rows) out[(size_t)orow * f.width + px] = o;
+        if (orow < out_rows) out[(size_t)orow * f.out_w + (px - f.out_x0)] = o;
     }
 }
 
@@ -1295,7 +1384,7 @@ __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* 
     const uint32_t grp = lane >> 4, gi = lane & 15u;      // same lane -> pixel map as k_composite
     const int lxi = (int)grp * 4 + (int)(gi & 3u);
     const int lyi = (int)wave * 4 + (int)(gi >> 2);
-    const int px = tx * kTile + lxi, py = ty * kTile + lyi;
+    const int px = (tx + f.col0) * kTile + lxi, py = ty * kTile + lyi;
     if (px >= f.width || py >= f.height) return;
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
     for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
@@ -1313,29 +1402,45 @@ __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* 
     o.z = fmaf(T, bg.z, ab);
     o.w = fmaf(T, bg.w, 1.0f - T);
     const int orow = tyl * kTile + lyi;
-    if (orow < out_rows) out[(size_t)orow * f.width + px] = o;
+    if (orow < out_rows) out[(size_t)orow * f.out_w + (px - f.out_x0)] = o;
 }
 
-// Zero-fill helper for shard padding rows / unshard scatter
+// all-gathered shards -> frame.  rows: shard = tile row % count (rows_padded rows each, full width);
+// columns: shard = tile column / band_tiles (height rows each, band_px wide)
 __global__ void k_unshard(const float4* __restrict__ gathered, float4* __restrict__ out, int width, int height,
-                          int shard_count, int rows_padded)
+                          int shard_count, int rows_padded, int band_px)
 {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
     if (x >= width || y >= height) return;
-    int ty = y >> 4;
-    int shard = ty % shard_count, tyl = ty / shard_count;
-    size_t src = ((size_t)shard * rows_padded + (size_t)tyl * kTile + (y & 15)) * width + x;
+    size_t src;
+    if (band_px > 0) {
+        const int shard = x / band_px;
+        src = ((size_t)shard * height + y) * band_px + (x - shard * band_px);
+    } else {
+        int ty = y >> 4;
+        int shard = ty % shard_count, tyl = ty / shard_count;
+        src = ((size_t)shard * rows_padded + (size_t)tyl * kTile + (y & 15)) * width + x;
+    }
     out[(size_t)y * width + x] = gathered[src];
 }
 
 // ---- launch wrappers (called from gswt_api.hip) -------------------------------------
-void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled,
+void launch_draw_bounds(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, const uint2* chunk_tab, uint32_t n_chunks,
+                        const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
+                        DrawBounds* bounds)
+{
+    if (n_draws == 0) return;
+    hipLaunchKernelGGL(k_draw_bounds_init, dim3((n_draws + 255u) / 256u), dim3(256), 0, s, bounds, n_draws);
+    if (n_chunks) hipLaunchKernelGGL(k_draw_bounds, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list, merged_map, tex, bounds);
+}
+
+void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, const DrawBounds* bounds,
                  uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b)
 {
     uint32_t grid = (n_draws + 255) / 256;
     if (grid < 32) grid = 32;
-    hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, zero_a, n_zero_a, zero_b, n_zero_b);
+    hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, bounds, zero_a, n_zero_a, zero_b, n_zero_b);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_chunks,
@@ -1482,9 +1587,9 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows);
 }
 
-void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded)
+void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded, int band_px)
 {
-    hipLaunchKernelGGL(k_unshard, dim3((width + 255) / 256, height), dim3(256), 0, s, gathered, out, width, height, shard_count, rows_padded);
+    hipLaunchKernelGGL(k_unshard, dim3((width + 255) / 256, height), dim3(256), 0, s, gathered, out, width, height, shard_count, rows_padded, band_px);
 }
 
 }  // namespace gswt

@@ -23,6 +23,12 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def _shard_args(shard):
+    """shard = (index, count) -> interleaved tile rows; (index, count, "cols") -> contiguous tile-column bands."""
+    mode = L.GSWT_SHARD_COLUMNS if len(shard) > 2 and shard[2] in ("cols", "columns", L.GSWT_SHARD_COLUMNS) and shard[2] != 0 else L.GSWT_SHARD_ROWS
+    return int(shard[0]), int(shard[1]), mode
+
+
 def make_draw(tile: L.TileUniforms, *, base=None, merged_range=None, merged_has_lod=False, corners=None,
               lod=None) -> L.Draw:
     """One draw of the loop renderer.rs:466-591.  base = (lod, tile, view) of a static list or
@@ -139,8 +145,12 @@ class GSWTRenderer:
         cfg = L.RenderConfig()
         cfg.culling_dist, cfg.lod_enable_mask, cfg.order_mode = culling_dist, lod_enable_mask & 0xFFFFFFFF, order_mode
         cfg.transmittance_eps = transmittance_eps
-        cfg.shard_index, cfg.shard_count = int(shard[0]), int(shard[1])
-        rows = height if shard[1] <= 1 else self._lib.gswt_shard_rows_padded(height, shard[1])
+        cfg.shard_index, cfg.shard_count, cfg.shard_mode = _shard_args(shard)
+        rows, out_w = height, width
+        if cfg.shard_count > 1 and cfg.shard_mode == L.GSWT_SHARD_COLUMNS:
+            out_w = self._lib.gswt_shard_cols_padded(width, cfg.shard_count)
+        elif cfg.shard_count > 1:
+            rows = self._lib.gswt_shard_rows_padded(height, cfg.shard_count)
         if bg_on_device:
             bgc = C.c_void_p(bg_rgba) if bg_rgba else None
             bgd = C.c_void_p(bg_depth) if bg_depth else None
@@ -152,7 +162,7 @@ class GSWTRenderer:
             self._check(self._lib.gswt_render(self._h, cam, sc, C.byref(cfg), width, height, bgc, bgd,
                                               1 if bg_on_device else 0, C.c_void_p(out_device_ptr), 1))
             return None
-        out = np.empty((rows, width, 4), dtype=np.float32)
+        out = np.empty((rows, out_w, 4), dtype=np.float32)
         self._check(self._lib.gswt_render(self._h, cam, sc, C.byref(cfg), width, height, bgc, bgd,
                                           1 if bg_on_device else 0, _ptr(out), 0))
         return out
@@ -166,7 +176,7 @@ class GSWTRenderer:
         cfg = L.RenderConfig()
         cfg.culling_dist, cfg.lod_enable_mask, cfg.order_mode = culling_dist, lod_enable_mask & 0xFFFFFFFF, order_mode
         cfg.transmittance_eps = transmittance_eps
-        cfg.shard_index, cfg.shard_count = int(shard[0]), int(shard[1])
+        cfg.shard_index, cfg.shard_count, cfg.shard_mode = _shard_args(shard)
         ticket = C.c_int(-1)
         self._check(self._lib.gswt_render_async(self._h, cam, sc, C.byref(cfg), width, height,
                                                 C.c_void_p(bg_rgba_ptr) if bg_rgba_ptr else None,
@@ -207,6 +217,14 @@ class GSWTRenderer:
 
     def shard_rows_padded(self, height: int, shard_count: int) -> int:
         return int(self._lib.gswt_shard_rows_padded(height, shard_count))
+
+    def shard_cols_padded(self, width: int, shard_count: int) -> int:
+        return int(self._lib.gswt_shard_cols_padded(width, shard_count))
+
+    def unshard_mode(self, gathered_device_ptr: int, width: int, height: int, shard_count: int, mode, out_device_ptr: int):
+        m = L.GSWT_SHARD_COLUMNS if mode in ("cols", "columns", L.GSWT_SHARD_COLUMNS) and mode != 0 else L.GSWT_SHARD_ROWS
+        self._check(self._lib.gswt_unshard_mode(self._h, C.c_void_p(gathered_device_ptr), width, height, shard_count, m,
+                                                C.c_void_p(out_device_ptr)))
 
     def unshard(self, gathered_device_ptr: int, width: int, height: int, shard_count: int, out_device_ptr: int):
         self._check(self._lib.gswt_unshard(self._h, C.c_void_p(gathered_device_ptr), width, height, shard_count,

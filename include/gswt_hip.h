@@ -124,13 +124,20 @@ typedef struct {
     uint32_t lod_enable_mask; /* bit l = render_config.lod_enable[l], renderer.rs:495 */
     int32_t order_mode;       /* GSWT_ORDER_* */
     float transmittance_eps;  /* front-to-back early-out threshold; 0 = never stop early */
-    /* screen-tile sharding for multi-GPU: this ctx composites only 16-px tile rows with
-       (row % shard_count) == shard_index and writes them compacted, in row order.
-       shard_count <= 1 renders the whole frame. */
+    /* screen-tile sharding for multi-GPU; shard_count <= 1 renders the whole frame.
+       GSWT_SHARD_ROWS: this ctx composites only the 16-px tile rows with (row % shard_count) == shard_index and writes
+         them compacted, in row order (gswt_shard_rows_padded rows x W).  Every rank projects every splat.
+       GSWT_SHARD_COLUMNS: this ctx composites the contiguous band of ceil(tiles_x / shard_count) tile columns number
+         shard_index (H rows x gswt_shard_cols_padded pixels) and, on the plain surface, skips the draws none of whose
+         splats can reach the band -- projection is sharded too.  Pair counts are even across column bands for a
+         horizon-dominated view, across contiguous row bands they are not. */
     int32_t shard_index;
     int32_t shard_count;
-    uint32_t _pad[2];
+    int32_t shard_mode;       /* GSWT_SHARD_* */
+    uint32_t _pad;
 } gswt_render_config;
+
+enum { GSWT_SHARD_ROWS = 0, GSWT_SHARD_COLUMNS = 1 };
 
 /* Per-stage device times of the last gswt_render (hipEvent, ms) and workload sizes. */
 typedef struct {
@@ -294,8 +301,13 @@ GSWT_API int gswt_shard_rows(int height, int shard_index, int shard_count);
  * all-gather delivers them; each padded to gswt_shard_rows_padded rows) back into a full
  * H x W frame.  Device pointers; runs on the ctx stream. */
 GSWT_API int gswt_shard_rows_padded(int height, int shard_count);
+/* Width in pixels of every rank's shard image in GSWT_SHARD_COLUMNS mode (ceil(tiles_x / shard_count) * 16). */
+GSWT_API int gswt_shard_cols_padded(int width, int shard_count);
 GSWT_API int gswt_unshard(gswt_ctx *ctx, const float *gathered, int width, int height,
                           int shard_count, float *out_rgba);
+/* The same for either shard mode (GSWT_SHARD_COLUMNS: the gathered shards are H x gswt_shard_cols_padded images). */
+GSWT_API int gswt_unshard_mode(gswt_ctx *ctx, const float *gathered, int width, int height,
+                               int shard_count, int shard_mode, float *out_rgba);
 
 GSWT_API int gswt_synchronize(gswt_ctx *ctx);
 GSWT_API int gswt_last_timings(const gswt_ctx *ctx, gswt_timings *out);

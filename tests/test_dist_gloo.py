@@ -70,3 +70,49 @@ def test_unshard_single_process():
     frame = torch.arange(H * W * 4, dtype=torch.float32).reshape(H, W, 4)
     gathered = torch.cat([gd.shard_of_frame(frame, r, world) for r in range(world)], dim=0)
     assert torch.equal(gd.unshard(gathered, H, world), frame)
+
+
+def _worker_cols(rank, world, port, H, W, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(11)
+        frame = torch.rand((H, W, 4), generator=g)
+        shard = gd.shard_of_frame_cols(frame, rank, world)
+        gathered = torch.empty((world * H, shard.shape[1], 4), dtype=torch.float32)
+        dist.all_gather_into_tensor(gathered, shard.contiguous())
+        full = gd.unshard_cols(gathered, W, world)
+        q.put((rank, bool(torch.equal(full, frame)), shard.shape[1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,W", [(2, 64, 1920), (2, 40, 150), (3, 24, 100)])
+def test_all_gather_rebuilds_frame_column_bands(world, H, W):
+    """The column-band layout bench.py uses for N > 1 (GSWT_SHARD_COLUMNS): gloo all-gather + re-assembly."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cols, args=(r, world, port, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, bw in res:
+        assert ok, rank
+        assert bw == gd.cols_padded(W, world)
+
+
+def test_column_layout_matches_c_abi_helpers():
+    from gswt_renderer_amd import _lib as L
+    lib = L.load()
+    for W in (1, 15, 16, 17, 150, 1920, 3840):
+        for world in (1, 2, 3, 4, 8):
+            assert lib.gswt_shard_cols_padded(W, world) == gd.cols_padded(W, world)
+    H, W, world = 20, 100, 4
+    frame = torch.arange(H * W * 4, dtype=torch.float32).reshape(H, W, 4)
+    gathered = torch.cat([gd.shard_of_frame_cols(frame, r, world) for r in range(world)], dim=0)
+    assert torch.equal(gd.unshard_cols(gathered, W, world), frame)

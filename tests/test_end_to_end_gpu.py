@@ -16,7 +16,7 @@ TOL = 1e-4
 
 
 def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0.0, shard=None, culling_dist=1.0, order_mode=0,
-              render_config=None):
+              render_config=None, shard_cols=False, stats=None):
     """render_config: RenderConfig fields of SceneUniforms (draw_mode, point_cloud_radius, use_clip, clip_height)."""
     rc = dict(render_config or {})
     verts = synth.make_tileset(n_lod=n_lod, n_tile=16, lod0_count=lod0)
@@ -49,6 +49,20 @@ def _run_case(renderer, cfg, cam, W, Hh, *, lod0=600, n_lod=3, bg=False, t_eps=0
         t = renderer.timings()
         assert t["n_visible"] == st["n_visible"]
         assert t["n_pairs"] == st["n_pairs16"]
+    elif shard_cols:
+        n = shard
+        bw = renderer.shard_cols_padded(W, n)
+        img = np.zeros((Hh, W, 4), dtype=np.float32)
+        for r in range(n):
+            part = pipe.render(cu, W, Hh, bg_rgba=bg_rgba, bg_depth=bg_depth, shard=(r, n, "cols"), culling_dist=culling_dist,
+                               order_mode=order_mode, transmittance_eps=t_eps, **rc)
+            assert part.shape == (Hh, bw, 4)
+            x0, x1 = r * bw, min(W, (r + 1) * bw)
+            if x1 > x0:
+                img[:, x0:x1] = part[:, :x1 - x0]
+                assert not part[:, x1 - x0:].any()                  # padding columns stay zero
+            if stats is not None:
+                stats.append(renderer.timings()["n_visible"])
     else:
         n = shard
         rows_p = renderer.shard_rows_padded(Hh, n)
@@ -240,3 +254,26 @@ def test_sphere_surface_end_to_end(renderer, cam):
     assert kinds["plain"] > 0 and kinds["blend"] + kinds["merged"] > 0, kinds
     assert st["n_visible"] > 3000
     assert H.max_abs_diff(img, ref) <= TOL
+
+
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_column_band_shards_equal_unsharded(renderer, n):
+    """GSWT_SHARD_COLUMNS: contiguous tile-column bands with per-rank draw culling (bounds of every draw's splat centres +
+    a conservative splat radius).  The union of the bands is the unsharded image BITWISE -- a draw dropped wrongly, or a
+    pair emitted for the wrong band, would show -- and the culling really removes work."""
+    cfg = dict(tile_map_half_wh=(4, 4), surface_type=0, lod_max_dist=24.0, tile_sort_type=3, merge_type=2)
+    for cam, kw in ((((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)), {}), (((-6.0, -2.0, 1.2), (2.0, 6.0, 0.6)), dict(bg=True)),
+                    (((0.5, 0.3, 6.0), (1.5, 4.0, 0.0)), dict(render_config=dict(draw_mode=3)))):
+        full, ref, kinds, st = _run_case(renderer, cfg, cam, 360, 200, lod0=900, **kw)
+        assert H.max_abs_diff(full, ref) <= TOL
+        vis = []
+        img, _, _, _ = _run_case(renderer, cfg, cam, 360, 200, lod0=900, shard=n, shard_cols=True, stats=vis, **kw)
+        assert np.array_equal(img, full), (cam, n)
+        assert sum(vis) > 0 and min(vis) < st["n_visible"]          # some rank projected fewer splats than the whole frame has
+    # surfaces other than the plane: column bands without the draw cull
+    cfgh = dict(tile_map_half_wh=(3, 4), surface_type=1, lod_max_dist=24.0, tile_sort_type=3, merge_type=2,
+                height_map_wh=(4, 4), height_map_scale=(1.0, 1.0, 0.3))
+    cam = ((0.5, 0.3, 5.0), (1.0, 1.0, 4.5))
+    full, ref, _, _ = _run_case(renderer, cfgh, cam, 320, 240)
+    img, _, _, _ = _run_case(renderer, cfgh, cam, 320, 240, shard=n, shard_cols=True)
+    assert np.array_equal(img, full)

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""What one rank of an N-GPU run does, measured on ONE GPU: shard r of N of the c3 frame (interleaved tile rows, and
+contiguous tile-column bands with per-band draw culling), two frames in flight, no all-gather.  max over r of the
+per-rank frame time bounds the N-GPU frame rate from above."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from gswt_renderer_amd.renderer import GSWTRenderer
+from gswt_renderer_amd import _lib as L
+
+w, wang, cu, vp, sort = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "c3")
+W, H = w["width"], w["height"]
+su = wang.scene_uniforms()
+r = GSWTRenderer(0)
+r.set_option(L.GSWT_OPT_TIMING, 0)
+wang.upload_to(r)
+r.configure(None)
+r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
+for mode, N in [("rows", 1), ("rows", 2), ("rows", 4), ("rows", 8), ("cols", 2), ("cols", 4), ("cols", 8)]:
+    rows = r.shard_rows_padded(H, N) if (N > 1 and mode == "rows") else H
+    cols = r.shard_cols_padded(W, N) if (N > 1 and mode == "cols") else W
+    outs = [torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    worst = 0.0
+    vis = []
+    for rank in range(N):
+        def run(n):
+            infl = []
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                infl.append(r.render_async(cu, su, W, H, outs[i % 2].data_ptr(), transmittance_eps=1e-5, shard=(rank, N, mode) if mode == "cols" else (rank, N)))
+                if len(infl) == 2:
+                    r.render_wait(infl.pop(0))
+            while infl:
+                r.render_wait(infl.pop(0))
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+        run(10)
+        worst = max(worst, run(100))
+        vis.append(r.timings()["n_visible"])
+    print(f"{mode} N={N}: slowest rank {worst * 1e6:.0f} us/frame -> <= {1.0 / worst:.0f} frames/s before the all-gather "
+          f"({rows * cols * 16 / 1e6:.1f} MB per rank; visible splats per rank {min(vis)}..{max(vis)})", flush=True)
