@@ -109,6 +109,7 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    fake_world = int(os.environ.get("GSWT_BENCH_FAKE_WORLD", "0"))     # test hook: rank 0 of an N-rank run without the other ranks
     force_dist = os.environ.get("GSWT_BENCH_FORCE_DIST") == "1"      # exercise the all-gather plumbing with one rank
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,6 +142,8 @@ def main():
     r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
     su = wang.scene_uniforms()
     use_dist = world > 1 or force_dist
+    if fake_world > 1 and world == 1:
+        world, use_dist = fake_world, True
     shard = (rank, world, "cols") if world > 1 else (0, 1)
     rows = H
     band_w = r.shard_cols_padded(W, world) if world > 1 else W
@@ -210,7 +213,10 @@ def main():
         if use_dist:
             r.render_fence(ticket)
             with torch.cuda.stream(stream):
-                dist.all_gather_into_tensor(gathered, o)
+                if fake_world > 1:
+                    gathered[:rows].copy_(o, non_blocking=True)      # stands in for the collective (own shard only)
+                else:
+                    dist.all_gather_into_tensor(gathered, o)
                 r.unshard_mode(gathered.data_ptr(), W, H, world, "cols", frame.data_ptr())
         r.render_wait(ticket)
         t = r.timings()
