@@ -696,7 +696,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     sl.cap = cap;
     HIP_TRY(c, sl.keys_a.ensure((size_t)cap + 1)); HIP_TRY(c, sl.keys_b.ensure((size_t)cap + 1));
     HIP_TRY(c, sl.vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure((size_t)cap + 1));
-    const size_t n_super2 = 2 * ((size_t)c->n_chunks / 256 + 1);
+    const size_t n_super2 = 3 * ((size_t)c->n_chunks / 256 + 1);     // pair sums, visible sums, exclusive pair prefix (k_totals)
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
     const uint32_t n_slots = c->n_chunks * (uint32_t)kChunk;
     const size_t depth_radix_words = depth_order ? radix_ws_words(n_slots, 32) : 0;

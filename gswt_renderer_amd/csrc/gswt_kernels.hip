@@ -625,17 +625,39 @@ __global__ __launch_bounds__(256) void k_project(
     }
 }
 
-// counters[0] = visible splats, counters[1] = pairs (single workgroup)
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total);
+
+// counters[0] = visible splats, counters[1] = pairs; super_excl[j] = pairs of all chunks before super-group j (exclusive
+// scan of the pair half of super_sums), so that k_emit reads one word instead of summing up to n_chunks / 256 of them
+// (c5: 1 430 per workgroup).  Single workgroup.
 __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ super_sums, uint32_t n_super,
-                                                unsigned long long* __restrict__ counters)
+                                                unsigned long long* __restrict__ counters, uint32_t* __restrict__ super_excl)
 {
-    __shared__ unsigned long long s_p[4], s_v[4];
-    unsigned long long p = 0, v = 0;
-    for (uint32_t j = threadIdx.x; j < n_super; j += 256u) { p += super_sums[j]; v += super_sums[n_super + j]; }
-    for (int off = 32; off > 0; off >>= 1) { p += __shfl_down(p, off, 64); v += __shfl_down(v, off, 64); }
-    if ((threadIdx.x & 63u) == 0) { s_p[threadIdx.x >> 6] = p; s_v[threadIdx.x >> 6] = v; }
+    __shared__ unsigned long long s_v[4];
+    __shared__ uint32_t s_w[4];
+    unsigned long long v = 0;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_super; base += 1024u) {
+        const uint32_t i = base + threadIdx.x * 4u;
+        uint32_t p[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t idx = min(i + (uint32_t)k, n_super - 1u);              // clamped, unmasked loads
+            const uint32_t pv = super_sums[idx], vv = super_sums[n_super + idx];
+            p[k] = i + k < n_super ? pv : 0u;
+            v += i + k < n_super ? vv : 0u;
+            sum += p[k];
+        }
+        uint32_t tot;
+        uint32_t ex = block_excl_scan(sum, s_w, &tot) + carry;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (i + k < n_super) super_excl[i + k] = ex; ex += p[k]; }
+        carry += tot;
+    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63u) == 0) s_v[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) { counters[1] = s_p[0] + s_p[1] + s_p[2] + s_p[3]; counters[0] = s_v[0] + s_v[1] + s_v[2] + s_v[3]; }
+    if (threadIdx.x == 0) { counters[1] = carry; counters[0] = s_v[0] + s_v[1] + s_v[2] + s_v[3]; }
 }
 
 // ------------------------------------------------------------------------------------
@@ -712,7 +734,7 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 // key = screen tile index local to the shard; val = slot.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __restrict__ rects,
-                                              const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ super_sums,
+                                              const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ super_excl,
                                               uint32_t pair_cap, unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
@@ -725,17 +747,13 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
     const uint32_t slot = c * 256u + threadIdx.x;
     const uint32_t my_sum = block_sums[c];
     const uint32_t bs = block_sums[min(cj, c)];
-    const uint32_t ss = super_sums[min(threadIdx.x, sup)];          // sup <= n_chunks / 256: one word per thread covers 65 k chunks
+    const uint32_t sbase = super_excl[sup];                          // pairs of all chunks before this chunk's group of 256 (k_totals)
     const uint2 rc = rects[slot];                                    // only meaningful when my_sum != 0 (k_project wrote it then)
     if (my_sum == 0u) return;
-    // first pair of this chunk = sum of all earlier chunks' pair counts, from the two-level sums
-    // k_project left behind (super_sums[j] = sum over chunks 256 j .. 256 j + 255): no scan kernel
-    uint32_t part = 0;
-    if (threadIdx.x < sup) part += ss;
-    for (uint32_t j = threadIdx.x + 256u; j < sup; j += 256u) part += super_sums[j];
-    if (cj < c) part += bs;
+    // first pair of this chunk = pairs of the earlier groups + of the earlier chunks of its own group
     uint32_t chunk_base;
-    (void)block_excl_scan(part, s_w, &chunk_base);
+    (void)block_excl_scan(cj < c ? bs : 0u, s_w, &chunk_base);
+    chunk_base += sbase;
     const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
     uint32_t count = 0;
     if (tx1 >= tx0) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
@@ -1461,7 +1479,7 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     else if (full) { GSWT_LAUNCH_PROJECT(false, true); }
     else { GSWT_LAUNCH_PROJECT(false, false); }
 #undef GSWT_LAUNCH_PROJECT
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super);
 }
 
 // exclusive scan of `n` u32 in `data` -> `out` (may alias), total -> *total_out.
@@ -1485,7 +1503,8 @@ void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* 
                  const uint32_t* super_sums, uint32_t pair_cap, unsigned long long* counters, uint32_t* keys, uint32_t* vals)
 {
     if (n_chunks == 0) return;
-    hipLaunchKernelGGL(k_emit, dim3(n_chunks), dim3(256), 0, s, f, rects, block_sums, super_sums, pair_cap, counters, keys, vals);
+    const uint32_t n_super = n_chunks / 256u + 1u;      // [pairs x n_super][visible x n_super][exclusive pair prefix x n_super]
+    hipLaunchKernelGGL(k_emit, dim3(n_chunks), dim3(256), 0, s, f, rects, block_sums, super_sums + 2u * n_super, pair_cap, counters, keys, vals);
 }
 
 // Sorts (keys, vals) by key bits [0, key_bits); the pair count is read on the device (*n_ptr), grids are
