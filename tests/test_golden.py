@@ -22,6 +22,7 @@ def _load(path):
     for k, v in list(cfg.items()):
         if isinstance(v, list):
             cfg[k] = tuple(v)
+    cfg["__rc"] = json.loads(str(g["render_config"])) if "render_config" in g.files else {}
     counts = g["row_counts"]
     rows, off = [], 0
     for l in range(counts.shape[0]):
@@ -50,6 +51,7 @@ def _host_wang(rows, cfg, ids, pos):
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
 def test_oracle_reproduces_golden(path):
     g, cfg, rows = _load(path)
+    rc = cfg.pop("__rc")
     W, H = [int(x) for x in g["size"]]
     pos, tgt = g["camera"][0], g["camera"][1]
     pp = orc.preprocess(rows)
@@ -65,7 +67,7 @@ def test_oracle_reproduces_golden(path):
     assert [t.map_index for t in osort["tile_instance_vec"]] == g["order"].tolist()
     assert [t.view_id for t in osort["tile_instance_vec"]] == g["views"].tolist()
     hm = ou.height_map.reshape(ou.height_map_wh[1], ou.height_map_wh[0]) if ou.surface_type == 1 else None
-    su = wo.scene_uniforms_from_data(ou, osd["center_coord"])
+    su = wo.scene_uniforms_from_data(ou, osd["center_coord"], **rc)
     img, st = orc.render(cam.uniforms(), su, pp.tex, draws, W, H, height_map=hm)
     assert [st["n_instanced"], st["n_visible"], st["n_pairs16"]] == g["stats"].tolist()
     assert np.max(np.abs(img - g["image"])) <= 1e-6      # expf may differ in the last ulp across libm builds
@@ -76,6 +78,7 @@ def test_oracle_reproduces_golden(path):
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
 def test_host_library_reproduces_golden_order(path):
     g, cfg, rows = _load(path)
+    cfg.pop("__rc")
     W, H = [int(x) for x in g["size"]]
     pos, tgt = g["camera"][0], g["camera"][1]
     w = _host_wang(rows, cfg, g["tile_ids"], pos)
@@ -91,6 +94,7 @@ def test_host_library_reproduces_golden_order(path):
 def test_gpu_matches_golden_image(renderer, path):
     from gswt_renderer_amd import _lib as L
     g, cfg, rows = _load(path)
+    rc = cfg.pop("__rc")
     W, H = [int(x) for x in g["size"]]
     pos, tgt = g["camera"][0], g["camera"][1]
     w = _host_wang(rows, cfg, g["tile_ids"], pos)
@@ -99,7 +103,59 @@ def test_gpu_matches_golden_image(renderer, path):
     w.upload_to(renderer)
     renderer.configure(w.height_map() if cfg["surface_type"] == 1 else None)
     renderer.set_draws(s.draws, s.merged_gs_index, s.merged_map_id, s.merged_lod_id)
-    img = renderer.render(cu, w.scene_uniforms(), W, H)
+    su = w.scene_uniforms()
+    su.draw_mode = int(rc.get("draw_mode", 0))
+    img = renderer.render(cu, su, W, H)
     assert np.max(np.abs(img.astype(np.float64) - g["image"].astype(np.float64))) <= 1e-4
     t = renderer.timings()
     assert [t["n_visible"], t["n_pairs"]] == g["stats"].tolist()[1:]
+
+
+PASSES = os.path.join(os.path.dirname(__file__), "golden", "passes_small.npz")
+
+
+def _passes_inputs():
+    g = np.load(PASSES, allow_pickle=False)
+    ts = int(g["tex_size"])
+    mips, off, n = [], 0, ts
+    while n >= 1:
+        mips.append(np.ascontiguousarray(g["mips"][off: off + n * n * 4].reshape(n, n, 4)))
+        off += n * n * 4
+        n //= 2
+    W, H = [int(x) for x in g["size"]]
+    cam = orc.Camera(W, H, g["camera"][0], g["camera"][1], [0, 0, 1])
+    us = [orc.Proxy224.from_buffer_copy(bytes(u)) for u in g["uniforms"]]
+    return g, mips, W, H, cam, us
+
+
+def test_oracle_reproduces_golden_passes():
+    """skybox + two proxy draws (GRID grid then map grid) on a HeightMap surface"""
+    g, mips, W, H, cam, us = _passes_inputs()
+    sky = orc.skybox_render(cam, g["faces"], W, H)
+    assert np.max(np.abs(sky - g["sky"])) <= 1e-6
+    rgba, depth = sky.copy(), np.ones((H, W), np.float32)
+    for u in us:
+        orc.proxy_render(u, W, H, rgba, depth, mips, height_map=g["hm"], grid_dim=int(g["grid_dim"]))
+    assert depth.tobytes() == g["depth"].tobytes()
+    assert np.max(np.abs(rgba - g["rgba"])) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden_passes(renderer):
+    import torch
+    g, mips, W, H, cam, us = _passes_inputs()
+    renderer.configure(g["hm"])
+    renderer.skybox_configure(g["faces"])
+    renderer.proxy_configure(mips, grid_dim=int(g["grid_dim"]))
+    rgba = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    depth = torch.zeros((H, W), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    renderer.skybox_render(cam.uniforms(), W, H, rgba.data_ptr())
+    renderer.synchronize()
+    assert np.max(np.abs(rgba.cpu().numpy() - g["sky"])) <= 1e-5
+    for k, u in enumerate(us):
+        renderer.proxy_render(u, W, H, rgba.data_ptr(), depth.data_ptr(), clear_depth=(k == 0))
+    renderer.synchronize()
+    assert depth.cpu().numpy().tobytes() == g["depth"].tobytes()
+    assert np.max(np.abs(rgba.cpu().numpy() - g["rgba"])) <= 1e-4
+    renderer.configure(None)
