@@ -277,3 +277,32 @@ def test_column_band_shards_equal_unsharded(renderer, n):
     full, ref, _, _ = _run_case(renderer, cfgh, cam, 320, 240)
     img, _, _, _ = _run_case(renderer, cfgh, cam, 320, 240, shard=n, shard_cols=True)
     assert np.array_equal(img, full)
+
+
+def test_column_bands_follow_a_moving_camera(renderer):
+    """Column-band frames over a camera path that shifts the tile map (new center_coord -> merged members move -> the draw
+    bounds of the band cull must be rebuilt) and re-sorts the draws every step: band union == unsharded, bitwise, each step."""
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=400)
+    pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer)
+    W, Hh, n = 272, 160, 3
+    bw = renderer.shard_cols_padded(W, n)
+    shifted = 0
+    last_center = None
+    for k in range(6):
+        pos = (0.3 + 2.3 * k, 0.2 + 1.1 * k, 3.0)
+        tgt = (pos[0] + 1.0, pos[1] + 2.0, 2.4)
+        cu, vp = host.camera_uniforms(pos, tgt, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
+        pipe.update(pos, vp, force_sort=True)
+        center = tuple(pipe.wang.scene_uniforms().center_coord[:])
+        shifted += int(last_center is not None and center != last_center)
+        last_center = center
+        full = pipe.render(cu, W, Hh)
+        img = np.zeros_like(full)
+        for r in range(n):
+            part = pipe.render(cu, W, Hh, shard=(r, n, "cols"))
+            x0, x1 = r * bw, min(W, (r + 1) * bw)
+            img[:, x0:x1] = part[:, :x1 - x0]
+        assert np.array_equal(img, full), k
+        assert full[..., 3].max() > 0.2
+    assert shifted >= 2
