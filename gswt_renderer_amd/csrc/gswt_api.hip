@@ -1,5 +1,6 @@
-// gswt_api.hip -- C ABI of libgswt_hip.so (include/gswt_hip.h): context, HBM buffers and the
-// per-frame launch sequence project -> scan -> emit -> sort -> ranges -> composite.
+// gswt_api.hip -- C ABI of libgswt_hip.so (include/gswt_hip.h): context, HBM buffers, frame slots (two frames in flight,
+// each on its own stream with its own per-frame buffers) and the per-frame launch sequence
+// cull -> project -> totals -> emit -> sort -> ranges -> items -> composite -> combine; background passes; sharding.
 //
 // HBM layout (all resident, sized for a 288 GB part; nothing is re-uploaded per frame):
 //   tex          U x 32 B      packed splat records, exactly Scene.tex_data (scene.rs:306-411)

@@ -1,12 +1,15 @@
 // gswt_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the GSWT hot path.
 //
-//   k_project   : Wang-tile instancing + vs_main (gswt.wgsl:27-422) per list entry
-//   k_emit      : (splat, 16x16 screen tile) pair emission in composite order
-//   radix sort  : stable LSD sort of the pairs on the tile bits only
-//   k_ranges    : per-screen-tile [start, end) of the sorted pair list
-//   k_composite : front-to-back alpha compositing (fs_main gswt.wgsl:425-435 +
-//                 blend/depth state renderer.rs:118-129,179-185), LDS-staged lists,
-//                 wave ballot early termination
+//   k_cull        : per-draw viewport cull + lod_enable skip (renderer.rs:472-497), column-band cull; clears the frame counters
+//   k_draw_bounds : per-draw bounds of the splat centres / covariance traces (per sort event; band cull of sharded frames)
+//   k_project     : Wang-tile instancing + vs_main (gswt.wgsl:27-422) per list entry: None / HeightMap / Sphere surface,
+//                   LOD blend, EWA projection, debug draw modes
+//   k_totals/k_emit : (splat, 16x16 screen tile) pair emission in composite order, no scan launches
+//   radix sort    : stable LSD sort of the pairs on the tile bits only; k_mg_* : merged-group lists on the device
+//   k_ranges/k_items : per-screen-tile [start, end) of the sorted pair list; work items (tile, <= 512-pair segment)
+//   k_composite   : front-to-back alpha compositing (fs_main gswt.wgsl:425-435 + blend/depth state
+//                   renderer.rs:118-129,179-185): LDS-staged batches, per-sub-block lists, wave ballot early termination
+//   k_combine     : folds the segment partials of long tile lists; k_unshard : all-gathered shards -> frame
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.  Contraction is OFF for the
 // whole file: the float sequences that feed discontinuous decisions (culling, |p|^2 <= 4,
