@@ -33,7 +33,7 @@ void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long 
 void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uint32_t*);
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
-void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, const uint32_t*, const uint32_t*,
+void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, uint32_t, const uint32_t*, const uint32_t*,
                     const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, uint32_t*, uint32_t*,
                     unsigned long long*, Varyings*, float4*);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
@@ -155,6 +155,8 @@ struct gswt_ctx {
     DevBuf<DrawBounds> draw_bounds;        // per draw, for the band cull of column-sharded frames
     bool bounds_valid = false;             // false after every gswt_set_draws*
     uint32_t bounds_key[6] = {};           // map_half_wh, center_coord, tile_width bits, surface_type the merged offsets were formed with
+    DevBuf<uint2> chunk_tab_xcd;           // chunk_tab in k_project's launch order: all chunks of a draw on XCD (draw % 8)
+    uint32_t n_launch = 0;                 // its length (>= n_chunks: short per-XCD lists are padded)
     uint32_t n_draws = 0, n_chunks = 0;
     uint64_t n_entries = 0;
     bool draws_ready = false;
@@ -246,7 +248,7 @@ void gswt_destroy(gswt_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     sync_all(c);
-    c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release(); c->draw_bounds.release();
+    c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release(); c->chunk_tab_xcd.release(); c->draw_bounds.release();
     c->merged_list.release(); c->merged_map.release(); c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release();
     c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
     for (auto& sl : c->slots) {
@@ -413,6 +415,19 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     HIP_TRY(c, c->chunk_tab.ensure(chunks.size() + 1));
     if (!dd.empty()) HIP_TRY(c, hipMemcpy(c->draws.p, dd.data(), dd.size() * sizeof(DrawDev), hipMemcpyHostToDevice));
     if (!chunks.empty()) HIP_TRY(c, hipMemcpy(c->chunk_tab.p, chunks.data(), chunks.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    {   // launch-order table for k_project: per-XCD lists (XCD = draw % 8), interleaved so that position p runs on XCD p % 8
+        std::vector<uint2> per[8];
+        for (const uint2& ch : chunks) per[ch.x & 7u].push_back(ch);
+        size_t longest = 0;
+        for (auto& v : per) longest = std::max(longest, v.size());
+        std::vector<uint2> order(longest * 8, make_uint2(0u, 0xFFFFFFFFu));
+        for (int x = 0; x < 8; x++)
+            for (size_t k = 0; k < per[x].size(); k++) order[k * 8 + x] = per[x][k];
+        if (order.size() >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: chunk table too large");
+        HIP_TRY(c, c->chunk_tab_xcd.ensure(order.size() + 1));
+        if (!order.empty()) HIP_TRY(c, hipMemcpy(c->chunk_tab_xcd.p, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        c->n_launch = (uint32_t)order.size();
+    }
     // merged arrays: pack gs_index | lod << 28
     HIP_TRY(c, c->merged_list.ensure(n_merged + 1));
     HIP_TRY(c, c->merged_map.ensure(n_merged + 1));
@@ -737,7 +752,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     }
     launch_cull(s, f, c->draws.p, c->n_draws, sl.draw_culled.p, c->draw_bounds.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
-    launch_project(s, dbg, f, c->draws.p, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
+    launch_project(s, dbg, f, c->draws.p, c->chunk_tab_xcd.p, c->n_launch, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p, sl.col_f.p);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));

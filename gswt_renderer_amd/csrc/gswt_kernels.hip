@@ -339,12 +339,17 @@ __global__ __launch_bounds__(256) void k_project(
     Varyings* __restrict__ dbg, float4* __restrict__ col_f)
 {
     __shared__ uint32_t s_wsum[4], s_wvis[4];
+    // chunk_tab is in LAUNCH order, which is not slot order: workgroup b runs on XCD b % 8, and the table is laid out so
+    // that all chunks of a draw land on one XCD (draw % 8) -- a draw's gathers stay inside one tile type's 313 KB of the
+    // record table, so an XCD's 4 MB L2 then holds the few tile types it is working on instead of all 48 (6.6 MB).
     const uint2 ct = chunk_tab[blockIdx.x];
+    if (ct.y == 0xFFFFFFFFu) return;        // padding of a short per-XCD list
     const DrawDev& d = draws[ct.x];
     const uint32_t tid = threadIdx.x;
+    const uint32_t cid = (d.slot_base + ct.y) >> 8;      // chunk id in slot space
     const bool s_culled = draw_culled[ct.x] != 0u;
     if (s_culled && !DEBUG) {               // nothing to project: the chunk contributes no pairs
-        if (tid == 0) block_sums[blockIdx.x] = 0u;
+        if (tid == 0) block_sums[cid] = 0u;
         return;
     }
 
@@ -619,12 +624,12 @@ __global__ __launch_bounds__(256) void k_project(
     // k_emit reads the rects of a chunk only when the chunk has pairs
     if (bsum) rects[slot] = my_rect;
     if (tid == 0) {
-        block_sums[blockIdx.x] = bsum;
+        block_sums[cid] = bsum;
         // two-level sums, spread over n_chunks / 256 addresses (a single hot counter serialises the whole grid);
         // k_totals folds them into counters[0] (visible splats) and counters[1] (pairs)
-        if (bsum) atomicAdd(&super_sums[blockIdx.x >> 8], bsum);
+        if (bsum) atomicAdd(&super_sums[cid >> 8], bsum);
         uint32_t v = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
-        if (v) atomicAdd(&super_sums[n_super + (blockIdx.x >> 8)], v);
+        if (v) atomicAdd(&super_sums[n_super + (cid >> 8)], v);
     }
 }
 
@@ -1466,7 +1471,7 @@ void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n
     hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, bounds, zero_a, n_zero_a, zero_b, n_zero_b);
 }
 
-void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_chunks,
+void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
                     const float* hmap, const uint32_t* draw_culled, uint2* rects, Rec* recs, uint32_t* block_sums,
                     uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f)
@@ -1475,7 +1480,7 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs x n_super][visible x n_super], zeroed by the caller
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
 #define GSWT_LAUNCH_PROJECT(D, F)                                                                                              \
-    hipLaunchKernelGGL((k_project<D, F>), dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,        \
+    hipLaunchKernelGGL((k_project<D, F>), dim3(n_launch), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,        \
                        merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg, col_f)
     if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
     else if (debug) { GSWT_LAUNCH_PROJECT(true, false); }
