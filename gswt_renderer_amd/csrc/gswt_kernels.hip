@@ -1116,31 +1116,45 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
                                                 uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items)
 {
+    // Each thread owns 8 consecutive tiles per pass (8192 tiles per pass: c3 is one pass, c5 four): the eight range loads
+    // are in flight together (clamped, unconditional), then one block scan of the per-thread sums.
+    constexpr int kPer = 8;
     __shared__ uint32_t s_w[16];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const int last = n_tiles > 0 ? n_tiles - 1 : 0;
+    const bool seg_pow2 = (seg & (seg - 1u)) == 0u;
+    const uint32_t seg_sh = (uint32_t)__ffs((int)seg) - 1u;
     uint32_t carry = 0;
-    for (int base = 0; base < n_tiles; base += 1024) {
-        const int t = base + (int)threadIdx.x;
-        uint32_t cnt = 0;
-        uint2 r = make_uint2(0u, 0u);
-        if (t < n_tiles) {
-            r = ranges[t];
-            const uint32_t len = r.y - r.x;
-            cnt = len == 0 ? 1u : (len + seg - 1u) / seg;
+    for (int base = 0; base < n_tiles; base += 1024 * kPer) {
+        const int t0 = base + (int)threadIdx.x * kPer;
+        uint2 r[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; j++) r[j] = ranges[min(t0 + j, last)];
+        uint32_t cnt[kPer], sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const uint32_t len = r[j].y - r[j].x;
+            const uint32_t q = seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;   // (a 32-bit divide is ~40 VALU)
+            cnt[j] = t0 + j < n_tiles ? (len == 0 ? 1u : q) : 0u;
+            sum += cnt[j];
         }
-        uint32_t inc = wave_incl_scan(cnt, lane);
+        const uint32_t inc = wave_incl_scan(sum, lane);
         if (lane == 63u) s_w[w] = inc;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
         for (uint32_t i = 0; i < 16u; i++) { if (i < w) wbase += s_w[i]; tot += s_w[i]; }
-        if (t < n_tiles) {
-            const uint32_t first = carry + wbase + inc - cnt;
-            item_base[t] = first;
-            const uint32_t multi = cnt > 1u ? 1u : 0u;
-            for (uint32_t k = 0; k < cnt && first + k < max_items; k++) {
-                const uint32_t a = r.x + k * seg;
-                item_tab[first + k] = make_uint4((uint32_t)t, (k << 1) | multi, a, min(r.y, a + seg));
+        uint32_t first = carry + wbase + inc - sum;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            if (t0 + j < n_tiles) {
+                item_base[t0 + j] = first;
+                const uint32_t multi = cnt[j] > 1u ? 1u : 0u;
+                for (uint32_t k = 0; k < cnt[j] && first + k < max_items; k++) {
+                    const uint32_t a = r[j].x + k * seg;
+                    item_tab[first + k] = make_uint4((uint32_t)(t0 + j), (k << 1) | multi, a, min(r[j].y, a + seg));
+                }
             }
+            first += cnt[j];
         }
         carry += tot;
         __syncthreads();
