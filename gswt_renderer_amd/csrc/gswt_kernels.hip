@@ -1292,6 +1292,16 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
     if (EARLY && __ballot(T >= t_eps) == 0ull) wave_live = false;
 }
 
+// Measured and dropped in the walk (all bit-identical, c3, base 97 us):
+//  * records through ONE ds_read_b32 per two steps + DPP row_newbcast of each dword (LDS cycles per step 9 -> 2): the
+//    compiler folds the broadcast into v_cvt_f32_ubyteN but not into v_fmac, +7 VALU per step, 135 us.  LDS-array
+//    cycles are not what bounds the walk; every VALU instruction added to a step costs ~5 us of kernel.
+//  * geometry A, geometry B, one skip test on (cover A | cover B), blend A, blend B in one basic block (more ILP:
+//    tools/ubench/valu_issue.hip measures 4.8 cycles per dependent v_fma per SIMD at 8 waves, 2.9 with two independent
+//    chains): the compiler sinks the record prefetch to the loop top and splits the .w dwords into extra ds_read_b32
+//    inside the blend, exposing two LDS latencies per iteration: 126 us.  Without any skip test: 97 us (no gain).
+//  * XCD-grouped item order (segments of a tile and x-neighbour tiles on one XCD, groups of 2..16): 96.4 - 97.7 us; the
+//    record gathers are not what bounds the kernel either.
 // Measured and dropped: the same compositor as a PERSISTENT grid (one workgroup walks many items, the gathers of the next
 // item's first batch in flight during the current item's walk; items dealt by weight class, boustrophedon, so that the
 // busiest workgroup is 3 % above the mean).  Bit-identical output, 142 us against 114 us: the time goes with the number
