@@ -1299,7 +1299,9 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 //  * geometry A, geometry B, one skip test on (cover A | cover B), blend A, blend B in one basic block (more ILP:
 //    tools/ubench/valu_issue.hip measures 4.8 cycles per dependent v_fma per SIMD at 8 waves, 2.9 with two independent
 //    chains): the compiler sinks the record prefetch to the loop top and splits the .w dwords into extra ds_read_b32
-//    inside the blend, exposing two LDS latencies per iteration: 126 us.  Without any skip test: 97 us (no gain).
+//    inside the blend, exposing two LDS latencies per iteration: 126 us.  Without any skip test: 97 us (no gain).  With
+//    the pipeline restored by hand (four record sets ping-pong, the next PAIR's records in flight, steps padded to a
+//    multiple of 4): the intended schedule in the ISA, but 81 VGPRs = 5 waves per SIMD: 105 us.
 //  * XCD-grouped item order (segments of a tile and x-neighbour tiles on one XCD, groups of 2..16): 96.4 - 97.7 us; the
 //    record gathers are not what bounds the kernel either.
 // Measured and dropped: the same compositor as a PERSISTENT grid (one workgroup walks many items, the gathers of the next
