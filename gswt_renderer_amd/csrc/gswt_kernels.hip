@@ -329,6 +329,9 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
 // measurable once two frames overlap (3519 vs 3517 frames/s); (3) four chunks per workgroup with all list / record
 // loads issued up front (88 VGPRs, 123 us); (4) a per-chunk copy of the draw record + per-chunk cull flag to shorten the
 // scalar chain chunk table -> draw -> flag: those were L2 hits, the 5.6 MB of copies are HBM misses (106 -> 113 us).
+// (5) four table entries per workgroup, flags of the group fetched together and culled chunks settled at once (what
+// paid in k_emit): unrolled, four inlined bodies = 77 VGPRs, 95 -> 101 us and c5 unchanged (527 frames/s); as a loop
+// around one body the uniform float sub-expressions are hoisted into VGPRs (85).
 template <bool DEBUG, bool FULL>
 __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
