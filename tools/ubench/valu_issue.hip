@@ -20,6 +20,41 @@ __global__ __launch_bounds__(256) void k_fma(float* out, int iters, float a, flo
     if (s == 12345.678f) out[0] = s;
 }
 
+// the same with IEEE divisions (each one a ~10-instruction dependent sequence): what k_project's canonical sequences are made of
+template <int CHAINS>
+__global__ __launch_bounds__(256) void k_div(float* out, int iters, float a, float b)
+{
+    float x[CHAINS];
+    for (int c = 0; c < CHAINS; c++) x[c] = (float)threadIdx.x + (float)c + 1.0f;
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int c = 0; c < CHAINS; c++) x[c] = a / x[c] + b;
+    }
+    float s = 0.f;
+    for (int c = 0; c < CHAINS; c++) s += x[c];
+    if (s == 12345.678f) out[0] = s;
+}
+
+template <int CHAINS>
+static void run_div(int wg_per_cu, int cus, float* d)
+{
+    const int iters = 1000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k_div<CHAINS>), dim3(cus * wg_per_cu), dim3(256), 0, 0, d, 10, 1.0001f, 0.5f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_div<CHAINS>), dim3(cus * wg_per_cu), dim3(256), 0, 0, d, iters, 1.0001f, 0.5f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double divs = (double)wg_per_cu * iters * 4.0 * CHAINS;
+    printf("div chains=%d waves/SIMD=%d  %.3f ms  -> %.1f ns per wave-division per SIMD = %.1f cycles @2.4GHz\n", CHAINS, wg_per_cu, ms,
+           ms * 1e6 / divs, ms * 1e6 / divs * 2.4);
+}
+
 template <int CHAINS>
 static void run(int wg_per_cu, int cus, float* d)
 {
@@ -48,5 +83,8 @@ int main()
     for (int w : {1, 2, 4, 8}) run<1>(w, cus, d);
     for (int w : {1, 2, 4, 8}) run<2>(w, cus, d);
     for (int w : {1, 2, 4}) run<4>(w, cus, d);
+    for (int w : {4, 8}) run_div<1>(w, cus, d);
+    for (int w : {2, 4}) run_div<2>(w, cus, d);
+    run_div<4>(2, cus, d);
     return 0;
 }
