@@ -1,6 +1,8 @@
 """Seeded random sweep: random cameras x surfaces x orderings x draw modes through the whole path
 (host worker -> draw list -> HIP render) against the oracle.  The discontinuous decisions (culls, |p|^2 <= 4, depth
 test, LOD drops) must agree everywhere, so one flipped pixel fails the 1e-4 bound."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,12 +12,14 @@ from tests.test_end_to_end_gpu import _run_case
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
-_RNG = np.random.default_rng(20261004)
+# GSWT_SWEEP_SEED / GSWT_SWEEP_CASES: a longer one-off sweep on the GPU box (the defaults are what the suite runs)
+_RNG = np.random.default_rng(int(os.environ.get("GSWT_SWEEP_SEED", "20261004")))
+_N_CASES = int(os.environ.get("GSWT_SWEEP_CASES", "14"))
 
 
 def _cases():
     out = []
-    for k in range(14):
+    for k in range(_N_CASES):
         surface = (0, 1, 2, 0, 1, 0, 1)[k % 7]
         sort_t = (3, 3, 3, 0, 2, 1, 3)[k % 7]
         merge = (2, 2, 2, 2, 2, 1, 0)[k % 7]
