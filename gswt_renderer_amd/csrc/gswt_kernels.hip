@@ -821,8 +821,10 @@ __device__ __forceinline__ uint32_t clamped_count(const unsigned long long* n_pt
     return (uint32_t)n;
 }
 
-constexpr int kSortItems = 16;   // per thread (c3 sweep of the sort stage: 4 -> 139 us, 8 -> 97.5, 16 -> 95, 32 -> 109)
-constexpr int kSortBlock = 256 * kSortItems;
+constexpr int kSortItems = 8;    // per thread
+constexpr int kSortThreads = 512;    // 8 waves: the per-wave ranking chain is 8 rounds long (16 rounds in 4 waves: scatter 25 -> see DESIGN)
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kSortBlock = kSortThreads * kSortItems;      // 4096 items per workgroup
 
 // Per pass: k_radix_hist leaves, for every digit d, the per-workgroup counts ghist[d][blk], the sums over
 // groups of 32 workgroups gsup[d][blk >> 5] and the digit totals gtot[d] (integer atomics, spread over
@@ -830,20 +832,20 @@ constexpr int kSortBlock = 256 * kSortItems;
 // base = sum of gtot[< d] + gsup[d][< blk >> 5] + ghist[d][same group, < blk] -- so no scan kernel runs.
 constexpr uint32_t kSupShift = 5;
 
-__global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
+__global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
                                                     uint32_t n_cap, uint32_t shift, uint32_t mask, uint32_t* __restrict__ ghist,
                                                     uint32_t* __restrict__ gsup, uint32_t* __restrict__ gtot, uint32_t nblk,
                                                     uint32_t nsup)
 {
     const uint32_t n = clamped_count(n_ptr, n_cap);
     __shared__ uint32_t s_h[256];
-    s_h[threadIdx.x] = 0;
+    if (threadIdx.x < 256u) s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t base = blockIdx.x * kSortBlock + w * (64 * kSortItems);
     if (base < n) {                               // wave-uniform
         // all loads first, with clamped indices (a load under a lane mask is waited for on the spot, which made
-        // the 16 loads of a lane 16 dependent round trips)
+        // the loads of a lane dependent round trips)
         uint32_t key[kSortItems];
 #pragma unroll
         for (int k = 0; k < kSortItems; k++) key[k] = keys[min(base + (uint32_t)k * 64u + lane, n - 1u)];
@@ -852,6 +854,7 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__
             if (base + (uint32_t)k * 64u + lane < n) atomicAdd(&s_h[(key[k] >> shift) & mask], 1u);
     }
     __syncthreads();
+    if (threadIdx.x >= 256u) return;
     const uint32_t cnt = s_h[threadIdx.x];
     // digit-minor layouts ([blk][256], [group][256]) so that one workgroup's reads and writes are contiguous
     ghist[blockIdx.x * 256u + threadIdx.x] = cnt;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(256) void k_radix_hist(const uint32_t* __restrict__
     (void)nblk; (void)nsup;
 }
 
-__global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
                                                        uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist,
@@ -871,10 +874,10 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
 {
     const uint32_t n = clamped_count(n_ptr, n_cap);
     if (blockIdx.x * kSortBlock >= n) return;
-    __shared__ uint32_t s_h[4][256];
+    __shared__ uint32_t s_h[kSortWaves][256];
     __shared__ uint32_t s_w[4];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (int k = 0; k < 4; k++) s_h[k][threadIdx.x] = 0;
+    for (int k = 0; k < kSortWaves * 256 / kSortThreads; k++) (&s_h[0][0])[k * kSortThreads + threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * kSortBlock + w * (64 * kSortItems);
     uint32_t key[kSortItems], val[kSortItems];
@@ -886,13 +889,14 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
         key[k] = keys_in[i];
         val[k] = vals_in[i];
     }
-    // digit = threadIdx.x: global base of this workgroup's first item with that digit = items with a smaller digit
-    // + the same digit in earlier groups of 32 workgroups (gsup) + in earlier workgroups of this group (ghist)
-    const uint32_t d = threadIdx.x;
+    // digit = threadIdx.x (first 256 threads): global base of this workgroup's first item with that digit = items with a
+    // smaller digit + the same digit in earlier groups of 32 workgroups (gsup) + in earlier workgroups of this group (ghist)
+    const uint32_t d = threadIdx.x & 255u;
+    const bool dig = threadIdx.x < 256u;
     const uint32_t sb = blockIdx.x >> kSupShift;
-    uint32_t pre = 0;
-    {
-        const uint32_t g_tot = gtot[d];
+    uint32_t pre = 0, g_tot = 0;
+    if (dig) {                                                                   // wave-uniform (waves 0..3)
+        g_tot = gtot[d];
         uint32_t t[32];
 #pragma unroll
         for (uint32_t u = 0; u < 32u; u++) {                                     // <= 31 earlier workgroups of this group
@@ -908,12 +912,21 @@ __global__ __launch_bounds__(256) void k_radix_scatter(const uint32_t* __restric
         }
 #pragma unroll
         for (uint32_t u = 0; u < 32u; u++) if ((sb << kSupShift) + u < blockIdx.x) pre += t[u];
+    }
 #pragma unroll
-        for (int k = 0; k < kSortItems; k++)
-            if (base + (uint32_t)k * 64u + lane < n) atomicAdd(&s_h[w][(key[k] >> shift) & mask], 1u);
-        uint32_t tot;
-        uint32_t b = block_excl_scan(g_tot, s_w, &tot) + pre;                    // (includes a barrier: the LDS counts are complete)
-        for (int k = 0; k < 4; k++) { uint32_t c = s_h[k][d]; s_h[k][d] = b; b += c; }      // per-wave bases
+    for (int k = 0; k < kSortItems; k++)
+        if (base + (uint32_t)k * 64u + lane < n) atomicAdd(&s_h[w][(key[k] >> shift) & mask], 1u);
+    {
+        // exclusive scan of the digit totals over the first 256 threads (the other waves only take part in the barriers)
+        uint32_t inc = wave_incl_scan(g_tot, lane);
+        if (dig && lane == 63u) s_w[w] = inc;
+        __syncthreads();                                                         // also: the LDS counts are complete
+        if (dig) {
+            uint32_t wb = 0;
+            for (uint32_t i = 0; i < w; i++) wb += s_w[i];
+            uint32_t b = wb + inc - g_tot + pre;
+            for (int k = 0; k < kSortWaves; k++) { uint32_t c = s_h[k][d]; s_h[k][d] = b; b += c; }      // per-wave bases
+        }
     }
     __syncthreads();
     volatile uint32_t* h = s_h[w];
@@ -1587,8 +1600,8 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         ws = gtot + 256;
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(256), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, ghist, gsup, gtot, nblk, nsup);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(256), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,
+        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(kSortThreads), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, ghist, gsup, gtot, nblk, nsup);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,
                            ghist, gsup, gtot, nblk, nsup);
         cur ^= 1;
     }
