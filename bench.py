@@ -92,8 +92,9 @@ def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, he
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    # defaults: long enough for the two-frame pipeline and the clocks to settle (50 steps after 5 of warm-up read 4-5 % low)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--lod0", type=int, default=0, help="override LOD0 splats per tile (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

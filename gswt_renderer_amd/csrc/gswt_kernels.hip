@@ -821,10 +821,13 @@ __device__ __forceinline__ uint32_t clamped_count(const unsigned long long* n_pt
     return (uint32_t)n;
 }
 
-constexpr int kSortItems = 8;    // per thread
-constexpr int kSortThreads = 512;    // 8 waves: the per-wave ranking chain is 8 rounds long (16 rounds in 4 waves: scatter 25 -> see DESIGN)
-constexpr int kSortWaves = kSortThreads / 64;
-constexpr int kSortBlock = kSortThreads * kSortItems;      // 4096 items per workgroup
+// A sort workgroup takes 4096 consecutive items whatever its width: THREADS x (4096 / THREADS) per thread, each wave ranking
+// its share 64 at a time.  Sweeps, frames/s with two frames in flight (bench.py, 300 steps): c3 (2.66 M pairs) 256 threads
+// 3733, 512 3925, 1024 3899; c3h 3105 / 3578 / 3589; c5 (21 M pairs) 537.5 / 531.6 / 506.2.  The sort stage alone at c3:
+// 77 / 69 / 76 us (other splits of the block: 1024x8 78, 512x16 82, 1024x2 95, 512x4 84).  launch_sort picks 512 threads up
+// to kSortWideMax pairs of capacity and 256 above.
+constexpr int kSortBlock = 4096;
+constexpr uint32_t kSortWideMax = 8u << 20;     // pair capacities up to this use 512-thread workgroups
 
 // Per pass: k_radix_hist leaves, for every digit d, the per-workgroup counts ghist[d][blk], the sums over
 // groups of 32 workgroups gsup[d][blk >> 5] and the digit totals gtot[d] (integer atomics, spread over
@@ -832,11 +835,13 @@ constexpr int kSortBlock = kSortThreads * kSortItems;      // 4096 items per wor
 // base = sum of gtot[< d] + gsup[d][< blk >> 5] + ghist[d][same group, < blk] -- so no scan kernel runs.
 constexpr uint32_t kSupShift = 5;
 
+template <int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
                                                     uint32_t n_cap, uint32_t shift, uint32_t mask, uint32_t* __restrict__ ghist,
                                                     uint32_t* __restrict__ gsup, uint32_t* __restrict__ gtot, uint32_t nblk,
                                                     uint32_t nsup)
 {
+    constexpr int kSortItems = kSortBlock / kSortThreads;
     const uint32_t n = clamped_count(n_ptr, n_cap);
     __shared__ uint32_t s_h[256];
     if (threadIdx.x < 256u) s_h[threadIdx.x] = 0;
@@ -865,6 +870,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
     (void)nblk; (void)nsup;
 }
 
+template <int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
@@ -872,6 +878,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
                                                        const uint32_t* __restrict__ gsup, const uint32_t* __restrict__ gtot,
                                                        uint32_t nblk, uint32_t nsup)
 {
+    constexpr int kSortItems = kSortBlock / kSortThreads, kSortWaves = kSortThreads / 64;
     const uint32_t n = clamped_count(n_ptr, n_cap);
     if (blockIdx.x * kSortBlock >= n) return;
     __shared__ uint32_t s_h[kSortWaves][256];
@@ -1592,6 +1599,7 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
 {
     if (n_cap == 0) return 0;
     const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
+    const int threads = n_cap <= kSortWideMax ? 512 : 256;
     int cur = 0;
     for (int shift = 0; shift < key_bits; shift += 8) {
         uint32_t nbits = (uint32_t)((key_bits - shift) < 8 ? (key_bits - shift) : 8);
@@ -1600,9 +1608,13 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         ws = gtot + 256;
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
-        hipLaunchKernelGGL(k_radix_hist, dim3(nblk), dim3(kSortThreads), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, ghist, gsup, gtot, nblk, nsup);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(nblk), dim3(kSortThreads), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,
-                           ghist, gsup, gtot, nblk, nsup);
+#define GSWT_SORT_PASS(T)                                                                                                        \
+        hipLaunchKernelGGL(k_radix_hist<T>, dim3(nblk), dim3(T), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, ghist, gsup, gtot, nblk, nsup); \
+        hipLaunchKernelGGL(k_radix_scatter<T>, dim3(nblk), dim3(T), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
+                           ghist, gsup, gtot, nblk, nsup)
+        if (threads == 512) { GSWT_SORT_PASS(512); }
+        else { GSWT_SORT_PASS(256); }
+#undef GSWT_SORT_PASS
         cur ^= 1;
     }
     return cur;
