@@ -41,7 +41,7 @@ void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*);
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t);
+                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, const unsigned long long*, unsigned long long*);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
 void launch_proxy(hipStream_t, const ProxyArgs&, const float*, const float4*, float4*, float*);
@@ -95,6 +95,7 @@ struct FrameSlot {
     hipEvent_t ev[10] = {};
     hipEvent_t ev_in = nullptr;            // recorded on the ctx stream at enqueue: the frame starts after it
     unsigned long long* hc = nullptr;      // pinned host: [0] visible [1] pairs [2] scratch [3] overflow ... [7] staging
+    unsigned long long* hc_dev = nullptr;  // the same words as the device sees them (k_combine writes [0..3] at the end of a frame)
     bool pending = false;
     FrameArgs args;
     uint32_t cap = 0;
@@ -236,8 +237,9 @@ int gswt_create(int device_id, gswt_ctx** out)
         if (hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         for (auto& e : sl.ev)
             if (hipEventCreate(&e) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
-        if (hipHostMalloc(reinterpret_cast<void**>(&sl.hc), 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+        if (hipHostMalloc(reinterpret_cast<void**>(&sl.hc), 8 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         memset(sl.hc, 0, 8 * sizeof(unsigned long long));
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.hc_dev), sl.hc, 0) != hipSuccess) sl.hc_dev = nullptr;   // then the copy stays
     }
     *out = c;
     return GSWT_OK;
@@ -779,12 +781,15 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[5], s));
     // ---- composite
     launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
-                     sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr);
+                     sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr,
+                     d_counters, sl.hc_dev);
     c->last_n_tiles = (uint32_t)n_tiles;
     c->last_slot = (int)(&sl - c->slots);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(sl.hc, d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    // k_combine (the frame's last kernel) stores the result counters into the pinned host words itself; only a frame
+    // without screen tiles has no such launch
+    if (n_tiles == 0 || !sl.hc_dev) HIP_TRY(c, hipMemcpyAsync(sl.hc, d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipEventRecord(ev[9], s));
     sl.timing_level = c->opt_timing;
     return GSWT_OK;

@@ -1157,47 +1157,57 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
                                                 uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items)
 {
-    // Each thread owns 8 consecutive tiles per pass (8192 tiles per pass: c3 is one pass, c5 four): the eight range loads
-    // are in flight together (clamped, unconditional), then one block scan of the per-thread sums.
+    // 8192 tiles per pass (c3 is one pass, c5 four).  Thread t owns tiles base + j * 1024 + t, j = 0..7: every load and
+    // store of a wave is contiguous (eight tiles per thread SIDE BY SIDE made each of them 64 separate 8-byte requests:
+    // ~8 k requests through one CU's address path, the larger part of this kernel's 14 us).  The eight block scans are
+    // batched: eight wave scans back to back, one table of 8 x 16 wave sums, one 128-entry scan of it by wave 0.
     constexpr int kPer = 8;
-    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_t[kPer * 16];           // [j][wave]: wave sums, then their exclusive scan in tile order
+    __shared__ uint32_t s_tot;
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const int last = n_tiles > 0 ? n_tiles - 1 : 0;
     const bool seg_pow2 = (seg & (seg - 1u)) == 0u;
     const uint32_t seg_sh = (uint32_t)__ffs((int)seg) - 1u;
     uint32_t carry = 0;
     for (int base = 0; base < n_tiles; base += 1024 * kPer) {
-        const int t0 = base + (int)threadIdx.x * kPer;
         uint2 r[kPer];
 #pragma unroll
-        for (int j = 0; j < kPer; j++) r[j] = ranges[min(t0 + j, last)];
-        uint32_t cnt[kPer], sum = 0;
+        for (int j = 0; j < kPer; j++) r[j] = ranges[min(base + j * 1024 + (int)threadIdx.x, last)];
+        uint32_t cnt[kPer], inc[kPer];
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
             const uint32_t len = r[j].y - r[j].x;
             const uint32_t q = seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;   // (a 32-bit divide is ~40 VALU)
-            cnt[j] = t0 + j < n_tiles ? (len == 0 ? 1u : q) : 0u;
-            sum += cnt[j];
+            cnt[j] = base + j * 1024 + (int)threadIdx.x < n_tiles ? (len == 0 ? 1u : q) : 0u;
         }
-        const uint32_t inc = wave_incl_scan(sum, lane);
-        if (lane == 63u) s_w[w] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-        for (uint32_t i = 0; i < 16u; i++) { if (i < w) wbase += s_w[i]; tot += s_w[i]; }
-        uint32_t first = carry + wbase + inc - sum;
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
-            if (t0 + j < n_tiles) {
-                item_base[t0 + j] = first;
+            inc[j] = wave_incl_scan(cnt[j], lane);
+            if (lane == 63u) s_t[j * 16 + (int)w] = inc[j];
+        }
+        __syncthreads();
+        if (w == 0u) {                            // exclusive scan of the 128 wave sums, two per lane
+            const uint32_t a = s_t[2u * lane], b2 = s_t[2u * lane + 1u];
+            const uint32_t pi = wave_incl_scan(a + b2, lane);
+            s_t[2u * lane] = pi - a - b2;
+            s_t[2u * lane + 1u] = pi - b2;
+            if (lane == 63u) s_tot = pi;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int t = base + j * 1024 + (int)threadIdx.x;
+            if (t < n_tiles) {
+                const uint32_t first = carry + s_t[j * 16 + (int)w] + inc[j] - cnt[j];
+                item_base[t] = first;
                 const uint32_t multi = cnt[j] > 1u ? 1u : 0u;
                 for (uint32_t k = 0; k < cnt[j] && first + k < max_items; k++) {
                     const uint32_t a = r[j].x + k * seg;
-                    item_tab[first + k] = make_uint4((uint32_t)(t0 + j), (k << 1) | multi, a, min(r[j].y, a + seg));
+                    item_tab[first + k] = make_uint4((uint32_t)t, (k << 1) | multi, a, min(r[j].y, a + seg));
                 }
             }
-            first += cnt[j];
         }
-        carry += tot;
+        carry += s_tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) item_base[n_tiles] = carry;
@@ -1467,9 +1477,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 // One workgroup per tile, same lane -> pixel mapping as k_composite.
 __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* __restrict__ item_base,
                                                  const float4* __restrict__ partials, const float4* __restrict__ bg_rgba,
-                                                 float4* __restrict__ out, int n_tiles, int out_rows)
+                                                 float4* __restrict__ out, int n_tiles, int out_rows,
+                                                 const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ host_counters)
 {
     const int tile = blockIdx.x;
+    // last kernel of the frame: the four result counters go straight into the slot's pinned host words (instead of a
+    // separate 32-byte device-to-host copy, ~4 us of stream time and one more API call per frame)
+    if (tile == 0 && threadIdx.x < 4u && host_counters) host_counters[threadIdx.x] = counters[threadIdx.x];
     const uint32_t i0 = item_base[tile], n_seg = item_base[tile + 1] - i0;
     if (n_seg <= 1u) return;
     const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
@@ -1666,7 +1680,7 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const un
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
                       const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
-                      hipEvent_t ev_begin, hipEvent_t ev_end)
+                      hipEvent_t ev_begin, hipEvent_t ev_end, const unsigned long long* counters, unsigned long long* host_counters)
 {
     if (n_tiles == 0) return;
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
@@ -1686,7 +1700,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     else GSWT_LAUNCH_COMPOSITE(false, false, false);
 #undef GSWT_LAUNCH_COMPOSITE
     if (ev_end) hipEventRecord(ev_end, s);
-    hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows);
+    hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded, int band_px)
