@@ -748,6 +748,8 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 // A workgroup takes kEmitGroup consecutive chunks: most chunks emit nothing (culled draws, LOD rings) and a workgroup
 // that only learns so from a load costs a full memory round trip per chunk -- with one chunk per workgroup the kernel ran
 // as (chunks / 2048 resident workgroups) x ~1.07 us: 22 us on c3, 190 us on c5's 365 k chunks.
+// (The four chunks side by side in a 1024-thread workgroup with a single barrier: 32 us at c3 -- four times the waves for the
+// empty groups; per-slot pair offsets left by k_project so that no per-chunk scan is needed here: 18 us, +1.3 us there, no gain.)
 constexpr uint32_t kEmitGroup = 4;          // divides 256: a workgroup's chunks share one super-group
 __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __restrict__ rects,
                                               const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ super_excl,
