@@ -1358,6 +1358,10 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 //    multiple of 4): the intended schedule in the ISA, but 81 VGPRs = 5 waves per SIMD: 105 us.
 //  * XCD-grouped item order (segments of a tile and x-neighbour tiles on one XCD, groups of 2..16): 96.4 - 97.7 us; the
 //    record gathers are not what bounds the kernel either.
+//  * occupancy: 7 workgroups per CU today (69 VGPRs; LDS 20.8 KB also caps at 7).  One LESS (LDS padded) costs 5 % of the
+//    frame rate, so the eighth was tried: pixel boxes as four signed bytes (exactly equivalent integer tests, LDS 17.9 KB)
+//    and the prefetched record trimmed to the ten words the staging uses -- at 64 VGPRs the compiler still spills four
+//    loop invariants to scratch and reloads them in the per-batch path: 111 us.
 // Measured and dropped: the same compositor as a PERSISTENT grid (one workgroup walks many items, the gathers of the next
 // item's first batch in flight during the current item's walk; items dealt by weight class, boustrophedon, so that the
 // busiest workgroup is 3 % above the mean).  Bit-identical output, 142 us against 114 us: the time goes with the number
