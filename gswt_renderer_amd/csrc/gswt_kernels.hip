@@ -1234,7 +1234,7 @@ __device__ unsigned long long g_stats[8];
 // Lane geometry of the compositor: wave w owns the 8x8 quadrant, 16-lane group g the 4x4 sub-block.
 struct CompLane {
     float lx, ly;                 // tile-local pixel centre of this lane
-    float y0, y1;                 // pixel-centre range (tile-local) of the wave's 16 x 4 strip
+    int r0;                       // first pixel row (tile-local) of the wave's 16 x 4 strip
     uint32_t lane, grp;
 };
 
@@ -1249,7 +1249,7 @@ constexpr uint32_t kNullRec = 256u;        // LDS record no pixel is ever inside
 // whose r^2 is +inf: the walk needs neither a shift nor an `i < n` test nor a mid-pair exit.
 template <bool EARLY, bool DEPTH, bool COLF>
 __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLane& g, uint32_t n, const float4* s_q0, const float4* s_q1,
-                                                   const float4* s_q2, const float4* s_bb, const float* s_dep, uint16_t* wlist,
+                                                   const float4* s_q2, const uint32_t* s_bb, const float* s_dep, uint16_t* wlist,
                                                    float dbuf, float t_eps, float& T, float& ar, float& ag, float& ab, bool& wave_live)
 {
     const uint32_t lane = g.lane, grp = g.grp;
@@ -1262,13 +1262,15 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
         const uint32_t idx = (uint32_t)c * 64u + lane;
         bool h0 = false, h1 = false, h2 = false, h3 = false;
         if (idx < n) {
-            const float4 bb = s_bb[idx];                     // (x_lo, x_hi, y_lo, y_hi) of the pixel-centre box
-            const bool hy = bb.w >= g.y0 && bb.z <= g.y1;
-            h0 = hy && bb.x <= 3.5f;                         // columns 0..3: centres 0.5 .. 3.5 (x_hi >= 0.5 always holds inside the tile)
-            h1 = hy && bb.y >= 4.5f && bb.x <= 7.5f;
-            h2 = hy && bb.y >= 8.5f && bb.x <= 11.5f;
-            h3 = hy && bb.y >= 12.5f;
-            h0 = h0 && bb.y >= 0.5f; h3 = h3 && bb.x <= 15.5f;
+            // the box as four signed bytes: (first, last) pixel column and row whose CENTRE it holds (see the staging code)
+            const uint32_t bb = s_bb[idx];
+            const int xa = __builtin_amdgcn_sbfe((int)bb, 0, 8), xb = __builtin_amdgcn_sbfe((int)bb, 8, 8);
+            const int ya = __builtin_amdgcn_sbfe((int)bb, 16, 8), yb = __builtin_amdgcn_sbfe((int)bb, 24, 8);
+            const bool hy = yb >= g.r0 && ya <= g.r0 + 3;
+            h0 = hy && xa <= 3 && xb >= 0;                   // columns 0..3
+            h1 = hy && xb >= 4 && xa <= 7;
+            h2 = hy && xb >= 8 && xa <= 11;
+            h3 = hy && xb >= 12 && xa <= 15;
         }
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
 #define GSWT_APPEND(H, M, CNT, G)                                                                                         \
@@ -1358,10 +1360,11 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 //    multiple of 4): the intended schedule in the ISA, but 81 VGPRs = 5 waves per SIMD: 105 us.
 //  * XCD-grouped item order (segments of a tile and x-neighbour tiles on one XCD, groups of 2..16): 96.4 - 97.7 us; the
 //    record gathers are not what bounds the kernel either.
-//  * occupancy: 7 workgroups per CU today (69 VGPRs; LDS 20.8 KB also caps at 7).  One LESS (LDS padded) costs 5 % of the
-//    frame rate, so the eighth was tried: pixel boxes as four signed bytes (exactly equivalent integer tests, LDS 17.9 KB)
-//    and the prefetched record trimmed to the ten words the staging uses -- at 64 VGPRs the compiler still spills four
-//    loop invariants to scratch and reloads them in the per-batch path: 111 us.
+//  (Occupancy matters here: one workgroup per CU LESS -- LDS padded -- costs 5 % of the frame rate.  The eighth came from the
+//  pixel boxes as four signed bytes (LDS 20.8 -> 17.9 KB) plus, to get from 69 to 63 VGPRs without spills: the prefetched record
+//  trimmed to the ten words the staging uses, the tile origin and the wave index through readfirstlane (SGPRs), and the output
+//  pixel recomputed at the end from an opaque copy of the thread id.  c3 3990 -> 4078, c3h 3555 -> 3685 frames/s on one box.
+//  The depth / float-colour variants need 71-72 VGPRs and stay at 7 waves: forcing 8 spilled loop invariants to scratch.)
 // Measured and dropped: the same compositor as a PERSISTENT grid (one workgroup walks many items, the gathers of the next
 // item's first batch in flight during the current item's walk; items dealt by weight class, boustrophedon, so that the
 // busiest workgroup is 3 % above the mean).  Bit-identical output, 142 us against 114 us: the time goes with the number
@@ -1371,7 +1374,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 // what staging costs with nothing to hide behind, not a serial share of the full kernel.
 
 template <bool EARLY, bool DEPTH, bool COLF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || COLF) ? 7 : 8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
                                                    uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
                                                    const float4* __restrict__ col_f,
@@ -1379,7 +1382,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                    float4* __restrict__ out, float4* __restrict__ partials,
                                                    int n_tiles, int out_rows)
 {
-    __shared__ float4 s_q0[257], s_q1[257], s_bb[256];          // [256] = the null record (list padding)
+    __shared__ float4 s_q0[257], s_q1[257];                     // [256] = the null record (list padding)
+    __shared__ uint32_t s_bb[256];                              // pixel box of a staged pair, four signed bytes
     __shared__ float4 s_q2[COLF ? 257 : 1];
     __shared__ float s_dep[DEPTH ? 257 : 1];
     __shared__ uint16_t s_list[4][4][kListStride];     // [wave][sub-block][i] -> LDS byte offset of the i-th hit's record
@@ -1395,15 +1399,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
     const int bx = (tx + f.col0) * kTile, by = ty * kTile;
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));      // uniform per wave: everything derived from it stays scalar
     const uint32_t grp = lane >> 4, gi = lane & 15u;                 // wave = 16 x 4 strip, 16-lane group = 4 x 4 sub-block
     const int lxi = (int)grp * 4 + (int)(gi & 3u), lyi = (int)wave * 4 + (int)(gi >> 2);
     const int px = bx + lxi, py = by + lyi;
     const bool inside = px < f.width && py < f.height;
     const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
-    const float fbx = (float)bx, fby = (float)by;
+    // tile origin as floats: uniform, kept in SGPRs (a v_cvt of a scalar would park them in two VGPRs for the whole kernel)
+    const float fbx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)bx)));
+    const float fby = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)by)));
     uint16_t* const wlist = &s_list[wave][0][0];
-    const CompLane cl = {lx, ly, (float)(wave * 4u) + 0.5f, (float)(wave * 4u) + 3.5f, lane, grp};
+    const CompLane cl = {lx, ly, (int)(wave * 4u), lane, grp};
     const uint2 rg = make_uint2(it.z, it.w);         // this item's slice of the tile's pair list
     // Transmittance doubles as the "still active" state: a lane is live while T >= t_eps.  Pixels
     // outside the target start at T = 0 when early-out is on (never live); with t_eps = 0 they just
@@ -1424,13 +1431,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     // while batch b is binned and walked (two dependent HBM latencies per batch otherwise sit between barriers).
     // The loads are unconditional with clamped indices (lanes past the end re-read the last pair and never stage
     // it): a load under a lane mask would be merged back through register copies that wait for it on the spot.
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra, rd = ra;
+    // (only the words the staging needs are kept in registers: the depth word rides along with a depth buffer only, the
+    // pad word of the third quad never)
+    struct F3 { float x, y, z; };
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rd = ra;
+    F3 rb = {0.f, 0.f, 0.f}, rc = {0.f, 0.f, 0.f};
+    float rbw = 0.f;
+#define GSWT_LOAD_REC(SLOT)                                                                          \
+        {                                                                                           \
+            const float* rp = reinterpret_cast<const float*>(recs + (SLOT));                        \
+            ra = *reinterpret_cast<const float4*>(rp);                                              \
+            if (DEPTH) { const float4 t4 = *reinterpret_cast<const float4*>(rp + 4); rb.x = t4.x; rb.y = t4.y; rb.z = t4.z; rbw = t4.w; } \
+            else rb = *reinterpret_cast<const F3*>(rp + 4);                                         \
+            rc = *reinterpret_cast<const F3*>(rp + 8);                                              \
+        }
     uint32_t slot_nxt = 0;
     const uint32_t last_pair = rg.y - 1u;
     if (rg.x < rg.y && !(f.dbg_flags & 4)) {
         const uint32_t slot0 = vals[min(rg.x + tid, last_pair)];
-        const float4* rp = reinterpret_cast<const float4*>(recs + slot0);
-        ra = rp[0]; rb = rp[1]; rc = rp[2];
+        GSWT_LOAD_REC(slot0)
         if (COLF) rd = col_f[slot0];
         slot_nxt = vals[min(rg.x + 256u + tid, last_pair)];
     }
@@ -1444,14 +1463,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const float nkv = -fmaf(rb.x, ox, rb.y * oy);
             s_q0[tid] = make_float4(ra.x, ra.y, nku, __builtin_amdgcn_logf(ra.w));   // v_log_f32 = log2; log2(0) = -inf -> B = 0
             s_q1[tid] = make_float4(rb.x, rb.y, nkv, rc.x);
-            s_bb[tid] = make_float4(ox - rc.y, ox + rc.y, oy - rc.z, oy + rc.z);     // pixel bbox, tile-local
-            if (DEPTH) s_dep[tid] = rb.w;
+            // Pixel box, tile-local, as the integer pixel ranges whose centres it holds: x_lo <= k + 0.5  <=>  ceil(x_lo - 0.5) <= k and
+            // x_hi >= k + 0.5  <=>  floor(x_hi - 0.5) >= k for every integer k (x - 0.5 is exact in binary32 wherever the
+            // outcome can depend on it), so the byte form bins exactly like the float box did; 16 -> 4 bytes of LDS per pair.
+            // Clamped to [-2, 17]: only 0..15 are ever compared.
+            const int xa = min(max((int)ceilf((ox - rc.y) - 0.5f), -2), 17), xb = min(max((int)floorf((ox + rc.y) - 0.5f), -2), 17);
+            const int ya = min(max((int)ceilf((oy - rc.z) - 0.5f), -2), 17), yb = min(max((int)floorf((oy + rc.z) - 0.5f), -2), 17);
+            s_bb[tid] = (uint32_t)(xa & 0xFF) | ((uint32_t)(xb & 0xFF) << 8) | ((uint32_t)(ya & 0xFF) << 16) | ((uint32_t)(yb & 0xFF) << 24);
+            if (DEPTH) s_dep[tid] = rbw;
             if (COLF) s_q2[tid] = rd;
         }
         __syncthreads();
         {
-            const float4* rp = reinterpret_cast<const float4*>(recs + slot_nxt);
-            ra = rp[0]; rb = rp[1]; rc = rp[2];
+            GSWT_LOAD_REC(slot_nxt)
             if (COLF) rd = col_f[slot_nxt];
             slot_nxt = vals[min(base + 512u + tid, last_pair)];
         }
@@ -1467,7 +1491,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         partials[(size_t)item * 256u + tid] = make_float4(ar, ag, ab, T);
         return;
     }
-    if (inside) {
+    // pixel coordinates again, from a copy of the thread id the compiler cannot connect to the one above: otherwise px, py
+    // and the output row stay in VGPRs across the whole walk (the kernel sits exactly at the 64-VGPR / 8-wave limit)
+    uint32_t tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int lxi2 = (int)(((tid2 & 63u) >> 4) * 4u + (tid2 & 3u)), lyi2 = (int)((tid2 >> 6) * 4u + ((tid2 & 15u) >> 2));
+    const int px2 = bx + lxi2, py2 = by + lyi2;
+    if (px2 < f.width && py2 < f.height) {
+        const int px = px2, py = py2, lyi = lyi2;
         float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bg_rgba) bg = bg_rgba[(size_t)py * f.width + px];
         float4 o;
