@@ -1160,60 +1160,77 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
                                                 uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items)
 {
-    // 8192 tiles per pass (c3 is one pass, c5 four).  Thread t owns tiles base + j * 1024 + t, j = 0..7: every load and
-    // store of a wave is contiguous (eight tiles per thread SIDE BY SIDE made each of them 64 separate 8-byte requests:
-    // ~8 k requests through one CU's address path, the larger part of this kernel's 14 us).  The eight block scans are
-    // batched: eight wave scans back to back, one table of 8 x 16 wave sums, one 128-entry scan of it by wave 0.
+    // One workgroup per 8192 tiles (c3: one workgroup, c5: four).  Thread t owns tiles base + j * 1024 + t, j = 0..7: every
+    // load and store of a wave is contiguous (eight tiles per thread SIDE BY SIDE made each of them 64 separate 8-byte
+    // requests: ~8 k requests through one CU's address path, the larger part of the old kernel's 14 us).  The eight block
+    // scans are batched: eight wave scans back to back, one table of 8 x 16 wave sums, one 128-entry scan of it by wave 0.
+    // A workgroup's first item = the segment count of all tiles in front of it, which it sums itself (<= 8 k tiles per
+    // earlier workgroup, contiguous reads) instead of waiting for the others: no inter-workgroup dependence.
     constexpr int kPer = 8;
     __shared__ uint32_t s_t[kPer * 16];           // [j][wave]: wave sums, then their exclusive scan in tile order
-    __shared__ uint32_t s_tot;
+    __shared__ uint32_t s_tot, s_carry[16];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const int last = n_tiles > 0 ? n_tiles - 1 : 0;
     const bool seg_pow2 = (seg & (seg - 1u)) == 0u;
     const uint32_t seg_sh = (uint32_t)__ffs((int)seg) - 1u;
+    const int base = (int)blockIdx.x * 1024 * kPer;
+    uint2 r[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) r[j] = ranges[min(base + j * 1024 + (int)threadIdx.x, last)];
+    // segments of the tiles in front of this workgroup
     uint32_t carry = 0;
-    for (int base = 0; base < n_tiles; base += 1024 * kPer) {
-        uint2 r[kPer];
+    if (base > 0) {
+        uint32_t part = 0;
+        for (int t0 = 0; t0 < base; t0 += 1024 * kPer) {
+            uint2 e[kPer];
 #pragma unroll
-        for (int j = 0; j < kPer; j++) r[j] = ranges[min(base + j * 1024 + (int)threadIdx.x, last)];
-        uint32_t cnt[kPer], inc[kPer];
+            for (int j = 0; j < kPer; j++) e[j] = ranges[t0 + j * 1024 + (int)threadIdx.x];      // t0 + 8191 < base <= n_tiles
 #pragma unroll
-        for (int j = 0; j < kPer; j++) {
-            const uint32_t len = r[j].y - r[j].x;
-            const uint32_t q = seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;   // (a 32-bit divide is ~40 VALU)
-            cnt[j] = base + j * 1024 + (int)threadIdx.x < n_tiles ? (len == 0 ? 1u : q) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < kPer; j++) {
-            inc[j] = wave_incl_scan(cnt[j], lane);
-            if (lane == 63u) s_t[j * 16 + (int)w] = inc[j];
-        }
-        __syncthreads();
-        if (w == 0u) {                            // exclusive scan of the 128 wave sums, two per lane
-            const uint32_t a = s_t[2u * lane], b2 = s_t[2u * lane + 1u];
-            const uint32_t pi = wave_incl_scan(a + b2, lane);
-            s_t[2u * lane] = pi - a - b2;
-            s_t[2u * lane + 1u] = pi - b2;
-            if (lane == 63u) s_tot = pi;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kPer; j++) {
-            const int t = base + j * 1024 + (int)threadIdx.x;
-            if (t < n_tiles) {
-                const uint32_t first = carry + s_t[j * 16 + (int)w] + inc[j] - cnt[j];
-                item_base[t] = first;
-                const uint32_t multi = cnt[j] > 1u ? 1u : 0u;
-                for (uint32_t k = 0; k < cnt[j] && first + k < max_items; k++) {
-                    const uint32_t a = r[j].x + k * seg;
-                    item_tab[first + k] = make_uint4((uint32_t)t, (k << 1) | multi, a, min(r[j].y, a + seg));
-                }
+            for (int j = 0; j < kPer; j++) {
+                const uint32_t len = e[j].y - e[j].x;
+                part += len == 0 ? 1u : (seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg);
             }
         }
-        carry += s_tot;
+        const uint32_t pi = wave_incl_scan(part, lane);
+        if (lane == 63u) s_carry[w] = pi;
         __syncthreads();
+        for (uint32_t i = 0; i < 16u; i++) carry += s_carry[i];
     }
-    if (threadIdx.x == 0) item_base[n_tiles] = carry;
+    uint32_t cnt[kPer], inc[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        const uint32_t len = r[j].y - r[j].x;
+        const uint32_t q = seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;   // (a 32-bit divide is ~40 VALU)
+        cnt[j] = base + j * 1024 + (int)threadIdx.x < n_tiles ? (len == 0 ? 1u : q) : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        inc[j] = wave_incl_scan(cnt[j], lane);
+        if (lane == 63u) s_t[j * 16 + (int)w] = inc[j];
+    }
+    __syncthreads();
+    if (w == 0u) {                            // exclusive scan of the 128 wave sums, two per lane
+        const uint32_t a = s_t[2u * lane], b2 = s_t[2u * lane + 1u];
+        const uint32_t pi = wave_incl_scan(a + b2, lane);
+        s_t[2u * lane] = pi - a - b2;
+        s_t[2u * lane + 1u] = pi - b2;
+        if (lane == 63u) s_tot = pi;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        const int t = base + j * 1024 + (int)threadIdx.x;
+        if (t < n_tiles) {
+            const uint32_t first = carry + s_t[j * 16 + (int)w] + inc[j] - cnt[j];
+            item_base[t] = first;
+            const uint32_t multi = cnt[j] > 1u ? 1u : 0u;
+            for (uint32_t k = 0; k < cnt[j] && first + k < max_items; k++) {
+                const uint32_t a = r[j].x + k * seg;
+                item_tab[first + k] = make_uint4((uint32_t)t, (k << 1) | multi, a, min(r[j].y, a + seg));
+            }
+        }
+    }
+    if (threadIdx.x == 0 && base + 1024 * kPer >= n_tiles) item_base[n_tiles] = carry + s_tot;      // the last workgroup
 }
 
 #ifdef GSWT_STATS
@@ -1722,7 +1739,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 {
     if (n_tiles == 0) return;
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
-    hipLaunchKernelGGL(k_items, dim3(1), dim3(1024), 0, s, ranges, n_tiles, seg, item_base, item_tab, max_items);
+    hipLaunchKernelGGL(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), 0, s, ranges, n_tiles, seg, item_base, item_tab, max_items);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
 #define GSWT_LAUNCH_COMPOSITE(E, D, C)                                                                                         \

@@ -86,6 +86,20 @@ def test_graph_edge_none_surface(renderer):
     assert H.max_abs_diff(img, ref) <= TOL
 
 
+def test_more_than_8192_screen_tiles(renderer):
+    """2304 x 1296 = 144 x 81 = 11 664 screen tiles: k_items runs as two workgroups, the second summing the segments of the
+    first one's tiles itself; a small segment size gives many tiles several work items (k_combine)."""
+    from gswt_renderer_amd import _lib as L
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    renderer.set_option(L.GSWT_OPT_SEGMENT, 256)
+    try:
+        img, ref, kinds, st = _run_case(renderer, cfg, ((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)), 2304, 1296, bg=True)
+    finally:
+        renderer.set_option(L.GSWT_OPT_SEGMENT, 512)
+    assert st["n_visible"] > 500
+    assert H.max_abs_diff(img, ref) <= TOL
+
+
 def test_heightmap_surface_with_background_and_depth(renderer):
     cfg = dict(tile_map_half_wh=(3, 4), surface_type=1, lod_max_dist=24.0, tile_sort_type=3, merge_type=2,
                height_map_wh=(4, 4), height_map_scale=(1.0, 1.0, 0.3))
