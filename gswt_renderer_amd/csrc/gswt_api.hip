@@ -712,7 +712,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_entries / 4, 1u << 20), 0xFFFFFF00ull);
     const uint32_t cap = c->pair_cap;
     sl.cap = cap;
-    HIP_TRY(c, sl.keys_a.ensure((size_t)cap + 1)); HIP_TRY(c, sl.keys_b.ensure((size_t)cap + 1));
+    HIP_TRY(c, sl.keys_a.ensure((size_t)cap + 4)); HIP_TRY(c, sl.keys_b.ensure((size_t)cap + 4));     // k_ranges reads whole quads
     HIP_TRY(c, sl.vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure((size_t)cap + 1));
     const size_t n_super2 = 3 * ((size_t)c->n_chunks / 256 + 1);     // pair sums, visible sums, exclusive pair prefix (k_totals)
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
