@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--passes", type=int, default=-1, help="1: run the skybox + proxy compute passes before the splats each frame "
                     "(BASELINE config 5); default: on for c5, off otherwise")
     ap.add_argument("--timing", type=int, default=1, help="hipEvent level: 1 = frame + k_composite (roofline), 2 = every stage")
+    ap.add_argument("--in-flight", type=int, default=0, help="frames in flight (default: every frame slot of the library, two when a "
+                    "slot's buffers exceed 2 GB)")
     ap.add_argument("--timing-every", type=int, default=8, help="frames between timed ones: the events around k_composite are recorded on "
                     "every N-th frame of the timed region (recording them on every frame costs ~4 %% of the frame rate)")
     args = ap.parse_args()
@@ -150,10 +152,20 @@ def main():
     shard = (rank, world, "cols") if world > 1 else (0, 1)
     rows = H
     band_w = r.shard_cols_padded(W, world) if world > 1 else W
-    # two frames in flight (gswt_render_async / gswt_render_wait): frame i+1 is queued on the stream while
-    # frame i executes, so the host never idles the GPU between frames; frames alternate output buffers
-    outs = [torch.empty((rows, band_w, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    # as many frames in flight as the library has frame slots (gswt_render_async / gswt_render_wait): the next frames are
+    # queued while the oldest executes; each frame in flight has its own output buffer
+    slots = r.frame_slots()
+    outs = [torch.empty((rows, band_w, 4), dtype=torch.float32, device=dev) for _ in range(slots)]
     out = outs[0]
+    # ... unless a slot's per-frame buffers are large: rotating three multi-GB buffer sets costs more than the third frame in
+    # flight gains (c5, ~5.6 GB per slot: 554 frames/s with two in flight, 543 with three).  The library reuses the lowest free
+    # slot, so keeping fewer frames in flight also keeps fewer buffer sets in rotation.
+    r.render_wait(r.render_async(cu, su, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, shard=shard))
+    per_slot_bytes = 60.0 * float(r.timings()["n_instanced"])           # rects + records per list entry, roughly
+    if args.in_flight > 0:
+        slots = max(1, min(slots, args.in_flight))
+    elif per_slot_bytes > 2e9:
+        slots = min(slots, 2)
     gathered = torch.empty((world * rows, band_w, 4), dtype=torch.float32, device=dev) if use_dist else None
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if use_dist else None
 
@@ -191,8 +203,8 @@ def main():
         pu.view[:] = cu.view[:]; pu.projection[:] = cu.projection[:]
         pu.map_half_wh[:] = su.map_half_wh[:]; pu.center_coord[:] = su.center_coord[:]
         pu.height_map_scale[:] = su.height_map_scale[:]; pu.cam_pos[:] = cu.cam_pos[:]
-        bgs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
-        depths = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(2)]
+        bgs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(slots)]
+        depths = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(slots)]
         torch.cuda.synchronize()
 
     comp_ms, total_ms, pairs = [], [], []
@@ -200,12 +212,12 @@ def main():
     last = [None]
 
     def submit(i):
-        # the frame runs on its slot's own stream (two frames overlap on the GPU); the all-gather of frame i is
+        # the frame runs on its slot's own stream (the frames in flight overlap on the GPU); the all-gather of frame i is
         # queued on the ctx stream behind a device-side fence, AFTER frame i+1 has been submitted
-        o = outs[i % 2]
+        o = outs[i % slots]
         bgp = dpp = 0
         if use_passes:      # state.rs:384-392: skybox, then proxy (colour + depth), then the splats over them
-            bgp, dpp = bgs[i % 2].data_ptr(), depths[i % 2].data_ptr()
+            bgp, dpp = bgs[i % slots].data_ptr(), depths[i % slots].data_ptr()
             r.skybox_render(cu, W, H, bgp)
             r.proxy_render(pu, W, H, bgp, dpp, True)
         timed = args.timing > 0 and i % max(1, args.timing_every) == 0
@@ -235,7 +247,7 @@ def main():
     def run(n):
         for i in range(n):
             submit(i)
-            if len(inflight) == 2:
+            if len(inflight) == slots:
                 collect()
         while inflight:
             collect()
@@ -253,7 +265,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     last = last[0]
-    out = outs[(args.steps - 1) % 2]
+    out = outs[(args.steps - 1) % slots]
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -311,7 +323,7 @@ def main():
                        "transmittance_eps": args.t_eps, "skybox_proxy_passes": bool(use_passes),
                        "parallelism": f"screen-tile-column bands x{world} (projection culled per band) + RCCL all-gather" if world > 1 else "single GPU"},
             "stage_ms": {k: float(last[k]) for k in ("ms_project", "ms_emit", "ms_sort", "ms_ranges", "ms_composite", "ms_composite_kernel", "ms_total")},
-            "frames_in_flight": 2,
+            "frames_in_flight": slots,
             "roofline": {"bound": "hbm", "kernel": "k_composite", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": comp * 1e3, "kernel_ms_samples": len(comp_ms), "timed_every": max(1, args.timing_every),

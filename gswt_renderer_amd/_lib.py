@@ -116,6 +116,7 @@ SYMBOLS = {
     "gswt_render_async": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, C.POINTER(C.c_int)]),
     "gswt_render_wait": (C.c_int, [_P, C.c_int]),
     "gswt_render_fence": (C.c_int, [_P, C.c_int]),
+    "gswt_frame_slots": (C.c_int, []),
     "gswt_skybox_configure": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "gswt_skybox_render": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "gswt_proxy_configure": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),

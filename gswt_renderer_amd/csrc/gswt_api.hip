@@ -76,7 +76,9 @@ struct ListRef { uint32_t pair_base, pair_count, self_base, self_count; };
 
 }  // namespace
 
-constexpr int kFrameSlots = 2;
+// Three frame slots: c3 4 220 (two) -> 4 600 frames/s (three); four slots are SLOWER (4 190, also with three in flight: the
+// frames then rotate over four sets of per-frame buffers and the working set outgrows the Infinity Cache).
+constexpr int kFrameSlots = 3;
 
 struct FrameArgs {
     gswt_camera_uniforms cam;
@@ -94,6 +96,7 @@ struct FrameSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};
     hipEvent_t ev_in = nullptr;            // recorded on the ctx stream at enqueue: the frame starts after it
+    unsigned long long seq = 0;            // submission order of the frame in this slot
     unsigned long long* hc = nullptr;      // pinned host: [0] visible [1] pairs [2] scratch [3] overflow ... [7] staging
     unsigned long long* hc_dev = nullptr;  // the same words as the device sees them (k_combine writes [0..3] at the end of a frame)
     bool pending = false;
@@ -122,7 +125,7 @@ struct FrameSlot {
 struct gswt_ctx {
     int device = 0;
     FrameSlot slots[kFrameSlots];
-    int next_slot = 0;
+    unsigned long long frame_seq = 0;      // frames submitted through gswt_render_async
     hipStream_t stream = nullptr;
     bool own_stream = true;
     std::string err;
@@ -881,18 +884,27 @@ int gswt_render_async(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_s
     int rc = validate_frame(c, cam, su, cfg, width, height, out_rgba_dev);
     if (rc != GSWT_OK) return rc;
     hipSetDevice(c->device);
-    const int si = c->next_slot;
+    // lowest free slot (a caller that keeps fewer frames in flight than there are slots then cycles over fewer buffer sets:
+    // the per-frame buffers of a c5-sized frame are ~5 GB per slot); all busy: the oldest frame is collected first
+    int si = -1;
+    for (int k = 0; k < kFrameSlots; k++) if (!c->slots[k].pending) { si = k; break; }
+    if (si < 0) {
+        si = 0;
+        for (int k = 1; k < kFrameSlots; k++) if (c->slots[k].seq < c->slots[si].seq) si = k;
+    }
     FrameSlot& sl = c->slots[si];
     if (sl.pending) { sl.pending = false; rc = finish_frame(c, sl); if (rc != GSWT_OK) return rc; }
+    sl.seq = ++c->frame_seq;
     fill_args(sl.args, cam, su, cfg, width, height, reinterpret_cast<const float4*>(bg_rgba_dev), bg_depth_dev,
               reinterpret_cast<float4*>(out_rgba_dev));
     rc = enqueue_frame(c, sl);
     if (rc != GSWT_OK) return rc;
     sl.pending = true;
-    c->next_slot = (si + 1) % kFrameSlots;
     *ticket = si;
     return GSWT_OK;
 }
+
+int gswt_frame_slots(void) { return kFrameSlots; }
 
 int gswt_render_wait(gswt_ctx* c, int ticket)
 {

@@ -184,6 +184,10 @@ class GSWTRenderer:
                                                 C.c_void_p(out_device_ptr), C.byref(ticket)))
         return ticket.value
 
+    def frame_slots(self) -> int:
+        """Frames that may be in flight at once (render_async tickets)."""
+        return int(self._lib.gswt_frame_slots())
+
     def render_wait(self, ticket: int):
         self._check(self._lib.gswt_render_wait(self._h, ticket))
 

@@ -235,21 +235,22 @@ GSWT_API int gswt_render(gswt_ctx *ctx, const gswt_camera_uniforms *camera,
  * display refresh; with the device library the next frame can be queued while the previous one is still
  * executing).  All pointers are DEVICE pointers.  gswt_render_async enqueues the frame and returns a
  * ticket; gswt_render_wait(ticket) blocks the host until it finished, re-runs it if the pair buffers had
- * to grow, and makes gswt_last_timings refer to it.  At most two frames may be in flight (enqueuing a
- * third waits for the oldest).  Each frame in flight runs on its own internal stream with its own
- * per-frame buffers, so two frames OVERLAP on the GPU; frames in flight together must write different
- * output buffers.  Ordering against the ctx stream (gswt_set_stream):
+ * to grow, and makes gswt_last_timings refer to it.  At most gswt_frame_slots() (= 3) frames may be in
+ * flight (enqueuing one more waits for the oldest).  Each frame in flight runs on its own internal stream
+ * with its own per-frame buffers, so the frames OVERLAP on the GPU; frames in flight together must write
+ * different output buffers.  Ordering against the ctx stream (gswt_set_stream):
  *   - a frame starts after all work submitted to the ctx stream before its gswt_render_async call
  *     (producers of bg_*, earlier consumers of out_rgba_dev);
  *   - gswt_render_fence(ticket) makes the ctx stream wait (on the device) for that frame, so work
  *     submitted to the ctx stream afterwards sees its output (e.g. the RCCL all-gather of the shards).
- *     To keep two frames overlapped, submit frame i+1 BEFORE fencing frame i.  A fenced consumer sees
+ *     To keep the frames overlapped, submit the following frame(s) BEFORE fencing frame i.  A fenced consumer sees
  *     an incomplete image in the rare frame whose pair buffers overflowed (first frames after a scene
  *     change; gswt_render_wait re-runs it) -- warm up before relying on fences. */
 GSWT_API int gswt_render_async(gswt_ctx *ctx, const gswt_camera_uniforms *camera,
                                const gswt_scene_uniforms *scene, const gswt_render_config *cfg,
                                int width, int height, const float *bg_rgba_dev, const float *bg_depth_dev,
                                float *out_rgba_dev, int *ticket);
+GSWT_API int gswt_frame_slots(void);   /* frames that may be in flight at once */
 GSWT_API int gswt_render_wait(gswt_ctx *ctx, int ticket);
 GSWT_API int gswt_render_fence(gswt_ctx *ctx, int ticket);
 

@@ -205,6 +205,34 @@ def test_async_pipelined_frames_match_sync(renderer):
     assert renderer.timings()["n_pairs"] > 0
 
 
+def test_async_all_slots_in_flight_and_slot_reuse(renderer):
+    """Every frame slot in flight at once, then more frames than slots without a wait in between (the library collects
+    the oldest frame itself and reuses its slot), then waits in submission order: every image equals the synchronous one."""
+    import torch
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=700)
+    pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer)
+    W, Hh = 240, 160
+    pos = (4.2, 1.0, 2.0)
+    slots = renderer.frame_slots()
+    assert slots >= 2
+    n = 2 * slots + 1
+    tgts = [(5.0 - 0.3 * k, 3.0 + 0.2 * k, 1.5 - 0.05 * k) for k in range(n)]
+    cams = [host.camera_uniforms(pos, t, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh) for t in tgts]
+    pipe.update(pos, cams[0][1])
+    su = pipe.wang.scene_uniforms()
+    want = [renderer.render(cu, su, W, Hh) for cu, _ in cams]
+    outs = [torch.zeros((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+    torch.cuda.synchronize()
+    tickets = [renderer.render_async(cu, su, W, Hh, o.data_ptr()) for (cu, _), o in zip(cams, outs)]
+    assert set(tickets) == set(range(slots))              # tickets are slot indices; the slots were reused
+    for t in tickets[-slots:]:                            # only the last `slots` frames are still in flight
+        renderer.render_wait(t)
+    torch.cuda.synchronize()
+    for o, wimg in zip(outs, want):
+        assert np.array_equal(o.cpu().numpy(), wimg)
+
+
 def test_device_side_merged_lists_bit_exact(renderer):
     """gswt_set_draws_merge_groups: the merged-group lists built on the GPU (segmented stable radix sort on
     (group, 16-bit depth bucket)) equal the host's Scene::sort_raw_depth_vec lists entry for entry, and the
