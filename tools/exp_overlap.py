@@ -24,7 +24,7 @@ def make_ctx():
     wang.upload_to(r)
     r.configure(None)
     r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
-    outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+    outs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(r.frame_slots())]
     return r, st, outs
 
 
@@ -41,8 +41,8 @@ def run(K, n):
     for i in range(n):
         k = i % K
         r, st, outs = ctxs[k]
-        infl[k].append(r.render_async(cu, su, W, H, outs[(i // K) % 2].data_ptr(), transmittance_eps=1e-5))
-        if len(infl[k]) == 2:
+        infl[k].append(r.render_async(cu, su, W, H, outs[(i // K) % r.frame_slots()].data_ptr(), transmittance_eps=1e-5))
+        if len(infl[k]) == r.frame_slots():
             r.render_wait(infl[k].pop(0))
     for k in range(K):
         while infl[k]:

@@ -16,7 +16,7 @@ r = GSWTRenderer(0)
 wang.upload_to(r)
 r.configure(None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
-outs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+outs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(r.frame_slots())]
 
 
 def throughput(n):
@@ -24,8 +24,8 @@ def throughput(n):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(n):
-        infl.append(r.render_async(cu, su, W, H, outs[i % 2].data_ptr(), transmittance_eps=1e-5))
-        if len(infl) == 2:
+        infl.append(r.render_async(cu, su, W, H, outs[i % r.frame_slots()].data_ptr(), transmittance_eps=1e-5))
+        if len(infl) == r.frame_slots():
             r.render_wait(infl.pop(0))
     while infl:
         r.render_wait(infl.pop(0))
@@ -45,5 +45,5 @@ r.set_option(L.GSWT_OPT_TIMING, 0)
 for name, flags in (("full", 0), ("no walk", 1), ("no staging, no walk", 4), ("no pairs at all", 8)):
     r.set_option(L.GSWT_OPT_DEBUG_FLAGS, flags)
     throughput(20); latency(10)
-    print(f"{name:22s}: two in flight {throughput(200):6.1f} us/frame, one at a time {latency(60):6.1f} us/frame", flush=True)
+    print(f"{name:22s}: all slots in flight {throughput(200):6.1f} us/frame, one at a time {latency(60):6.1f} us/frame", flush=True)
 r.set_option(L.GSWT_OPT_DEBUG_FLAGS, 0)

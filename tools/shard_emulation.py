@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What one rank of an N-GPU run does, measured on ONE GPU: shard r of N of the c3 frame (interleaved tile rows, and
-contiguous tile-column bands with per-band draw culling), two frames in flight, no all-gather.  max over r of the
+contiguous tile-column bands with per-band draw culling), every frame slot in flight, no all-gather.  max over r of the
 per-rank frame time bounds the N-GPU frame rate from above."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +21,7 @@ r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lo
 for mode, N in [("rows", 1), ("rows", 2), ("rows", 4), ("rows", 8), ("cols", 2), ("cols", 4), ("cols", 8)]:
     rows = r.shard_rows_padded(H, N) if (N > 1 and mode == "rows") else H
     cols = r.shard_cols_padded(W, N) if (N > 1 and mode == "cols") else W
-    outs = [torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+    outs = [torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda") for _ in range(r.frame_slots())]
     worst = 0.0
     vis = []
     for rank in range(N):
@@ -30,8 +30,8 @@ for mode, N in [("rows", 1), ("rows", 2), ("rows", 4), ("rows", 8), ("cols", 2),
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(n):
-                infl.append(r.render_async(cu, su, W, H, outs[i % 2].data_ptr(), transmittance_eps=1e-5, shard=(rank, N, mode) if mode == "cols" else (rank, N)))
-                if len(infl) == 2:
+                infl.append(r.render_async(cu, su, W, H, outs[i % r.frame_slots()].data_ptr(), transmittance_eps=1e-5, shard=(rank, N, mode) if mode == "cols" else (rank, N)))
+                if len(infl) == r.frame_slots():
                     r.render_wait(infl.pop(0))
             while infl:
                 r.render_wait(infl.pop(0))
