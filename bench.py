@@ -40,7 +40,7 @@ def build_workload(name: str, lod0_override: int | None = None):
     wang = host.WangTile(ts)
     user = host.user_data(tile_map_half_wh=w["half"], **w["user"])
     wang.configure(user)
-    cam = workloads.DEFAULT_CAMERA
+    cam = workloads.camera_for(name)
     cu, vp = host.camera_uniforms(cam["pos"], cam["target"], cam["up"], cam["fovy"], cam["near"], cam["far"], w["width"], w["height"])
     wang.build_tiles(cam["pos"])
     sort = wang.sort_tiles(cam["pos"], vp)
@@ -87,6 +87,44 @@ def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, he
     img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads, bg_rgba=bg, bg_depth=bgd, height_map=height_map)
     dt = time.perf_counter() - t0
     return img, st, dt, n_threads
+
+
+def make_passes(r, su, cu):
+    """Synthetic inputs of the skybox and proxy passes (BASELINE config 5): a sky cube that is smooth in direction, a checker
+    proxy texture with its mip chain, a `proxy_map` grid at z = -0.5.  Configures them on renderer `r`; returns
+    (faces, mips, proxy uniforms) so that the oracle can be fed the same."""
+    from gswt_renderer_amd import _lib as L
+    # synthetic sky cube (smooth in direction) and proxy texture (checker mip chain); proxy_map grid at z = -0.5
+    n = 256
+    faces = np.zeros((6, n, n, 4), np.float32)
+    tt, ss = np.meshgrid((np.arange(n) + .5) / n * 2 - 1, (np.arange(n) + .5) / n * 2 - 1, indexing="ij")
+    one = np.ones_like(ss)
+    dirs = {0: (one, -tt, -ss), 1: (-one, -tt, ss), 2: (ss, one, tt), 3: (ss, -one, -tt), 4: (ss, -tt, one), 5: (-ss, -tt, -one)}
+    for fi in range(6):
+        dv = np.stack(dirs[fi], -1)
+        dv /= np.linalg.norm(dv, axis=-1, keepdims=True)
+        faces[fi, ..., :3] = 0.5 + 0.4 * dv
+        faces[fi, ..., 3] = 1.0
+    ts = 512
+    yy, xx = np.mgrid[0:ts, 0:ts]
+    cur = np.zeros((ts, ts, 4), np.float32)
+    cur[..., 0] = ((xx // 32 + yy // 32) % 2) * 0.6 + 0.2
+    cur[..., 1] = 0.35; cur[..., 2] = 0.25; cur[..., 3] = 1.0
+    mips = []
+    while True:
+        mips.append(cur.copy())
+        if cur.shape[0] == 1:
+            break
+        cur = cur.reshape(cur.shape[0] // 2, 2, cur.shape[1] // 2, 2, 4).mean((1, 3)).astype(np.float32)
+    r.skybox_configure(faces)
+    r.proxy_configure(mips)
+    pu = L.ProxyUniforms()
+    pu.height_offset, pu.tile_width, pu.surface_type, pu.width_scale = -0.5, su.tile_width, 0, 4.0
+    pu.map_proxy, pu.use_clip, pu.clip_height, pu.brightness, pu.black_background = 1, 0, 0.0, 1.0, 0
+    pu.view[:] = cu.view[:]; pu.projection[:] = cu.projection[:]
+    pu.map_half_wh[:] = su.map_half_wh[:]; pu.center_coord[:] = su.center_coord[:]
+    pu.height_map_scale[:] = su.height_map_scale[:]; pu.cam_pos[:] = cu.cam_pos[:]
+    return faces, mips, pu
 
 
 def main():
@@ -173,36 +211,7 @@ def main():
     bgs = depths = None
     pu = None
     if use_passes:
-        # synthetic sky cube (smooth in direction) and proxy texture (checker mip chain); proxy_map grid at z = -0.5
-        n = 256
-        faces = np.zeros((6, n, n, 4), np.float32)
-        tt, ss = np.meshgrid((np.arange(n) + .5) / n * 2 - 1, (np.arange(n) + .5) / n * 2 - 1, indexing="ij")
-        one = np.ones_like(ss)
-        dirs = {0: (one, -tt, -ss), 1: (-one, -tt, ss), 2: (ss, one, tt), 3: (ss, -one, -tt), 4: (ss, -tt, one), 5: (-ss, -tt, -one)}
-        for fi in range(6):
-            dv = np.stack(dirs[fi], -1)
-            dv /= np.linalg.norm(dv, axis=-1, keepdims=True)
-            faces[fi, ..., :3] = 0.5 + 0.4 * dv
-            faces[fi, ..., 3] = 1.0
-        ts = 512
-        yy, xx = np.mgrid[0:ts, 0:ts]
-        cur = np.zeros((ts, ts, 4), np.float32)
-        cur[..., 0] = ((xx // 32 + yy // 32) % 2) * 0.6 + 0.2
-        cur[..., 1] = 0.35; cur[..., 2] = 0.25; cur[..., 3] = 1.0
-        mips = []
-        while True:
-            mips.append(cur.copy())
-            if cur.shape[0] == 1:
-                break
-            cur = cur.reshape(cur.shape[0] // 2, 2, cur.shape[1] // 2, 2, 4).mean((1, 3)).astype(np.float32)
-        r.skybox_configure(faces)
-        r.proxy_configure(mips)
-        pu = L.ProxyUniforms()
-        pu.height_offset, pu.tile_width, pu.surface_type, pu.width_scale = -0.5, su.tile_width, 0, 4.0
-        pu.map_proxy, pu.use_clip, pu.clip_height, pu.brightness, pu.black_background = 1, 0, 0.0, 1.0, 0
-        pu.view[:] = cu.view[:]; pu.projection[:] = cu.projection[:]
-        pu.map_half_wh[:] = su.map_half_wh[:]; pu.center_coord[:] = su.center_coord[:]
-        pu.height_map_scale[:] = su.height_map_scale[:]; pu.cam_pos[:] = cu.cam_pos[:]
+        faces, mips, pu = make_passes(r, su, cu)
         bgs = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(slots)]
         depths = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(slots)]
         torch.cuda.synchronize()

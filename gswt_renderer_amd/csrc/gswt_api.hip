@@ -35,7 +35,8 @@ void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, MergeGroup*, uin
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, uint32_t, const uint32_t*, const uint32_t*,
                     const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, uint32_t*, uint32_t*,
-                    unsigned long long*, Varyings*, float4*);
+                    unsigned long long*, Varyings*, float4*, uint32_t);
+void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
                  uint32_t*, uint32_t*);
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*);
@@ -99,7 +100,10 @@ struct FrameSlot {
     unsigned long long seq = 0;            // submission order of the frame in this slot
     unsigned long long* hc = nullptr;      // pinned host: [0] visible [1] pairs [2] scratch [3] overflow ... [7] staging
     unsigned long long* hc_dev = nullptr;  // the same words as the device sees them (k_combine writes [0..3] at the end of a frame)
-    bool pending = false;
+    bool pending = false;                  // submitted through gswt_render_async, ticket not yet handed back by gswt_render_wait
+    bool collected = false;                // finish_frame already ran for the pending frame (fence / gswt_set_draws*): its status and
+    int collected_rc = 0;                  // timings wait here for gswt_render_wait
+    gswt_timings collected_timings = {};
     FrameArgs args;
     uint32_t cap = 0;
     int n_tiles = 0;
@@ -176,6 +180,7 @@ struct gswt_ctx {
     int opt_dbg_flags = 0;
     int opt_timing = 2;      // 0: no events, 1: frame + k_composite, 2: every stage
     int opt_segment = 512;   // pairs per compositor work item (multiple of 256); c3 sweep: 512 best
+    int opt_fixed_pair_cap = 0;   // test hook (GSWT_OPT_PAIR_CAP): the pair capacity is pinned until a frame overflows it
     uint32_t last_n_tiles = 0;
     gswt_timings timings = {};
 };
@@ -202,6 +207,12 @@ hipError_t sync_all(gswt_ctx* c)
     return e;
 }
 
+// No C++ exception may unwind through the C ABI: every extern "C" body that returns a status is a function-try-block
+// closed by this handler (std::vector / std::string allocations of the draw-list code are the throwing sites).
+#define GSWT_CATCH(NAME)                                                                   \
+    catch (const std::bad_alloc&) { return GSWT_ERR_CAPACITY; }                             \
+    catch (...) { return GSWT_ERR_HIP; }
+
 #define HIP_TRY(c, expr)                                                                              \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \
@@ -221,10 +232,26 @@ void mat4_mul(const float* a, const float* b, float* out)
 
 }  // namespace
 
+static int finish_frame(gswt_ctx* c, FrameSlot& sl);
+
+// Runs every frame still in flight to completion (including the re-run of a frame whose pair buffers overflowed) while the
+// state it was submitted with -- scene, draw list, capacities -- is still in place; the status and timings wait in the slot
+// for the ticket's gswt_render_wait.  Called before anything that changes that state.
+static hipError_t collect_pending(gswt_ctx* c)
+{
+    for (auto& sl : c->slots)
+        if (sl.pending && !sl.collected) {
+            sl.collected_rc = finish_frame(c, sl);
+            sl.collected_timings = c->timings;
+            sl.collected = true;
+        }
+    return sync_all(c);
+}
+
 extern "C" {
 
 int gswt_create(int device_id, gswt_ctx** out)
-{
+try {
     if (!out) return GSWT_ERR_BAD_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -246,7 +273,7 @@ int gswt_create(int device_id, gswt_ctx** out)
     }
     *out = c;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_create")
 
 void gswt_destroy(gswt_ctx* c)
 {
@@ -270,40 +297,44 @@ void gswt_destroy(gswt_ctx* c)
 const char* gswt_last_error(const gswt_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
 int gswt_set_stream(gswt_ctx* c, void* hip_stream)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
-    sync_all(c);
+    collect_pending(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_set_stream")
 
 int gswt_set_option(gswt_ctx* c, int key, int value)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     switch (key) {
     case GSWT_OPT_NO_LOD_PREFILTER: c->opt_no_prefilter = value; c->draws_ready = false; return GSWT_OK;
     case GSWT_OPT_DEBUG_VARYINGS: c->opt_debug_varyings = value; return GSWT_OK;
     case GSWT_OPT_DEBUG_FLAGS: c->opt_dbg_flags = value; return GSWT_OK;
     case GSWT_OPT_TIMING: c->opt_timing = value; return GSWT_OK;
+    case GSWT_OPT_PAIR_CAP:
+        if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "pair capacity must be >= 0");
+        c->opt_fixed_pair_cap = value > 0; if (value > 0) c->pair_cap = (uint32_t)value;
+        return GSWT_OK;
     case GSWT_OPT_SEGMENT:
         if (value < 256 || value % 256) return fail(c, GSWT_ERR_BAD_ARG, "segment must be a positive multiple of 256");
         c->opt_segment = value; return GSWT_OK;
     default: return fail(c, GSWT_ERR_BAD_ARG, "unknown option %d", key);
     }
-}
+} GSWT_CATCH("gswt_set_option")
 
 int gswt_upload_scene(gswt_ctx* c, const uint32_t* tex_data, size_t n_splats, const gswt_base_list* lists, int n_lod,
                       int n_tile, int n_view)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     if (!tex_data || n_splats == 0 || !lists || n_lod <= 0 || n_tile <= 0 || n_view <= 0)
         return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_scene: empty scene");
     if (n_lod > 16) return fail(c, GSWT_ERR_BAD_ARG, "gswt_upload_scene: n_lod %d > 16 (transition_dist_vec holds 16)", n_lod);
     if (n_splats > (size_t)kIdxMask) return fail(c, GSWT_ERR_CAPACITY, "gswt_upload_scene: %zu splats exceed 2^28", n_splats);
     hipSetDevice(c->device);
-    HIP_TRY(c, sync_all(c));
+    HIP_TRY(c, collect_pending(c));
     c->scene_ready = false; c->draws_ready = false;
     HIP_TRY(c, c->tex.ensure(2 * n_splats));
     HIP_TRY(c, hipMemcpy(c->tex.p, tex_data, n_splats * 32, hipMemcpyHostToDevice));
@@ -338,19 +369,19 @@ int gswt_upload_scene(gswt_ctx* c, const uint32_t* tex_data, size_t n_splats, co
     c->n_lod = n_lod; c->n_tile = n_tile; c->n_view = n_view;
     c->scene_ready = true;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_upload_scene")
 
 int gswt_configure(gswt_ctx* c, const float* height_map, int hm_w, int hm_h)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     hipSetDevice(c->device);
-    HIP_TRY(c, sync_all(c));
+    HIP_TRY(c, collect_pending(c));
     if (!height_map || hm_w <= 0 || hm_h <= 0) { c->hm_w = c->hm_h = 0; return GSWT_OK; }
     HIP_TRY(c, c->hmap.ensure((size_t)hm_w * hm_h));
     HIP_TRY(c, hipMemcpy(c->hmap.p, height_map, (size_t)hm_w * hm_h * 4, hipMemcpyHostToDevice));
     c->hm_w = hm_w; c->hm_h = hm_h;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_configure")
 
 // Shared by gswt_set_draws (merged arrays from the host) and gswt_set_draws_merge_groups (built on the device:
 // merged_gs_index == nullptr && device_merge).
@@ -363,7 +394,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     if (!device_merge && n_merged && (!merged_gs_index || !merged_map_id)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged arrays missing");
     if (n_merged >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: merged lists exceed 2^32 entries");
     hipSetDevice(c->device);
-    HIP_TRY(c, sync_all(c));
+    HIP_TRY(c, collect_pending(c));      // a frame in flight is finished (and re-run if it overflowed) against the draws it was submitted with
     c->draws_ready = false;
     std::vector<DrawDev> dd((size_t)n_draws);
     uint64_t entries = 0;
@@ -465,12 +496,12 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
 
 int gswt_set_draws(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint32_t* merged_gs_index,
                    const uint32_t* merged_map_id, const uint32_t* merged_lod_id, size_t n_merged)
-{
+try {
     return set_draws_impl(c, draws, n_draws, merged_gs_index, merged_map_id, merged_lod_id, n_merged, false);
-}
+} GSWT_CATCH("gswt_set_draws")
 
 int gswt_upload_raw_depth(gswt_ctx* c, const int32_t* const* raw_depth, const uint32_t* counts, const uint32_t* merge_offset)
-{
+try {
     if (!c || !raw_depth || !counts || !merge_offset) return GSWT_ERR_BAD_ARG;
     if (!c->scene_ready) return fail(c, GSWT_ERR_STATE, "gswt_upload_raw_depth before gswt_upload_scene");
     hipSetDevice(c->device);
@@ -491,11 +522,11 @@ int gswt_upload_raw_depth(gswt_ctx* c, const int32_t* const* raw_depth, const ui
     HIP_TRY(c, c->raw_depth.ensure(total + 1));
     if (total) HIP_TRY(c, hipMemcpy(c->raw_depth.p, arena.data(), total * 4, hipMemcpyHostToDevice));
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_upload_raw_depth")
 
 int gswt_set_draws_merge_groups(gswt_ctx* c, const gswt_draw* draws, int n_draws, const gswt_merge_group* groups, int n_groups,
                                 const gswt_merge_member* members, int n_members)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     if (n_groups < 0 || n_members < 0 || (n_groups && (!groups || !members))) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: bad groups");
     if (n_groups && c->raw_cnt.empty()) return fail(c, GSWT_ERR_STATE, "gswt_set_draws_merge_groups before gswt_upload_raw_depth");
@@ -561,10 +592,10 @@ int gswt_set_draws_merge_groups(gswt_ctx* c, const gswt_draw* draws, int n_draws
     HIP_TRY(c, hipStreamSynchronize(s));
     c->draws_ready = true;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_set_draws_merge_groups")
 
 int gswt_debug_read_merged(gswt_ctx* c, uint32_t* packed_list, uint32_t* map_id, size_t capacity, size_t* n)
-{
+try {
     if (!c || !n) return GSWT_ERR_BAD_ARG;
     *n = c->n_merged;
     if (!packed_list || !map_id) return GSWT_OK;
@@ -576,30 +607,30 @@ int gswt_debug_read_merged(gswt_ctx* c, uint32_t* packed_list, uint32_t* map_id,
         HIP_TRY(c, hipMemcpy(map_id, c->merged_map.p, c->n_merged * 4, hipMemcpyDeviceToHost));
     }
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_debug_read_merged")
 
 int gswt_shard_rows_padded(int height, int shard_count)
-{
+try {
     int tiles_y = (height + kTile - 1) / kTile;
     int sc = shard_count <= 1 ? 1 : shard_count;
     return ((tiles_y + sc - 1) / sc) * kTile;
-}
+} GSWT_CATCH("gswt_shard_rows_padded")
 
 int gswt_shard_cols_padded(int width, int shard_count)
-{
+try {
     int tiles_x = (width + kTile - 1) / kTile;
     int sc = shard_count <= 1 ? 1 : shard_count;
     return ((tiles_x + sc - 1) / sc) * kTile;
-}
+} GSWT_CATCH("gswt_shard_cols_padded")
 
 int gswt_shard_rows(int height, int shard_index, int shard_count)
-{
+try {
     int sc = shard_count <= 1 ? 1 : shard_count;
     if (shard_index < 0 || shard_index >= sc) return 0;
     int rows = 0;
     for (int y = 0; y < height; y++) if (((y / kTile) % sc) == shard_index) rows++;
     return rows;
-}
+} GSWT_CATCH("gswt_shard_rows")
 
 // ---- frame machinery ------------------------------------------------------------------------------
 // A frame is enqueued without any host round trip (enqueue_frame) and collected later (finish_frame).
@@ -759,7 +790,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
     launch_project(s, dbg, f, c->draws.p, c->chunk_tab_xcd.p, c->n_launch, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, sl.block_sums.p, d_super,
-                   d_counters, c->dbg.p, sl.col_f.p);
+                   d_counters, c->dbg.p, sl.col_f.p, cap);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
     // ---- emit
     if (!depth_order) {
@@ -807,26 +838,26 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
         if (P64 >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: %llu pairs exceed 2^32", P64);
         if (sl.hc[3] == 0 && P64 <= sl.cap) break;
         if (attempt >= 2) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");
-        c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 4 + 4096, 0xFFFFFF00ull));
+        c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 2 + 4096, 0xFFFFFF00ull));
         int rc = enqueue_frame(c, sl);
         if (rc != GSWT_OK) return rc;
     }
     const uint32_t P = (uint32_t)sl.hc[1];
-    // keep ~25 % headroom over the running pair count without shrinking on every small dip
-    if ((uint64_t)P + P / 8 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 4 + 4096, 0xFFFFFF00ull);
+    // keep 25-50 % headroom over the running pair count without shrinking on every small dip
+    if (!c->opt_fixed_pair_cap && (uint64_t)P + P / 4 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 2 + 4096, 0xFFFFFF00ull);
     gswt_timings& t = c->timings;
     memset(&t, 0, sizeof(t));
     hipEvent_t* ev = sl.ev;
     if (sl.timing_level >= 2) {
-        hipEventElapsedTime(&t.ms_project, ev[0], ev[1]);
-        hipEventElapsedTime(&t.ms_emit, ev[1], ev[3]);
-        hipEventElapsedTime(&t.ms_sort, ev[3], ev[4]);
-        hipEventElapsedTime(&t.ms_ranges, ev[4], ev[5]);
-        hipEventElapsedTime(&t.ms_composite, ev[5], ev[6]);
+        HIP_TRY(c, hipEventElapsedTime(&t.ms_project, ev[0], ev[1]));
+        HIP_TRY(c, hipEventElapsedTime(&t.ms_emit, ev[1], ev[3]));
+        HIP_TRY(c, hipEventElapsedTime(&t.ms_sort, ev[3], ev[4]));
+        HIP_TRY(c, hipEventElapsedTime(&t.ms_ranges, ev[4], ev[5]));
+        HIP_TRY(c, hipEventElapsedTime(&t.ms_composite, ev[5], ev[6]));
     }
     if (sl.timing_level >= 1) {
-        hipEventElapsedTime(&t.ms_total, ev[0], ev[6]);
-        hipEventElapsedTime(&t.ms_composite_kernel, ev[7], ev[8]);
+        HIP_TRY(c, hipEventElapsedTime(&t.ms_total, ev[0], ev[6]));
+        HIP_TRY(c, hipEventElapsedTime(&t.ms_composite_kernel, ev[7], ev[8]));
     }
     t.n_draws = c->n_draws; t.n_instanced = c->n_entries; t.n_visible = sl.hc[0]; t.n_pairs = P; t.n_tiles = (uint32_t)sl.n_tiles;
     return GSWT_OK;
@@ -841,14 +872,13 @@ static void fill_args(FrameArgs& a, const gswt_camera_uniforms* cam, const gswt_
 int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_uniforms* su, const gswt_render_config* cfg,
                 int width, int height, const float* bg_rgba, const float* bg_depth, int bg_on_device, float* out_rgba,
                 int out_on_device)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     int rc = validate_frame(c, cam, su, cfg, width, height, out_rgba);
     if (rc != GSWT_OK) return rc;
     hipSetDevice(c->device);
     hipStream_t s = c->stream;
-    for (auto& sl : c->slots)                      // collect anything still in flight from the async API
-        if (sl.pending) { sl.pending = false; rc = finish_frame(c, sl); if (rc != GSWT_OK) return rc; }
+    HIP_TRY(c, collect_pending(c));                // frames still in flight from the async API keep their tickets
     const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
     const bool cols = sc > 1 && cfg->shard_mode == GSWT_SHARD_COLUMNS;
     const int out_rows = sc > 1 && !cols ? gswt_shard_rows_padded(height, sc) : height;
@@ -864,7 +894,10 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
     }
     if (out_on_device) d_out = reinterpret_cast<float4*>(out_rgba);
     else { HIP_TRY(c, c->out_img.ensure(out_px)); d_out = c->out_img.p; }
-    FrameSlot& sl = c->slots[0];
+    int si0 = 0;
+    for (int k = 0; k < kFrameSlots; k++) if (!c->slots[k].pending) { si0 = k; break; }
+    FrameSlot& sl = c->slots[si0];
+    if (sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render: every frame slot holds an uncollected gswt_render_async ticket");
     fill_args(sl.args, cam, su, cfg, width, height, d_bg, d_bgd, d_out);
     rc = enqueue_frame(c, sl);
     if (rc != GSWT_OK) return rc;
@@ -875,11 +908,11 @@ int gswt_render(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_u
         HIP_TRY(c, hipStreamSynchronize(s));
     }
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_render")
 
 int gswt_render_async(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_scene_uniforms* su, const gswt_render_config* cfg,
                       int width, int height, const float* bg_rgba_dev, const float* bg_depth_dev, float* out_rgba_dev, int* ticket)
-{
+try {
     if (!c || !ticket) return GSWT_ERR_BAD_ARG;
     int rc = validate_frame(c, cam, su, cfg, width, height, out_rgba_dev);
     if (rc != GSWT_OK) return rc;
@@ -893,41 +926,56 @@ int gswt_render_async(gswt_ctx* c, const gswt_camera_uniforms* cam, const gswt_s
         for (int k = 1; k < kFrameSlots; k++) if (c->slots[k].seq < c->slots[si].seq) si = k;
     }
     FrameSlot& sl = c->slots[si];
-    if (sl.pending) { sl.pending = false; rc = finish_frame(c, sl); if (rc != GSWT_OK) return rc; }
+    if (sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render_async: all %d frame slots are in flight; gswt_render_wait the oldest ticket first", kFrameSlots);
     sl.seq = ++c->frame_seq;
     fill_args(sl.args, cam, su, cfg, width, height, reinterpret_cast<const float4*>(bg_rgba_dev), bg_depth_dev,
               reinterpret_cast<float4*>(out_rgba_dev));
     rc = enqueue_frame(c, sl);
     if (rc != GSWT_OK) return rc;
-    sl.pending = true;
+    sl.pending = true; sl.collected = false;
     *ticket = si;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_render_async")
 
 int gswt_frame_slots(void) { return kFrameSlots; }
 
 int gswt_render_wait(gswt_ctx* c, int ticket)
-{
+try {
     if (!c || ticket < 0 || ticket >= kFrameSlots) return GSWT_ERR_BAD_ARG;
     FrameSlot& sl = c->slots[ticket];
     if (!sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render_wait: ticket %d is not in flight", ticket);
     hipSetDevice(c->device);
     sl.pending = false;
+    if (sl.collected) {                 // already finished by gswt_render_fence / a state change: hand back what it left
+        sl.collected = false;
+        c->timings = sl.collected_timings;
+        return sl.collected_rc;
+    }
     return finish_frame(c, sl);
-}
+} GSWT_CATCH("gswt_render_wait")
 
+// All-or-nothing, like GSWTRenderer::render (renderer.rs:407-414): work ordered behind the fence never reads a frame whose pair
+// buffers overflowed.  Overflow is only known once the frame's counters are back on the host, so the fence first waits
+// (host side) for THIS frame -- the younger frames in flight keep the GPU busy meanwhile --, lets finish_frame re-run it
+// with grown buffers if it has to, and only then orders the ctx stream behind the frame's final completion event.
 int gswt_render_fence(gswt_ctx* c, int ticket)
-{
+try {
     if (!c || ticket < 0 || ticket >= kFrameSlots) return GSWT_ERR_BAD_ARG;
     FrameSlot& sl = c->slots[ticket];
     if (!sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render_fence: ticket %d is not in flight", ticket);
     hipSetDevice(c->device);
+    if (!sl.collected) {
+        sl.collected_rc = finish_frame(c, sl);
+        sl.collected_timings = c->timings;
+        sl.collected = true;
+    }
+    if (sl.collected_rc != GSWT_OK) return sl.collected_rc;
     HIP_TRY(c, hipStreamWaitEvent(c->stream, sl.ev[9], 0));
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_render_fence")
 
 int gswt_skybox_configure(gswt_ctx* c, const float* faces_rgba, int face_size, int equirectangular)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     if (!faces_rgba || face_size <= 0 || face_size > 16384) return fail(c, GSWT_ERR_BAD_ARG, "gswt_skybox_configure: bad cube map");
     hipSetDevice(c->device);
@@ -937,10 +985,10 @@ int gswt_skybox_configure(gswt_ctx* c, const float* faces_rgba, int face_size, i
     HIP_TRY(c, hipMemcpy(c->sky_faces.p, faces_rgba, n * 16, hipMemcpyHostToDevice));
     c->sky_size = face_size; c->sky_equi = equirectangular ? 1 : 0;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_skybox_configure")
 
 int gswt_skybox_render(gswt_ctx* c, const gswt_camera_uniforms* cam, int width, int height, float* out_rgba_dev)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     if (!cam || !out_rgba_dev || width <= 0 || height <= 0) return fail(c, GSWT_ERR_BAD_ARG, "gswt_skybox_render: bad argument");
     if (c->sky_size == 0) return fail(c, GSWT_ERR_STATE, "gswt_skybox_render before gswt_skybox_configure");
@@ -950,10 +998,10 @@ int gswt_skybox_render(gswt_ctx* c, const gswt_camera_uniforms* cam, int width, 
                   reinterpret_cast<float4*>(out_rgba_dev));
     HIP_TRY(c, hipGetLastError());
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_skybox_render")
 
 int gswt_proxy_configure(gswt_ctx* c, const float* const* mips, int tex_size, int n_mips, int grid_dim)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     if (!mips || tex_size <= 0 || n_mips <= 0 || n_mips > 16 || (tex_size >> (n_mips - 1)) < 1 || grid_dim <= 0 || grid_dim > 32768)
         return fail(c, GSWT_ERR_BAD_ARG, "gswt_proxy_configure: bad mip chain / grid");
@@ -971,10 +1019,10 @@ int gswt_proxy_configure(gswt_ctx* c, const float* const* mips, int tex_size, in
         HIP_TRY(c, hipMemcpy(c->proxy_tex.p + c->proxy_mip_off[l], mips[l], (size_t)(tex_size >> l) * (tex_size >> l) * 16, hipMemcpyHostToDevice));
     c->proxy_size = tex_size; c->proxy_mips = n_mips; c->proxy_grid_dim = grid_dim;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_proxy_configure")
 
 int gswt_proxy_render(gswt_ctx* c, const gswt_proxy_uniforms* u, int width, int height, float* rgba_dev, float* depth_dev, int clear_depth)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     if (!u || !rgba_dev || !depth_dev || width <= 0 || height <= 0) return fail(c, GSWT_ERR_BAD_ARG, "gswt_proxy_render: bad argument");
     if (c->proxy_size == 0 && !u->black_background) return fail(c, GSWT_ERR_STATE, "gswt_proxy_render before gswt_proxy_configure");
@@ -1013,15 +1061,15 @@ int gswt_proxy_render(gswt_ctx* c, const gswt_proxy_uniforms* u, int width, int 
     launch_proxy(c->stream, a, c->hmap.p, c->proxy_tex.p, reinterpret_cast<float4*>(rgba_dev), depth_dev);
     HIP_TRY(c, hipGetLastError());
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_proxy_render")
 
 int gswt_unshard(gswt_ctx* c, const float* gathered, int width, int height, int shard_count, float* out_rgba)
-{
+try {
     return gswt_unshard_mode(c, gathered, width, height, shard_count, GSWT_SHARD_ROWS, out_rgba);
-}
+} GSWT_CATCH("gswt_unshard")
 
 int gswt_unshard_mode(gswt_ctx* c, const float* gathered, int width, int height, int shard_count, int shard_mode, float* out_rgba)
-{
+try {
     if (!c || !gathered || !out_rgba || width <= 0 || height <= 0 || shard_count < 1) return GSWT_ERR_BAD_ARG;
     if (shard_mode != GSWT_SHARD_ROWS && shard_mode != GSWT_SHARD_COLUMNS) return GSWT_ERR_BAD_ARG;
     hipSetDevice(c->device);
@@ -1030,25 +1078,45 @@ int gswt_unshard_mode(gswt_ctx* c, const float* gathered, int width, int height,
                    shard_mode == GSWT_SHARD_COLUMNS ? gswt_shard_cols_padded(width, shard_count) : 0);
     HIP_TRY(c, hipGetLastError());
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_unshard_mode")
 
 int gswt_synchronize(gswt_ctx* c)
-{
+try {
     if (!c) return GSWT_ERR_BAD_ARG;
     hipSetDevice(c->device);
     HIP_TRY(c, sync_all(c));
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_synchronize")
 
 int gswt_last_timings(const gswt_ctx* c, gswt_timings* out)
-{
+try {
     if (!c || !out) return GSWT_ERR_BAD_ARG;
     *out = c->timings;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_last_timings")
+
+int gswt_debug_totals(gswt_ctx* c, const uint32_t* pair_sums, const uint32_t* visible_sums, uint32_t n_super, uint32_t pair_cap,
+                      unsigned long long counters_out[4], uint32_t* super_excl_out)
+try {
+    if (!c || !pair_sums || !visible_sums || n_super == 0 || !counters_out) return GSWT_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    DevBuf<uint32_t> buf;
+    HIP_TRY(c, buf.ensure(3 * (size_t)n_super + 16));
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(buf.p + 3 * (size_t)n_super + (n_super & 1));
+    HIP_TRY(c, hipMemset(buf.p, 0, (3 * (size_t)n_super + 16) * 4));
+    HIP_TRY(c, hipMemcpy(buf.p, pair_sums, (size_t)n_super * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(buf.p + n_super, visible_sums, (size_t)n_super * 4, hipMemcpyHostToDevice));
+    launch_totals(c->stream, buf.p, n_super, d_cnt, pair_cap);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(counters_out, d_cnt, 32, hipMemcpyDeviceToHost));
+    if (super_excl_out) HIP_TRY(c, hipMemcpy(super_excl_out, buf.p + 2 * (size_t)n_super, (size_t)n_super * 4, hipMemcpyDeviceToHost));
+    buf.release();
+    return GSWT_OK;
+} GSWT_CATCH("gswt_debug_totals")
 
 int gswt_debug_read_ranges(gswt_ctx* c, uint32_t* out, size_t capacity_tiles, size_t* n_tiles)
-{
+try {
     if (!c || !n_tiles) return GSWT_ERR_BAD_ARG;
     *n_tiles = c->last_n_tiles;
     if (!out) return GSWT_OK;
@@ -1057,10 +1125,10 @@ int gswt_debug_read_ranges(gswt_ctx* c, uint32_t* out, size_t capacity_tiles, si
     HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(out, c->slots[c->last_slot].ranges.p, (size_t)c->last_n_tiles * 8, hipMemcpyDeviceToHost));
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_debug_read_ranges")
 
 int gswt_debug_read_projected(gswt_ctx* c, void* out, size_t capacity_entries, size_t* n_entries)
-{
+try {
     if (!c || !n_entries) return GSWT_ERR_BAD_ARG;
     *n_entries = (size_t)c->n_entries;
     if (!out) return GSWT_OK;
@@ -1070,6 +1138,6 @@ int gswt_debug_read_projected(gswt_ctx* c, void* out, size_t capacity_entries, s
     HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(out, c->dbg.p, (size_t)c->n_entries * sizeof(Varyings), hipMemcpyDeviceToHost));
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_debug_read_projected")
 
 }  // extern "C"

@@ -643,15 +643,19 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 // (c5: 1 430 per workgroup).  Single workgroup.  (Folding it into k_emit -- every workgroup sums the super-group counts
 // in front of it, workgroup 0 leaves the totals -- was measured: k_emit +6 us for the 4.6 us saved, 4015 -> 3881 frames/s.)
 __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ super_sums, uint32_t n_super,
-                                                unsigned long long* __restrict__ counters, uint32_t* __restrict__ super_excl)
+                                                unsigned long long* __restrict__ counters, uint32_t* __restrict__ super_excl, uint32_t pair_cap)
 {
     __shared__ unsigned long long s_v[4];
     __shared__ uint32_t s_w[4];
     unsigned long long v = 0;
-    uint32_t carry = 0;
+    // the frame's pair count is carried in 64 bits (a super-group sum is a u32 of at most 65 536 slots x #screen tiles); the
+    // prefix words k_emit reads stay 32-bit: once the running total passes the pair capacity the frame is flagged as
+    // overflowed right here, and nothing downstream of k_emit consumes pairs of a flagged frame
+    unsigned long long carry = 0;
     for (uint32_t base = 0; base < n_super; base += 1024u) {
         const uint32_t i = base + threadIdx.x * 4u;
-        uint32_t p[4], sum = 0;
+        uint32_t p[4];
+        unsigned long long sum = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t idx = min(i + (uint32_t)k, n_super - 1u);              // clamped, unmasked loads
@@ -660,16 +664,26 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ sup
             v += i + k < n_super ? vv : 0u;
             sum += p[k];
         }
-        uint32_t tot;
-        uint32_t ex = block_excl_scan(sum, s_w, &tot) + carry;
+        // block scan of the low words; the high part of the block total is recovered from a 64-bit reduction
+        uint32_t tot32;
+        uint32_t ex = block_excl_scan((uint32_t)sum, s_w, &tot32) + (uint32_t)carry;
 #pragma unroll
         for (int k = 0; k < 4; k++) { if (i + k < n_super) super_excl[i + k] = ex; ex += p[k]; }
-        carry += tot;
+        unsigned long long t64 = sum;
+        for (int off = 32; off > 0; off >>= 1) t64 += __shfl_down(t64, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63u) == 0) s_v[threadIdx.x >> 6] = t64;
+        __syncthreads();
+        carry += s_v[0] + s_v[1] + s_v[2] + s_v[3];
+        __syncthreads();
     }
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63u) == 0) s_v[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) { counters[1] = carry; counters[0] = s_v[0] + s_v[1] + s_v[2] + s_v[3]; }
+    if (threadIdx.x == 0) {
+        counters[1] = carry; counters[0] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
+        if (carry > (unsigned long long)pair_cap) counters[3] = 1ull;       // pair buffers too small: the host re-runs the frame
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1619,7 +1633,7 @@ void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
                     const float* hmap, const uint32_t* draw_culled, uint2* rects, Rec* recs, uint32_t* block_sums,
-                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f)
+                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap)
 {
     if (n_chunks == 0) return;
     const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs x n_super][visible x n_super], zeroed by the caller
@@ -1632,7 +1646,7 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     else if (full) { GSWT_LAUNCH_PROJECT(false, true); }
     else { GSWT_LAUNCH_PROJECT(false, false); }
 #undef GSWT_LAUNCH_PROJECT
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap);
 }
 
 // exclusive scan of `n` u32 in `data` -> `out` (may alias), total -> *total_out.
@@ -1746,7 +1760,11 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
                       hipEvent_t ev_begin, hipEvent_t ev_end, const unsigned long long* counters, unsigned long long* host_counters)
 {
-    if (n_tiles == 0) return;
+    if (n_tiles == 0) {                 // a shard without screen tiles (more ranks than tile columns): the events still exist
+        if (ev_begin) hipEventRecord(ev_begin, s);
+        if (ev_end) hipEventRecord(ev_end, s);
+        return;
+    }
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
     hipLaunchKernelGGL(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), 0, s, ranges, n_tiles, seg, item_base, item_tab, max_items);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
@@ -1765,6 +1783,12 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 #undef GSWT_LAUNCH_COMPOSITE
     if (ev_end) hipEventRecord(ev_end, s);
     hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+}
+
+// k_totals alone on caller-provided sums (unit test of the 64-bit pair count)
+void launch_totals(hipStream_t s, uint32_t* super_sums, uint32_t n_super, unsigned long long* counters, uint32_t pair_cap)
+{
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded, int band_px)

@@ -10,6 +10,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <deque>
@@ -41,6 +42,13 @@ int fail(int code, const char* fmt, ...)
     g_err = buf;
     return code;
 }
+
+// No C++ exception may unwind through the C ABI (the callers are ctypes / Rust FFI): every extern "C" body that returns a
+// status is a function-try-block closed by this handler.
+#define GSWT_CATCH(NAME)                                                                                    \
+    catch (const std::bad_alloc&) { return fail(GSWT_ERR_CAPACITY, NAME ": out of memory"); }                \
+    catch (const std::exception& e) { return fail(GSWT_ERR_IO, NAME ": %s", e.what()); }                     \
+    catch (...) { return fail(GSWT_ERR_IO, NAME ": unknown exception"); }
 
 // ------------------------------------------------------------------------------------------
 // halves (utils.rs:66-73; half 2.7.1 f16::from_f32, round to nearest even)
@@ -128,8 +136,10 @@ int parse_ply_header(const uint8_t* data, size_t len, size_t* header_size, size_
         if (line.rfind("element vertex ", 0) == 0) {
             char* endp = nullptr;
             std::string num = line.substr(15, line.size() - 16);
+            errno = 0;
             unsigned long long v = strtoull(num.c_str(), &endp, 10);
-            if (num.empty() || *endp != '\0') return fail(GSWT_ERR_IO, "Scene::parse_file_header(): bad vertex count '%s'", num.c_str());
+            if (num.empty() || *endp != '\0' || errno == ERANGE || num[0] == '-' || num[0] == '+')
+                return fail(GSWT_ERR_IO, "Scene::parse_file_header(): bad vertex count '%s'", num.c_str());
             splat_count = (size_t)v;
         }
     }
@@ -1357,14 +1367,14 @@ const char* gswt_host_last_error(void) { return g_err.c_str(); }
 uint32_t gswt_pack_half_2x16(float x, float y) { return pack_half_2x16(x, y); }
 
 int gswt_tileset_create(int n_lod, int n_tile, gswt_tileset** out)
-{
+try {
     if (!out || n_lod <= 0 || n_tile <= 0) return fail(GSWT_ERR_BAD_ARG, "gswt_tileset_create: bad dims");
     auto* ts = new gswt_tileset();
     ts->n_lod = n_lod; ts->n_tile = n_tile;
     ts->s.assign(n_lod, std::vector<Scene>(n_tile));
     *out = ts;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_tileset_create")
 
 void gswt_tileset_destroy(gswt_tileset* ts) { delete ts; }
 
@@ -1376,18 +1386,18 @@ static int ts_slot(gswt_tileset* ts, int lod, int tile, Scene** sc)
 }
 
 int gswt_tileset_set_vertices(gswt_tileset* ts, int lod, int tile, const float* verts62, size_t n)
-{
-    Scene* sc;
+try {
+    Scene* sc = nullptr;
     int rc = ts_slot(ts, lod, tile, &sc);
     if (rc) return rc;
     if (!verts62 && n) return fail(GSWT_ERR_BAD_ARG, "null vertices");
     scene_load(*sc, verts62, n);
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_tileset_set_vertices")
 
 int gswt_tileset_set_ply(gswt_tileset* ts, int lod, int tile, const uint8_t* bytes, size_t len)
-{
-    Scene* sc;
+try {
+    Scene* sc = nullptr;
     int rc = ts_slot(ts, lod, tile, &sc);
     if (rc) return rc;
     if (!bytes) return fail(GSWT_ERR_BAD_ARG, "null ply");
@@ -1395,25 +1405,27 @@ int gswt_tileset_set_ply(gswt_tileset* ts, int lod, int tile, const uint8_t* byt
     rc = parse_ply_header(bytes, len, &hs, &n);
     if (rc) return rc;
     if (hs > 65535) return fail(GSWT_ERR_IO, "Scene::parse_file_header(): header of %zu bytes overflows the reference's u16", hs);
-    if (hs + n * 248 > len) return fail(GSWT_ERR_IO, "Scene::load(): file holds fewer than %zu vertices (read_exact fails)", n);
+    if (hs > len || n > (len - hs) / 248) return fail(GSWT_ERR_IO, "Scene::load(): file holds fewer than %zu vertices (read_exact fails)", n);
     std::vector<float> verts(62 * n);
     memcpy(verts.data(), bytes + hs, n * 248);
     scene_load(*sc, verts.data(), n);
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_tileset_set_ply")
 
 int gswt_tileset_set_rows(gswt_tileset* ts, int lod, int tile, const uint8_t* rows32, size_t n)
-{
-    Scene* sc;
+try {
+    Scene* sc = nullptr;
     int rc = ts_slot(ts, lod, tile, &sc);
     if (rc) return rc;
+    if (!rows32 && n) return fail(GSWT_ERR_BAD_ARG, "null rows");
+    if (n > ((size_t)1 << 28)) return fail(GSWT_ERR_CAPACITY, "gswt_tileset_set_rows: %zu splats exceed 2^28", n);
     sc->splat_count = n;
     sc->buffer.assign(rows32, rows32 + 32 * n);
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_tileset_set_rows")
 
 int gswt_load_scene_zip_mem(const uint8_t* bytes, size_t len, gswt_tileset** out)
-{
+try {
     if (!bytes || !out) return fail(GSWT_ERR_BAD_ARG, "gswt_load_scene_zip: null argument");
     std::vector<ZipEntry> all;
     int rc = zip_list(bytes, len, all);
@@ -1427,11 +1439,16 @@ int gswt_load_scene_zip_mem(const uint8_t* bytes, size_t len, gswt_tileset** out
         if (slash != std::string::npos) fname = fname.substr(slash + 1);
         if (fname.empty()) continue;
         std::smatch m;
-        if (std::regex_search(fname, m, re)) files.push_back({i, fname, (size_t)std::stoull(m[1]), (size_t)std::stoull(m[2])});
+        if (std::regex_search(fname, m, re)) {
+            // the reference parses into usize and would then index / allocate by it; a tile set is a few LODs x 16..4096 tiles
+            if (m[1].length() > 4 || m[2].length() > 7) return fail(GSWT_ERR_IO, "load_scene_zip: lod / tile number out of range in '%s'", fname.c_str());
+            files.push_back({i, fname, (size_t)std::stoull(m[1]), (size_t)std::stoull(m[2])});
+        }
     }
     if (files.empty()) return fail(GSWT_ERR_IO, "load_scene_zip: no lod<L>_tile_<T> entries");
     std::stable_sort(files.begin(), files.end(), [](const F& a, const F& b) { return a.lod != b.lod ? a.lod < b.lod : a.tile < b.tile; });
     size_t n_lod = files.back().lod - files.front().lod + 1, n_tile = files.back().tile + 1;
+    if (n_lod > 64 || n_tile > ((size_t)1 << 20)) return fail(GSWT_ERR_IO, "load_scene_zip: %zu LODs x %zu tiles is not a tile set", n_lod, n_tile);
     if (files.size() < n_lod * n_tile) return fail(GSWT_ERR_IO, "load_scene_zip: %zu entries for %zu x %zu tiles (index out of bounds in the reference)", files.size(), n_lod, n_tile);
     gswt_tileset* ts = nullptr;
     rc = gswt_tileset_create((int)n_lod, (int)n_tile, &ts);
@@ -1450,44 +1467,44 @@ int gswt_load_scene_zip_mem(const uint8_t* bytes, size_t len, gswt_tileset** out
         }
     *out = ts;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_load_scene_zip_mem")
 
 int gswt_load_scene_zip(const char* path, gswt_tileset** out)
-{
+try {
     if (!path) return fail(GSWT_ERR_BAD_ARG, "null path");
     std::ifstream fs(path, std::ios::binary);
     if (!fs) return fail(GSWT_ERR_IO, "cannot open %s", path);
     std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(fs)), std::istreambuf_iterator<char>());
     return gswt_load_scene_zip_mem(bytes.data(), bytes.size(), out);
-}
+} GSWT_CATCH("gswt_load_scene_zip")
 
 int gswt_tileset_dims(const gswt_tileset* ts, int* n_lod, int* n_tile)
-{
+try {
     if (!ts) return GSWT_ERR_BAD_ARG;
     if (n_lod) *n_lod = ts->n_lod;
     if (n_tile) *n_tile = ts->n_tile;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_tileset_dims")
 size_t gswt_tileset_splat_count(const gswt_tileset* ts, int lod, int tile) { return ts->s[lod][tile].splat_count; }
 const uint8_t* gswt_tileset_rows(const gswt_tileset* ts, int lod, int tile) { return ts->s[lod][tile].buffer.data(); }
 
 int gswt_generate_texture(const uint8_t* rows32, size_t n, uint32_t* tex_out)
-{
+try {
     if ((!rows32 || !tex_out) && n) return GSWT_ERR_BAD_ARG;
     generate_texture(rows32, n, tex_out);
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_generate_texture")
 
 int gswt_sort_raw_depth(const int32_t* depths, size_t n, uint32_t* order_out)
-{
+try {
     if ((!depths || !order_out) && n) return GSWT_ERR_BAD_ARG;
     sort_raw_depth(depths, n, order_out);
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_sort_raw_depth")
 
 int gswt_camera_uniforms_from_camera(const float pos[3], const float target[3], const float up[3], float fovy_deg, float z_near,
                          float z_far, int width, int height, gswt_camera_uniforms* out, float* view_proj16)
-{
+try {
     if (!pos || !target || !up || !out || width <= 0 || height <= 0) return fail(GSWT_ERR_BAD_ARG, "gswt_camera_uniforms_from_camera: bad argument");
     float view[16], proj[16];
     look_at_rh(V3{pos[0], pos[1], pos[2]}, V3{target[0], target[1], target[2]}, V3{up[0], up[1], up[2]}, view);
@@ -1505,10 +1522,10 @@ int gswt_camera_uniforms_from_camera(const float pos[3], const float target[3], 
     out->cam_pos[0] = pos[0]; out->cam_pos[1] = pos[1]; out->cam_pos[2] = pos[2]; out->cam_pos[3] = 0;
     if (view_proj16) mat4_mul(proj, view, view_proj16);
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_camera_uniforms_from_camera")
 
 int gswt_wang_new(gswt_tileset* ts, gswt_wang** out)
-{
+try {
     if (!ts || !out) return fail(GSWT_ERR_BAD_ARG, "gswt_wang_new: null argument");
     auto* w = new gswt_wang();
     w->tiles = std::move(ts->s);
@@ -1517,35 +1534,35 @@ int gswt_wang_new(gswt_tileset* ts, gswt_wang** out)
     if (rc) { delete w; return rc; }
     *out = w;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_new")
 
 void gswt_wang_destroy(gswt_wang* w) { delete w; }
 
 int gswt_wang_preload(gswt_wang* w, gswt_preload* out)
-{
+try {
     if (!w || !out) return GSWT_ERR_BAD_ARG;
     out->tex_data = w->tex.data();
     out->n_splats = w->merged_count;
     out->n_lod = (int)w->n_lod; out->n_tile = (int)w->n_tile; out->n_view = (int)w->n_view;
     out->lists = w->base_lists.data();
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_preload")
 
 int gswt_wang_tile_base(const gswt_wang* w, int tile, float center[3], float aabb[6])
-{
+try {
     if (!w || tile < 0 || (size_t)tile >= w->n_tile) return GSWT_ERR_BAD_ARG;
     V3 c = w->tile_center[tile], lo = w->aabb_lo[tile], hi = w->aabb_hi[tile];
     if (center) { center[0] = c.x; center[1] = c.y; center[2] = c.z; }
     if (aabb) { aabb[0] = lo.x; aabb[1] = lo.y; aabb[2] = lo.z; aabb[3] = hi.x; aabb[4] = hi.y; aabb[5] = hi.z; }
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_tile_base")
 
 int gswt_wang_lod_avg_scale(const gswt_wang* w, float* out, int cap)
-{
+try {
     if (!w || !out || cap < (int)w->n_lod) return GSWT_ERR_BAD_ARG;
     for (size_t l = 0; l < w->n_lod; l++) out[l] = w->lod_avg_scale[l];
     return (int)w->n_lod;
-}
+} GSWT_CATCH("gswt_wang_lod_avg_scale")
 
 const int32_t* gswt_wang_raw_depth(const gswt_wang* w, int lod, int tile, int view, size_t* n)
 {
@@ -1555,14 +1572,14 @@ const int32_t* gswt_wang_raw_depth(const gswt_wang* w, int lod, int tile, int vi
 }
 
 int gswt_wang_merge_offset(const gswt_wang* w, int lod, int tile, uint32_t* out)
-{
+try {
     if (!w || !out || lod < 0 || (size_t)lod >= w->n_lod || tile < 0 || (size_t)tile >= w->n_tile) return GSWT_ERR_BAD_ARG;
     *out = w->merge_offset[lod][tile];
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_merge_offset")
 
 int gswt_wang_configure(gswt_wang* w, const gswt_user_data* user, gswt_configured* out)
-{
+try {
     if (!w || !user) return fail(GSWT_ERR_BAD_ARG, "gswt_wang_configure: null argument");
     int rc = check_user(*user);
     if (rc) return rc;
@@ -1629,17 +1646,17 @@ int gswt_wang_configure(gswt_wang* w, const gswt_user_data* user, gswt_configure
         out->n_lod = (uint32_t)w->n_lod; out->n_tile = (uint32_t)w->n_tile; out->n_view = (uint32_t)w->n_view;
     }
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_configure")
 
 int gswt_wang_check_update(const gswt_wang* w, const float cam_pos[3])
-{
+try {
     if (!w || !cam_pos) return GSWT_ERR_BAD_ARG;
     if (!w->initialized) return 1;
     return distance2(V3{cam_pos[0], cam_pos[1], cam_pos[2]}, w->camera_pos) >= w->user.update_distance2 ? 1 : 0;
-}
+} GSWT_CATCH("gswt_wang_check_update")
 
 int gswt_wang_build_tiles(gswt_wang* w, const float cam_pos[3], gswt_scene_data* out)
-{
+try {
     if (!w || !cam_pos) return fail(GSWT_ERR_BAD_ARG, "gswt_wang_build_tiles: null argument");
     if (w->map_w == 0) return fail(GSWT_ERR_STATE, "WangTile::build_tiles before configure");
     w->initialized = true;
@@ -1659,17 +1676,17 @@ int gswt_wang_build_tiles(gswt_wang* w, const float cam_pos[3], gswt_scene_data*
             }
     }
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_build_tiles")
 
 int gswt_wang_set_device_merge(gswt_wang* w, int enable)
-{
+try {
     if (!w) return GSWT_ERR_BAD_ARG;
     w->device_merge = enable != 0;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_set_device_merge")
 
 int gswt_wang_raw_depth_tables(gswt_wang* w, const int32_t* const** ptrs, const uint32_t** counts, const uint32_t** merge_offset)
-{
+try {
     if (!w || !ptrs || !counts || !merge_offset) return GSWT_ERR_BAD_ARG;
     w->rd_ptrs.clear(); w->rd_counts.clear(); w->rd_offsets.clear();
     for (size_t l = 0; l < w->n_lod; l++)
@@ -1680,10 +1697,10 @@ int gswt_wang_raw_depth_tables(gswt_wang* w, const int32_t* const** ptrs, const 
         }
     *ptrs = w->rd_ptrs.data(); *counts = w->rd_counts.data(); *merge_offset = w->rd_offsets.data();
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_raw_depth_tables")
 
 int gswt_wang_get_tile_ids(const gswt_wang* w, uint32_t* ids, size_t cap)
-{
+try {
     if (!w || !ids) return GSWT_ERR_BAD_ARG;
     size_t n = (size_t)w->map_w * w->map_h;
     if (cap < n) return fail(GSWT_ERR_CAPACITY, "need %zu ids", n);
@@ -1692,10 +1709,10 @@ int gswt_wang_get_tile_ids(const gswt_wang* w, uint32_t* ids, size_t cap)
         ids[i] = (uint32_t)w->tile_map[i]->tile;
     }
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_get_tile_ids")
 
 int gswt_wang_set_tile_ids(gswt_wang* w, const uint32_t* ids, size_t n)
-{
+try {
     if (!w || !ids) return GSWT_ERR_BAD_ARG;
     if (n != (size_t)w->map_w * w->map_h) return fail(GSWT_ERR_BAD_ARG, "expected %d ids", w->map_w * w->map_h);
     for (size_t i = 0; i < n; i++) {
@@ -1714,10 +1731,10 @@ int gswt_wang_set_tile_ids(gswt_wang* w, const uint32_t* ids, size_t n)
         }
     update_lod(*w, w->camera_pos);
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_set_tile_ids")
 
 int gswt_wang_sort_tiles(gswt_wang* w, const float cam_pos[3], const float vp[16], gswt_sort_data* out)
-{
+try {
     if (!w || !cam_pos || !vp || !out) return fail(GSWT_ERR_BAD_ARG, "gswt_wang_sort_tiles: null argument");
     if (!w->initialized) return fail(GSWT_ERR_STATE, "WangTile::sort_tiles before build_tiles");
     const bool need_corner = w->user.tile_sort_type == SORT_GRAPH || w->user.merge_type == MERGE_EDGE;
@@ -1853,11 +1870,11 @@ int gswt_wang_sort_tiles(gswt_wang* w, const float cam_pos[3], const float vp[16
     out->n_groups = (uint32_t)w->m_groups.size(); out->n_members = (uint32_t)w->m_members.size();
     out->groups = w->m_groups.data(); out->members = w->m_members.data();
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_wang_sort_tiles")
 
 // renderer.rs:466-591 (host half) + TileUniforms::from_tile :691-725
 int gswt_renderer_build_draws(const gswt_sort_data* sort, gswt_draw* draws_out)
-{
+try {
     if (!sort || (!draws_out && sort->n_tiles)) return fail(GSWT_ERR_BAD_ARG, "gswt_renderer_build_draws: null argument");
     for (uint32_t i = 0; i < sort->n_tiles; i++) {
         const gswt_sorted_tile& t = sort->tiles[i];
@@ -1892,11 +1909,11 @@ int gswt_renderer_build_draws(const gswt_sort_data* sort, gswt_draw* draws_out)
         }
     }
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_renderer_build_draws")
 
 int gswt_scene_uniforms_from_data(const gswt_user_data* user, const gswt_configured* conf, const gswt_scene_data* scene, float splat_scale,
                         const float scene_scale[3], float height_map_scale_v, gswt_scene_uniforms* out)
-{
+try {
     if (!user || !conf || !scene || !out) return fail(GSWT_ERR_BAD_ARG, "gswt_scene_uniforms_from_data: null argument");
     memset(out, 0, sizeof(*out));
     out->splat_scale = splat_scale;
@@ -1915,6 +1932,6 @@ int gswt_scene_uniforms_from_data(const gswt_user_data* user, const gswt_configu
     out->scene_scale[1] = scene_scale ? scene_scale[1] : 1.0f;
     out->scene_scale[2] = scene_scale ? scene_scale[2] : 1.0f;
     return GSWT_OK;
-}
+} GSWT_CATCH("gswt_scene_uniforms_from_data")
 
 }  // extern "C"

@@ -15,10 +15,14 @@ from . import host
 WORKLOADS = {
     "c1": dict(desc="1x1 map, ~50k Gaussians, 640x480 (reference CPU-runnable plumbing case)",
                half=(0, 0), lod0=50000, n_lod=3, width=640, height=480,
+               # a 1x1 map sits under the camera's own tile: look down at it (the reference default camera looks along +y at z = 5
+               # and sees nothing of a single tile)
+               camera=dict(pos=(2.0, 0.5, 7.0), target=(2.0, 2.0, 0.0), up=(0.0, 0.0, 1.0), fovy=45.0, near=0.1, far=2400.0),
                user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_DISTANCE, merge_type=host.MERGE_EDGE,
                          lod_max_dist=96.0 * 4.0)),
     "c2": dict(desc="5x5 map (4x4 grid nearest valid), ~1M instanced Gaussians, 1280x720, LOD off",
                half=(2, 2), lod0=62500, n_lod=1, width=1280, height=720,
+               camera=dict(pos=(2.0, 2.0, 14.0), target=(2.0, 6.0, 0.0), up=(0.0, 0.0, 1.0), fovy=45.0, near=0.1, far=2400.0),
                user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
                          lod_blending=False, lod_max_dist=96.0 * 4.0)),
     "c3": dict(desc="33x33 map (32x32 grid nearest valid), ~10M instanced Gaussians, 1920x1080, LOD blending + Edge merging",
@@ -45,6 +49,11 @@ WORKLOADS = {
 }
 
 DEFAULT_CAMERA = dict(pos=(0.0, 0.0, 5.0), target=(0.0, 1.0, 5.0), up=(0.0, 0.0, 1.0), fovy=45.0, near=0.1, far=2400.0)  # state.rs:114-122
+
+
+def camera_for(name: str) -> dict:
+    """The workload's camera: its own where the reference default would see nothing of the map, else state.rs:114-122."""
+    return WORKLOADS[name].get("camera", DEFAULT_CAMERA)
 
 
 def user_data_for(name: str) -> host.UserData:

@@ -1,0 +1,144 @@
+"""BASELINE.json's configurations through the C ABI, each against the CPU oracle at full size.
+
+c1 (1x1 map, ~50 k splats, 640x480), c2 (5x5 map, ~1 M instanced, 1280x720, LOD off), c3 (33x33 map, ~10 M instanced,
+1920x1080, LOD blending + Edge merging; `c3h` = the same on the GUI's default HeightMap surface) and c5 (129x129 map,
+~94 M instanced, 3840x2160, skybox + proxy passes in front of the splats).  c4 (c3 sharded over 2/4/8 GPUs) needs more than
+the one GPU of the test box: its shard layout is covered here by the bitwise union of the 8 column bands rendered one
+after the other on one device.  The workloads are built exactly as bench.py builds them (gswt_renderer_amd/workloads.py);
+the oracle side is the pure-Python WangTile restatement + the C oracle renderer, so the draw list is checked too.
+The last test goes GSWT tile-zip -> PLY loader -> pipeline -> frame (scene.rs:1030-1141).
+"""
+import numpy as np
+import pytest
+
+from gswt_renderer_amd import host, synth, workloads
+from gswt_renderer_amd import _lib as L
+from gswt_renderer_amd.pipeline import GSWTPipeline
+from oracle import gswt_oracle as orc
+from oracle import wangtile_oracle as wo
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # BASELINE.json north_star: 1e-4 per-channel L-inf on a float framebuffer
+
+
+def _both_sides(renderer, name, device_merge=False):
+    w = workloads.WORKLOADS[name]
+    cfg = dict(tile_map_half_wh=w["half"], **w["user"])
+    cam = workloads.camera_for(name)
+    W, Hh = w["width"], w["height"]
+    verts = synth.make_tileset(n_lod=w["n_lod"], n_tile=16, lod0_count=w["lod0"])
+    pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer, device_merge=device_merge)
+    cu, vp = host.camera_uniforms(cam["pos"], cam["target"], cam["up"], cam["fovy"], cam["near"], cam["far"], W, Hh)
+    pipe.update(cam["pos"], vp)
+    pp = orc.preprocess([[orc.scene_load(v) for v in lod] for lod in verts])
+    ow = wo.WangTile(pp)
+    ou = ow.configure(wo.UserData(**cfg))
+    ocam = orc.Camera(W, Hh, cam["pos"], cam["target"], cam["up"], fovy_deg=cam["fovy"], z_near=cam["near"], z_far=cam["far"])
+    osd = ow.build_tiles(cam["pos"])
+    osort = ow.sort_tiles(cam["pos"], ocam.view_proj())
+    odraws = wo.renderer_draws(pp, osort, ocam.view_proj())
+    osu = wo.scene_uniforms_from_data(ou, osd["center_coord"])
+    hm = ou.height_map.reshape(ou.height_map_wh[1], ou.height_map_wh[0]) if ou.surface_type == 1 else None
+    return dict(w=w, W=W, H=Hh, pipe=pipe, cu=cu, vp=vp, pp=pp, ocam=ocam, odraws=odraws, osu=osu, hm=hm, osort=osort)
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c3h"])
+def test_baseline_config_matches_oracle(renderer, name):
+    s = _both_sides(renderer, name)
+    W, Hh, pipe = s["W"], s["H"], s["pipe"]
+    ref, st = orc.render(s["ocam"].uniforms(), s["osu"], s["pp"].tex, s["odraws"], W, Hh, height_map=s["hm"])
+    assert st["n_visible"] > 10000, st                 # the configuration's camera really sees the map
+    img = pipe.render(s["cu"], W, Hh)                   # transmittance_eps = 0: no early termination
+    t = renderer.timings()
+    assert t["n_visible"] == st["n_visible"]
+    assert t["n_pairs"] == st["n_pairs16"]
+    assert H.max_abs_diff(img, ref) <= TOL
+    # what bench.py times: front-to-back early termination at 1e-5
+    img_e = pipe.render(s["cu"], W, Hh, transmittance_eps=1e-5)
+    assert H.max_abs_diff(img_e, ref) <= TOL
+    if name == "c3":
+        # c4's shard layout on one device: 8 column bands, each with its own draw cull; their union is the frame, bit for bit
+        n = 8
+        bw = renderer.shard_cols_padded(W, n)
+        uni = np.zeros_like(img)
+        for r in range(n):
+            part = pipe.render(s["cu"], W, Hh, shard=(r, n, "cols"))
+            x0, x1 = r * bw, min(W, (r + 1) * bw)
+            uni[:, x0:x1] = part[:, :x1 - x0]
+        assert np.array_equal(uni, img)
+
+
+def test_c3_device_built_merged_lists(renderer):
+    """c3 with the merged-group lists built on the device per sort event (gswt_set_draws_merge_groups)."""
+    s = _both_sides(renderer, "c3", device_merge=True)
+    W, Hh = s["W"], s["H"]
+    ref, st = orc.render(s["ocam"].uniforms(), s["osu"], s["pp"].tex, s["odraws"], W, Hh)
+    img = s["pipe"].render(s["cu"], W, Hh)
+    assert renderer.timings()["n_visible"] == st["n_visible"]
+    assert H.max_abs_diff(img, ref) <= TOL
+
+
+def test_c5_full_size_with_passes(renderer):
+    """BASELINE config 5 on one GPU: skybox -> proxy (colour + depth) -> splats at 3840x2160 on the 129x129 map."""
+    import torch
+    import bench
+    s = _both_sides(renderer, "c5")
+    W, Hh, pipe, cu = s["W"], s["H"], s["pipe"], s["cu"]
+    su = pipe.wang.scene_uniforms()
+    faces, mips, pu = bench.make_passes(renderer, su, cu)
+    dev = torch.device("cuda", 0)
+    bg = torch.empty((Hh, W, 4), dtype=torch.float32, device=dev)
+    dep = torch.empty((Hh, W), dtype=torch.float32, device=dev)
+    out = torch.empty((Hh, W, 4), dtype=torch.float32, device=dev)
+    renderer.skybox_render(cu, W, Hh, bg.data_ptr())
+    renderer.proxy_render(pu, W, Hh, bg.data_ptr(), dep.data_ptr(), True)
+    renderer.synchronize()
+    renderer.render_wait(renderer.render_async(cu, su, W, Hh, out.data_ptr(), bg_rgba_ptr=bg.data_ptr(), bg_depth_ptr=dep.data_ptr()))
+    t = renderer.timings()
+    img = out.cpu().numpy()
+    # oracle chain (state.rs:384-402)
+    cam = type("Cam", (), {})()
+    ocu = s["ocam"].uniforms()
+    cam.view = np.array(ocu.view[:], dtype=np.float32)
+    cam.projection = np.array(ocu.projection[:], dtype=np.float32)
+    obg = orc.skybox_render(cam, faces, W, Hh)
+    obgd = np.ones((Hh, W), np.float32)
+    orc.proxy_render(orc.Proxy224.from_buffer_copy(bytes(pu)), W, Hh, obg, obgd, mips)
+    assert np.array_equal(dep.cpu().numpy(), obgd)                 # the proxy depth buffer is bit-exact
+    ref, st = orc.render(ocu, s["osu"], s["pp"].tex, s["odraws"], W, Hh, bg_rgba=obg, bg_depth=obgd)
+    assert st["n_visible"] > 10_000_000
+    assert t["n_visible"] == st["n_visible"]
+    assert t["n_pairs"] == st["n_pairs16"]
+    assert H.max_abs_diff(img, ref) <= TOL
+    del bg, dep, out
+    torch.cuda.empty_cache()
+
+
+def test_tile_zip_to_frame(renderer, tmp_path):
+    """GSWT tile-zip on disk -> gswt_load_scene_zip (PLY parse + 32-B packing) -> WangTile -> frame, against the oracle
+    fed with the same vertex arrays.  The zip is written in the reference's input layout (lod{L}_tile_{T}.ply)."""
+    w = workloads.WORKLOADS["tiny"]
+    cfg = dict(tile_map_half_wh=w["half"], **w["user"])
+    verts = synth.make_tileset(n_lod=w["n_lod"], n_tile=16, lod0_count=w["lod0"])
+    path = tmp_path / "tiles.zip"
+    synth.write_tile_zip(str(path), verts)
+    W, Hh = w["width"], w["height"]
+    pos, tgt = (4.2, 1.0, 3.0), (5.0, 3.0, 2.5)
+    cu, vp = host.camera_uniforms(pos, tgt, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
+    ref = st = None
+    for source in (str(path), path.read_bytes()):                  # from a path and from bytes already in memory
+        pipe = GSWTPipeline(source, host.user_data(**cfg), renderer=renderer)
+        pipe.update(pos, vp)
+        img = pipe.render(cu, W, Hh)
+        if ref is None:
+            pp = orc.preprocess([[orc.scene_load(v) for v in lod] for lod in verts])
+            ow = wo.WangTile(pp)
+            ou = ow.configure(wo.UserData(**cfg))
+            ocam = orc.Camera(W, Hh, pos, tgt, [0, 0, 1])
+            osd = ow.build_tiles(pos)
+            osort = ow.sort_tiles(pos, ocam.view_proj())
+            odraws = wo.renderer_draws(pp, osort, ocam.view_proj())
+            ref, st = orc.render(ocam.uniforms(), wo.scene_uniforms_from_data(ou, osd["center_coord"]), pp.tex, odraws, W, Hh)
+        assert renderer.timings()["n_visible"] == st["n_visible"] and st["n_visible"] > 0
+        assert H.max_abs_diff(img, ref) <= TOL

@@ -286,3 +286,24 @@ def test_reference_panics_become_errors(tiles):
         bad[1][t] = bad[1][t].copy(); bad[1][t][:, 55:58] -= 5.0
     with pytest.raises(host.GSWTHostError):
         host.WangTile(host.TileSet.from_vertices(bad))
+
+
+def test_loader_rejects_crafted_counts_without_unwinding():
+    """a header count whose byte size wraps size_t, a 30-digit tile index and null rows must come back as
+    status codes -- no over-read, no C++ exception through the C ABI."""
+    import io
+    import zipfile
+    lib = host.load()
+    ts = host.TileSet.from_vertices([[np.zeros((1, 62), np.float32)]])
+    for count in (2 ** 62, 2 ** 64 - 1, 2 ** 70, 74381295208399815):       # 248 * n wraps to a small number for the last one
+        ply = (f"ply\nformat binary_little_endian 1.0\nelement vertex {count}\nend_header\n").encode() + b"\0" * 1000
+        buf = np.frombuffer(ply, dtype=np.uint8)
+        assert lib.gswt_tileset_set_ply(ts._h, 0, 0, buf.ctypes.data, len(ply)) == -5
+    assert lib.gswt_tileset_set_rows(ts._h, 0, 0, None, 5) == -1
+    good = synth.write_ply(np.zeros((2, 62), np.float32))
+    for name in ("lod0_tile_" + "9" * 30 + ".ply", "lod" + "7" * 25 + "_tile_0.ply", "lod0_tile_99999999.ply"):
+        bio = io.BytesIO()
+        with zipfile.ZipFile(bio, "w") as zf:
+            zf.writestr(name, good)
+        with pytest.raises(host.GSWTHostError):
+            host.TileSet.from_zip(bio.getvalue())
