@@ -301,8 +301,10 @@ try {
     if (!c) return GSWT_ERR_BAD_ARG;
     collect_pending(c);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
-    c->stream = (hipStream_t)hip_stream;
-    c->own_stream = false;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; return GSWT_OK; }
+    c->stream = nullptr; c->own_stream = true;            // NULL: back to a stream of the ctx's own
+    hipSetDevice(c->device);
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     return GSWT_OK;
 } GSWT_CATCH("gswt_set_stream")
 
@@ -926,7 +928,11 @@ try {
         for (int k = 1; k < kFrameSlots; k++) if (c->slots[k].seq < c->slots[si].seq) si = k;
     }
     FrameSlot& sl = c->slots[si];
-    if (sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render_async: all %d frame slots are in flight; gswt_render_wait the oldest ticket first", kFrameSlots);
+    if (sl.pending) {                   // every slot in flight: the oldest frame is collected here and its slot reused
+        sl.pending = false;
+        if (sl.collected) { sl.collected = false; rc = sl.collected_rc; } else rc = finish_frame(c, sl);
+        if (rc != GSWT_OK) return rc;
+    }
     sl.seq = ++c->frame_seq;
     fill_args(sl.args, cam, su, cfg, width, height, reinterpret_cast<const float4*>(bg_rgba_dev), bg_depth_dev,
               reinterpret_cast<float4*>(out_rgba_dev));

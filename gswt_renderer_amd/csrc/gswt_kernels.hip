@@ -1164,9 +1164,9 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 
 // ------------------------------------------------------------------------------------
 // k_composite: one workgroup (4 wave64) per work item = (16x16 screen tile, segment of its pair list).
-// Wave w owns the 8x8 pixel quadrant (w & 1, w >> 1); inside a wave the four 16-lane groups own the
-// four 4x4 sub-blocks and walk DIFFERENT splats concurrently (the c3 scene averages ~9 covered pixels
-// per pair, so a whole wave per splat would leave most lanes idle).
+// Wave w owns the 16x4 pixel strip of rows 4w .. 4w+3; inside a wave the four 16-lane groups own the
+// four 4x4 sub-blocks of that strip and walk DIFFERENT splats concurrently (the c3 scene averages ~9 covered
+// pixels per pair, so a whole wave per splat would leave most lanes idle).
 //   stage   : 256 pairs per batch -> LDS (16 KB): the staging lane gathers the 48-B record, unpacks the
 //             colour, evaluates the per-(splat, tile) constants F3 and the tile-local pixel-centre box
 //   bin     : every wave ballots the batch against its four sub-blocks and appends the hits, in list
@@ -1271,7 +1271,7 @@ __device__ unsigned long long g_stats[8];
 // alpha rides in the exponent (B = 2^(-r2 log2 e + log2 alpha): one fma + v_exp), the colour stays packed and is
 // unpacked by v_cvt_f32_ubyteN in the blend; the accumulators run in 0..255 units and are scaled once at the end.
 // COLF (debug draw modes only): colours are floats from the side buffer col_f[slot], staged into a third LDS word.
-// Lane geometry of the compositor: wave w owns the 8x8 quadrant, 16-lane group g the 4x4 sub-block.
+// Lane geometry of the compositor: wave w owns the 16x4 strip of rows 4w .. 4w+3, 16-lane group g its 4x4 sub-block of columns 4g .. 4g+3.
 struct CompLane {
     float lx, ly;                 // tile-local pixel centre of this lane
     int r0;                       // first pixel row (tile-local) of the wave's 16 x 4 strip

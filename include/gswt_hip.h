@@ -158,7 +158,7 @@ typedef struct {
 GSWT_API int gswt_create(int device_id, gswt_ctx **out);
 GSWT_API void gswt_destroy(gswt_ctx *ctx);
 GSWT_API const char *gswt_last_error(const gswt_ctx *ctx);
-/* Runs on a user-provided HIP stream (hipStream_t as void*) instead of the ctx's own. */
+/* Runs on a user-provided HIP stream (hipStream_t as void*) instead of the ctx's own; NULL returns to a stream of the ctx's own. */
 GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
 
 /* Options (no reference counterpart; test / profiling switches).
@@ -169,7 +169,8 @@ GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
 enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
        GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 512) */,
        GSWT_OPT_DEBUG_FLAGS = 4 /* ablation bits for profiling; output is wrong when nonzero */,
-       GSWT_OPT_TIMING = 5 /* hipEvent timing: 0 none, 1 frame + k_composite, 2 every stage (default) */ };
+       GSWT_OPT_TIMING = 5 /* hipEvent timing: 0 none, 1 frame + k_composite, 2 every stage (default) */,
+       GSWT_OPT_PAIR_CAP = 6 /* test hook: pin the pair-buffer capacity to `value` pairs until a frame overflows it (0: automatic) */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data
@@ -241,11 +242,14 @@ GSWT_API int gswt_render(gswt_ctx *ctx, const gswt_camera_uniforms *camera,
  * different output buffers.  Ordering against the ctx stream (gswt_set_stream):
  *   - a frame starts after all work submitted to the ctx stream before its gswt_render_async call
  *     (producers of bg_*, earlier consumers of out_rgba_dev);
- *   - gswt_render_fence(ticket) makes the ctx stream wait (on the device) for that frame, so work
- *     submitted to the ctx stream afterwards sees its output (e.g. the RCCL all-gather of the shards).
- *     To keep the frames overlapped, submit the following frame(s) BEFORE fencing frame i.  A fenced consumer sees
- *     an incomplete image in the rare frame whose pair buffers overflowed (first frames after a scene
- *     change; gswt_render_wait re-runs it) -- warm up before relying on fences. */
+ *   - gswt_render_fence(ticket) orders the ctx stream behind that frame, so work submitted to the ctx stream afterwards sees
+ *     its output (e.g. the RCCL all-gather of the shards).  All-or-nothing like GSWTRenderer::render (renderer.rs:407-414): a
+ *     frame whose pair buffers overflowed is re-run with larger ones BEFORE the fence releases the ctx stream, so a fenced
+ *     consumer never reads an incomplete image.  Overflow is only known on the host, hence the call blocks the host until
+ *     THIS frame has finished (not the younger frames in flight: submit them before fencing frame i and the GPU stays
+ *     busy).  The ticket stays valid; gswt_render_wait(ticket) then returns at once with the frame's status and timings.
+ *   - gswt_set_draws*, gswt_upload_scene, gswt_configure first run every frame in flight to completion against the state it
+ *     was submitted with (tickets stay valid). */
 GSWT_API int gswt_render_async(gswt_ctx *ctx, const gswt_camera_uniforms *camera,
                                const gswt_scene_uniforms *scene, const gswt_render_config *cfg,
                                int width, int height, const float *bg_rgba_dev, const float *bg_depth_dev,
@@ -318,6 +322,11 @@ GSWT_API int gswt_last_timings(const gswt_ctx *ctx, gswt_timings *out);
  * minor.xy, rgba) -- the varyings of vs_main (gswt.wgsl:4-8,412-419). Host pointer. */
 GSWT_API int gswt_debug_read_projected(gswt_ctx *ctx, void *out, size_t capacity_entries,
                                        size_t *n_entries);
+
+/* Test hook: k_totals alone -- folds n_super (pair, visible) super-group sums into the frame counters {visible, pairs, -,
+ * overflow flag} (64-bit) and the exclusive pair prefix per super-group (u32).  Host pointers. */
+GSWT_API int gswt_debug_totals(gswt_ctx *ctx, const uint32_t *pair_sums, const uint32_t *visible_sums, uint32_t n_super,
+                               uint32_t pair_cap, unsigned long long counters_out[4], uint32_t *super_excl_out);
 
 /* Test / profiling hook: [start, end) of every screen tile in the sorted pair list of the last
  * gswt_render (2 u32 per tile, shard-local tile order). Host pointer. */

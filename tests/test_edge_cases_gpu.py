@@ -144,3 +144,109 @@ def test_error_codes(renderer):
     # the ctx is still usable afterwards
     img = renderer.render(cam, orc.scene_uniforms(num_lod=2, map_half_wh=(1, 2)), 64, 48)
     assert img.shape == (48, 64, 4)
+
+
+def test_fenced_consumer_never_sees_an_overflowed_frame(renderer):
+    """ADVICE r1 / VERDICT r1: with the pair capacity pinned far below the frame's pair count, work ordered behind
+    gswt_render_fence on the ctx stream (here: a device-to-device copy, standing in for the RCCL all-gather) must still read
+    the complete frame -- the fence re-runs the overflowed frame before it releases the ctx stream."""
+    import torch
+    from gswt_renderer_amd import host, synth
+    from gswt_renderer_amd.pipeline import GSWTPipeline
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=800)
+    pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer)
+    W, Hh = 256, 160
+    pos = (4.2, 1.0, 2.0)
+    cu, vp = host.camera_uniforms(pos, (5.0, 3.0, 1.5), (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
+    pipe.update(pos, vp)
+    su = pipe.wang.scene_uniforms()
+    want = renderer.render(cu, su, W, Hh)
+    n_pairs = renderer.timings()["n_pairs"]
+    assert n_pairs > 1000
+    stream = torch.cuda.Stream()
+    renderer.set_stream(stream.cuda_stream)
+    try:
+        out = torch.zeros((Hh, W, 4), dtype=torch.float32, device="cuda")
+        seen = torch.zeros_like(out)
+        torch.cuda.synchronize()
+        renderer.set_option(L.GSWT_OPT_PAIR_CAP, 256)             # every frame overflows until the capacity has grown
+        ticket = renderer.render_async(cu, su, W, Hh, out.data_ptr())
+        renderer.render_fence(ticket)
+        with torch.cuda.stream(stream):
+            seen.copy_(out, non_blocking=True)                     # the fenced consumer
+        renderer.render_wait(ticket)
+        stream.synchronize()
+        assert renderer.timings()["n_pairs"] == n_pairs
+        assert np.array_equal(seen.cpu().numpy(), want)
+        # the same with a sort event between submit and wait: the pending frame finishes against ITS draw list
+        renderer.set_option(L.GSWT_OPT_PAIR_CAP, 256)
+        out.zero_()
+        torch.cuda.synchronize()
+        ticket = renderer.render_async(cu, su, W, Hh, out.data_ptr())
+        renderer.set_draws([])
+        renderer.render_wait(ticket)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want)
+    finally:
+        renderer.set_option(L.GSWT_OPT_PAIR_CAP, 0)
+        renderer.set_stream(0)
+
+
+def test_more_shards_than_tile_columns_or_rows(renderer):
+    """a rank whose band holds no screen tile (more ranks than 16-px tile columns / rows) renders an empty shard
+    frame after frame with every timing level, and the non-empty shards still assemble the unsharded image bitwise."""
+    pp = H.tileset()
+    _upload(renderer, pp)
+    case = H.grid_case(pp)
+    renderer.set_draws(case.draws)
+    W, Hh = 40, 24                                     # 3 tile columns, 2 tile rows
+    cam = orc.default_camera(W, Hh).uniforms()
+    su = orc.scene_uniforms(num_lod=pp.n_lod)
+    full = renderer.render(cam, su, W, Hh)
+    n = 8
+    bw = renderer.shard_cols_padded(W, n)
+    for level in (2, 1, 0):
+        renderer.set_option(L.GSWT_OPT_TIMING, level)
+        uni = np.zeros_like(full)
+        for _ in range(2):                              # twice: a sticky error of the first frame would fail the second
+            for r in range(n):
+                part = renderer.render(cam, su, W, Hh, shard=(r, n, "cols"))
+                x0, x1 = r * bw, min(W, (r + 1) * bw)
+                if x1 > x0:
+                    uni[:, x0:x1] = part[:, :x1 - x0]
+                else:
+                    assert renderer.timings()["n_tiles"] == 0 and not part.any()
+        assert np.array_equal(uni, full)
+        rows_p = renderer.shard_rows_padded(Hh, n)
+        uni = np.zeros_like(full)
+        for r in range(n):
+            part = renderer.render(cam, su, W, Hh, shard=(r, n))
+            assert part.shape == (rows_p, W, 4)
+            for y in range(Hh):
+                if (y // 16) % n == r:
+                    uni[y] = part[((y // 16) // n) * 16 + (y % 16)]
+        assert np.array_equal(uni, full)
+    renderer.set_option(L.GSWT_OPT_TIMING, 2)
+
+
+def test_pair_total_is_carried_in_64_bits(renderer):
+    """k_totals folds the super-group sums in 64 bits -- a frame past 2^32 pairs reports its true count and the
+    overflow flag instead of wrapping."""
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    for n_super, big in ((7, False), (1500, True), (2049, True)):
+        pairs = rng.integers(0, 3_000_000 if big else 1000, size=n_super, dtype=np.uint32)
+        if big:
+            pairs[5] = 0xFFFFFFF0
+        vis = rng.integers(0, 65536, size=n_super, dtype=np.uint32)
+        cnt = (C.c_ulonglong * 4)()
+        excl = np.zeros(n_super, dtype=np.uint32)
+        cap = 1 << 30
+        rc = lib.gswt_debug_totals(renderer._h, pairs.ctypes.data, vis.ctypes.data, n_super, cap, cnt, excl.ctypes.data)
+        assert rc == 0
+        total = int(pairs.astype(np.uint64).sum())
+        assert cnt[1] == total and cnt[0] == int(vis.astype(np.uint64).sum())
+        assert (cnt[3] != 0) == (total > cap)
+        want = np.concatenate([[0], np.cumsum(pairs.astype(np.uint64))[:-1]]) & 0xFFFFFFFF
+        assert np.array_equal(excl.astype(np.uint64), want)
