@@ -24,6 +24,7 @@
 
 namespace gswt {
 void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, const DrawBounds*, uint32_t*, uint32_t, uint32_t*, uint32_t);
+void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*);
 void launch_draw_bounds(hipStream_t, const Frame&, const DrawDev*, uint32_t, const uint2*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
                         const uint4*, DrawBounds*);
 size_t radix_ws_words(uint32_t, int);
@@ -75,11 +76,64 @@ struct DevBuf {
 
 struct ListRef { uint32_t pair_base, pair_count, self_base, self_count; };
 
+// pinned host staging (asynchronous uploads read it after the call has returned)
+template <typename T>
+struct HostBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        const size_t ncap = n + n / 4 + 64;
+        T* np = nullptr;
+        hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&np), ncap * sizeof(T), hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        if (p) hipHostFree(p);
+        p = np; cap = ncap;
+        return hipSuccess;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 }  // namespace
 
 // Three frame slots: c3 4 220 (two) -> 4 600 frames/s (three); four slots are SLOWER (4 190, also with three in flight: the
 // frames then rotate over four sets of per-frame buffers and the working set outgrows the Infinity Cache).
 constexpr int kFrameSlots = 3;
+
+// The per-sort-event state (GSWTRenderer's swap-in of a SortData, state.rs:361-376): draw descriptors, chunk tables, merged
+// lists, band-cull bounds.  Double-buffered: gswt_set_draws* fills the set that is NOT current while the frames in flight
+// keep reading the one they were submitted with, so a sort event does not drain the frame pipeline.
+constexpr int kDrawSets = 2;
+struct DrawSet {
+    DevBuf<DrawDev> draws;
+    DevBuf<uint2> chunk_tab;
+    DevBuf<uint2> chunk_tab_xcd;           // chunk_tab in k_project's launch order: all chunks of a draw on XCD (draw % 8)
+    DevBuf<uint32_t> merged_list, merged_map;
+    DevBuf<DrawBounds> draw_bounds;        // per draw, for the band cull of column-sharded frames
+    DevBuf<uint32_t> xcd_first;            // per draw: position of its first chunk in its XCD's launch list
+    // pinned staging of the per-sort-event upload (one asynchronous copy each on the ctx stream) + the event behind them
+    HostBuf<DrawDev> h_draws;
+    HostBuf<uint32_t> h_xcd_first;
+    HostBuf<MergeSeg> h_segs;
+    HostBuf<MergeGroup> h_groups;
+    HostBuf<unsigned long long> h_n64;
+    hipEvent_t ev_up = nullptr;
+    bool ev_up_pending = false;
+    size_t n_merged = 0;
+    bool bounds_valid = false;
+    uint32_t bounds_key[6] = {};           // map_half_wh, center_coord, tile_width bits, surface_type the merged offsets were formed with
+    uint32_t n_launch = 0;                 // length of chunk_tab_xcd (>= n_chunks: short per-XCD lists are padded)
+    uint32_t n_draws = 0, n_chunks = 0;
+    uint64_t n_entries = 0;
+    void release()
+    {
+        draws.release(); chunk_tab.release(); chunk_tab_xcd.release(); merged_list.release(); merged_map.release(); draw_bounds.release();
+        xcd_first.release(); h_draws.release(); h_xcd_first.release(); h_segs.release(); h_groups.release(); h_n64.release();
+        if (ev_up) hipEventDestroy(ev_up);
+        ev_up = nullptr;
+    }
+};
 
 struct FrameArgs {
     gswt_camera_uniforms cam;
@@ -105,6 +159,7 @@ struct FrameSlot {
     int collected_rc = 0;                  // timings wait here for gswt_render_wait
     gswt_timings collected_timings = {};
     FrameArgs args;
+    int set = 0;                           // draw set the frame was submitted with (a re-run after overflow uses the same one)
     uint32_t cap = 0;
     int n_tiles = 0;
     int timing_level = 0;
@@ -149,10 +204,8 @@ struct gswt_ctx {
     int proxy_size = 0, proxy_mips = 0, proxy_grid_dim = 2048;
     uint32_t proxy_mip_off[16] = {};
     // draws
-    DevBuf<DrawDev> draws;
-    DevBuf<uint2> chunk_tab;
-    DevBuf<uint32_t> merged_list, merged_map;
-    size_t n_merged = 0;
+    DrawSet sets[kDrawSets];
+    int cur_set = 0;                       // the set frames submitted from now on read
     // on-device merged lists
     DevBuf<int32_t> raw_depth;
     std::vector<uint32_t> raw_off;          // [(lod*n_tile + tile)*n_view + view] -> offset in raw_depth
@@ -160,13 +213,6 @@ struct gswt_ctx {
     DevBuf<MergeSeg> mg_segs;
     DevBuf<MergeGroup> mg_groups;
     DevBuf<uint32_t> mg_ws;
-    DevBuf<DrawBounds> draw_bounds;        // per draw, for the band cull of column-sharded frames
-    bool bounds_valid = false;             // false after every gswt_set_draws*
-    uint32_t bounds_key[6] = {};           // map_half_wh, center_coord, tile_width bits, surface_type the merged offsets were formed with
-    DevBuf<uint2> chunk_tab_xcd;           // chunk_tab in k_project's launch order: all chunks of a draw on XCD (draw % 8)
-    uint32_t n_launch = 0;                 // its length (>= n_chunks: short per-XCD lists are padded)
-    uint32_t n_draws = 0, n_chunks = 0;
-    uint64_t n_entries = 0;
     bool draws_ready = false;
     // frame (the per-frame buffers live in the slots)
     uint32_t pair_cap = 0;                 // capacity the pair buffers / grids are sized for (grows on overflow)
@@ -248,6 +294,17 @@ static hipError_t collect_pending(gswt_ctx* c)
     return sync_all(c);
 }
 
+// Frames still in flight on draw set `set` are run to completion before that set is refilled.
+static void collect_set(gswt_ctx* c, int set)
+{
+    for (auto& sl : c->slots)
+        if (sl.pending && !sl.collected && sl.set == set) {
+            sl.collected_rc = finish_frame(c, sl);
+            sl.collected_timings = c->timings;
+            sl.collected = true;
+        }
+}
+
 extern "C" {
 
 int gswt_create(int device_id, gswt_ctx** out)
@@ -280,8 +337,8 @@ void gswt_destroy(gswt_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     sync_all(c);
-    c->tex.release(); c->static_list.release(); c->hmap.release(); c->draws.release(); c->chunk_tab.release(); c->chunk_tab_xcd.release(); c->draw_bounds.release();
-    c->merged_list.release(); c->merged_map.release(); c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release();
+    c->tex.release(); c->static_list.release(); c->hmap.release(); for (auto& ds : c->sets) ds.release();
+    c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release();
     c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
     for (auto& sl : c->slots) {
         sl.release_buffers();
@@ -396,9 +453,19 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     if (!device_merge && n_merged && (!merged_gs_index || !merged_map_id)) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged arrays missing");
     if (n_merged >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: merged lists exceed 2^32 entries");
     hipSetDevice(c->device);
-    HIP_TRY(c, collect_pending(c));      // a frame in flight is finished (and re-run if it overflowed) against the draws it was submitted with
-    c->draws_ready = false;
-    std::vector<DrawDev> dd((size_t)n_draws);
+    // The new list goes into the draw set that is not current; the frames in flight keep the set they were submitted with
+    // (only a frame still running on the set being refilled -- two sort events old -- is waited for), so a sort event
+    // does not drain the frame pipeline.  The upload is asynchronous on the ctx stream from the set's pinned staging; every
+    // frame submitted afterwards starts behind an event recorded on that stream (enqueue_frame).
+    const int target = c->draws_ready ? (c->cur_set + 1) % kDrawSets : c->cur_set;
+    collect_set(c, target);
+    DrawSet& D = c->sets[target];
+    // the set's pinned staging is free again once its previous upload has been consumed
+    if (D.ev_up_pending) { HIP_TRY(c, hipEventSynchronize(D.ev_up)); D.ev_up_pending = false; }
+    if (!D.ev_up) HIP_TRY(c, hipEventCreateWithFlags(&D.ev_up, hipEventDisableTiming));
+    HIP_TRY(c, D.h_draws.ensure((size_t)n_draws + 1));
+    HIP_TRY(c, D.h_xcd_first.ensure((size_t)n_draws + 1));
+    DrawDev* const dd = D.h_draws.p;
     uint64_t entries = 0;
     for (int i = 0; i < n_draws; i++) {
         const gswt_draw& g = draws[i];
@@ -438,38 +505,45 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
         entries += d.count;
     }
     if (entries >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: %llu list entries exceed 2^32", (unsigned long long)entries);
-    // composite-order slots: the LAST draw is nearest (drawn last = on top), so it gets the lowest slots
-    std::vector<uint2> chunks;
-    uint64_t slot = 0;
+    // composite-order slots: the LAST draw is nearest (drawn last = on top), so it gets the lowest slots.  A chunk = 256 list
+    // entries of one draw; chunk c of the frame = slot c * 256.  The two chunk tables (slot order; k_project's launch order:
+    // per-XCD lists, XCD = draw % 8, interleaved so that position p runs on XCD p % 8) are written on the DEVICE from the
+    // draw records (k_chunk_tabs): the host only sums the O(#draws) counts, and a sort event uploads O(#draws) bytes.
+    uint64_t slot = 0, per_xcd[8] = {};
     for (int i = n_draws - 1; i >= 0; i--) {
         DrawDev& d = dd[i];
         d.slot_base = (uint32_t)slot;
-        uint32_t nch = (d.count + kChunk - 1) / kChunk;
-        for (uint32_t k = 0; k < nch; k++) chunks.push_back(make_uint2((uint32_t)i, k * kChunk));
+        const uint32_t nch = (d.count + kChunk - 1) / kChunk;
+        D.h_xcd_first.p[i] = (uint32_t)per_xcd[i & 7];
+        per_xcd[i & 7] += nch;
         slot += (uint64_t)nch * kChunk;
     }
     if (slot >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: slot space exceeds 2^32");
-    HIP_TRY(c, c->draws.ensure(dd.size() + 1));
-    HIP_TRY(c, c->chunk_tab.ensure(chunks.size() + 1));
-    if (!dd.empty()) HIP_TRY(c, hipMemcpy(c->draws.p, dd.data(), dd.size() * sizeof(DrawDev), hipMemcpyHostToDevice));
-    if (!chunks.empty()) HIP_TRY(c, hipMemcpy(c->chunk_tab.p, chunks.data(), chunks.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    {   // launch-order table for k_project: per-XCD lists (XCD = draw % 8), interleaved so that position p runs on XCD p % 8
-        std::vector<uint2> per[8];
-        for (const uint2& ch : chunks) per[ch.x & 7u].push_back(ch);
-        size_t longest = 0;
-        for (auto& v : per) longest = std::max(longest, v.size());
-        std::vector<uint2> order(longest * 8, make_uint2(0u, 0xFFFFFFFFu));
-        for (int x = 0; x < 8; x++)
-            for (size_t k = 0; k < per[x].size(); k++) order[k * 8 + x] = per[x][k];
-        if (order.size() >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: chunk table too large");
-        HIP_TRY(c, c->chunk_tab_xcd.ensure(order.size() + 1));
-        if (!order.empty()) HIP_TRY(c, hipMemcpy(c->chunk_tab_xcd.p, order.data(), order.size() * sizeof(uint2), hipMemcpyHostToDevice));
-        c->n_launch = (uint32_t)order.size();
+    const size_t n_chunks = (size_t)(slot / kChunk);
+    size_t longest = 0;
+    for (int x = 0; x < 8; x++) longest = std::max<size_t>(longest, (size_t)per_xcd[x]);
+    if (longest * 8 >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: chunk table too large");
+    HIP_TRY(c, D.draws.ensure((size_t)n_draws + 1));
+    HIP_TRY(c, D.xcd_first.ensure((size_t)n_draws + 1));
+    HIP_TRY(c, D.chunk_tab.ensure(n_chunks + 1));
+    HIP_TRY(c, D.chunk_tab_xcd.ensure(longest * 8 + 1));
+    D.n_launch = (uint32_t)(longest * 8);
+    {
+        hipStream_t s = c->stream;
+        if (n_draws) {
+            HIP_TRY(c, hipMemcpyAsync(D.draws.p, dd, (size_t)n_draws * sizeof(DrawDev), hipMemcpyHostToDevice, s));
+            HIP_TRY(c, hipMemcpyAsync(D.xcd_first.p, D.h_xcd_first.p, (size_t)n_draws * 4, hipMemcpyHostToDevice, s));
+        }
+        if (longest) HIP_TRY(c, hipMemsetAsync(D.chunk_tab_xcd.p, 0xFF, longest * 8 * sizeof(uint2), s));      // padding of short per-XCD lists
+        launch_chunk_tabs(s, D.draws.p, D.xcd_first.p, (uint32_t)n_draws, D.chunk_tab.p, D.chunk_tab_xcd.p);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipEventRecord(D.ev_up, s));
+        D.ev_up_pending = true;
     }
     // merged arrays: pack gs_index | lod << 28
-    HIP_TRY(c, c->merged_list.ensure(n_merged + 1));
-    HIP_TRY(c, c->merged_map.ensure(n_merged + 1));
-    c->n_merged = n_merged;
+    HIP_TRY(c, D.merged_list.ensure(n_merged + 1));
+    HIP_TRY(c, D.merged_map.ensure(n_merged + 1));
+    D.n_merged = n_merged;
     if (n_merged && !device_merge) {
         std::vector<uint32_t> packed(n_merged);
         for (size_t k = 0; k < n_merged; k++) {
@@ -485,13 +559,14 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
                     packed[g.merged_offset + k] |= l << kLodShift;
                 }
         }
-        HIP_TRY(c, hipMemcpy(c->merged_list.p, packed.data(), n_merged * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->merged_map.p, merged_map_id, n_merged * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(D.merged_list.p, packed.data(), n_merged * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(D.merged_map.p, merged_map_id, n_merged * 4, hipMemcpyHostToDevice));
     }
-    c->n_draws = (uint32_t)n_draws;
-    c->n_chunks = (uint32_t)chunks.size();
-    c->bounds_valid = false;
-    c->n_entries = entries;
+    D.n_draws = (uint32_t)n_draws;
+    D.n_chunks = (uint32_t)n_chunks;
+    D.bounds_valid = false;
+    D.n_entries = entries;
+    c->cur_set = target;
     c->draws_ready = true;       // the per-frame buffers are sized by enqueue_frame, per slot
     return GSWT_OK;
 }
@@ -533,9 +608,20 @@ try {
     if (n_groups < 0 || n_members < 0 || (n_groups && (!groups || !members))) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: bad groups");
     if (n_groups && c->raw_cnt.empty()) return fail(c, GSWT_ERR_STATE, "gswt_set_draws_merge_groups before gswt_upload_raw_depth");
     if (n_groups > 32768) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws_merge_groups: more than 32768 merged groups");
-    // segments and group ranges (the concatenation order IS the merged-arena order)
-    std::vector<MergeSeg> segs;
-    std::vector<MergeGroup> grp((size_t)n_groups);
+    // segments and group ranges (the concatenation order IS the merged-arena order), staged in the target set's pinned memory
+    hipSetDevice(c->device);
+    const int target = c->draws_ready ? (c->cur_set + 1) % kDrawSets : c->cur_set;
+    collect_set(c, target);
+    DrawSet& D = c->sets[target];
+    if (D.ev_up_pending) { HIP_TRY(c, hipEventSynchronize(D.ev_up)); D.ev_up_pending = false; }
+    HIP_TRY(c, D.h_groups.ensure((size_t)n_groups + 1));
+    HIP_TRY(c, D.h_n64.ensure(1));
+    size_t seg_cap = 0;
+    for (int g = 0; g < n_groups; g++) seg_cap += 2 * (size_t)groups[g].n_members;
+    HIP_TRY(c, D.h_segs.ensure(seg_cap + 1));
+    MergeSeg* const segs = D.h_segs.p;
+    MergeGroup* const grp = D.h_groups.p;
+    size_t n_segs = 0;
     uint64_t total = 0;
     const size_t nv = (size_t)c->n_view;
     for (int g = 0; g < n_groups; g++) {
@@ -553,7 +639,7 @@ try {
                 MergeSeg sg;
                 sg.group = (uint32_t)g; sg.src = c->raw_off[lt * nv + G.view_id]; sg.len = c->raw_cnt[lt]; sg.start = (uint32_t)total;
                 sg.gs_offset = c->raw_merge_offset[lt]; sg.map_index = M.map_index; sg.lod = (uint32_t)lods[k]; sg._pad = 0;
-                if (sg.len) segs.push_back(sg);
+                if (sg.len) segs[n_segs++] = sg;
                 total += sg.len;
             }
         }
@@ -567,7 +653,7 @@ try {
                 return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: draw %d does not match group %u (offset %u/%u count %u/%u)", i, g,
                             draws[i].merged_offset, (int)g < n_groups ? grp[g].base : 0u, draws[i].merged_count, (int)g < n_groups ? grp[g].len : 0u);
         }
-    int rc = set_draws_impl(c, draws, n_draws, nullptr, nullptr, nullptr, (size_t)total, true);
+    int rc = set_draws_impl(c, draws, n_draws, nullptr, nullptr, nullptr, (size_t)total, true);       // fills the same target set
     if (rc != GSWT_OK) return rc;
     if (total == 0) return GSWT_OK;
     c->draws_ready = false;
@@ -575,23 +661,27 @@ try {
     const uint32_t n_total = (uint32_t)total;
     int gbits = 1;
     while ((1 << gbits) < n_groups) gbits++;
-    HIP_TRY(c, c->mg_segs.ensure(segs.size() + 1));
-    HIP_TRY(c, c->mg_groups.ensure(grp.size() + 1));
+    // The build's device scratch (segments, groups, sort workspace) is shared by all sort events; everything below is ordered
+    // on the ctx stream, so the previous build is through with it by the time this one's copies run.  Nothing is waited for:
+    // every frame submitted from now on starts behind an event recorded on that stream (enqueue_frame), i.e. behind the
+    // finished lists.  (A grown scratch buffer is the exception: hipFree waits for the device.)
+    HIP_TRY(c, c->mg_segs.ensure(n_segs + 1));
+    HIP_TRY(c, c->mg_groups.ensure((size_t)n_groups + 1));
     const size_t radix_words = radix_ws_words(n_total, 16 + gbits);
     HIP_TRY(c, c->mg_ws.ensure(4 * (size_t)n_total + radix_words + 16));
-    HIP_TRY(c, hipMemcpyAsync(c->mg_segs.p, segs.data(), segs.size() * sizeof(MergeSeg), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->mg_groups.p, grp.data(), grp.size() * sizeof(MergeGroup), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->mg_segs.p, segs, n_segs * sizeof(MergeSeg), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(c->mg_groups.p, grp, (size_t)n_groups * sizeof(MergeGroup), hipMemcpyHostToDevice, s));
     uint32_t* w = c->mg_ws.p;
     uint32_t* radix = w + 4 * (size_t)n_total;
     HIP_TRY(c, hipMemsetAsync(radix, 0, (radix_words + 16) * 4, s));
     unsigned long long* n_dev = reinterpret_cast<unsigned long long*>(radix + radix_words + (radix_words & 1));   // 8-byte aligned, followed by zeros
-    const unsigned long long n64 = n_total;
-    HIP_TRY(c, hipMemcpyAsync(n_dev, &n64, 8, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipStreamSynchronize(s));                 // n64 / segs / grp are host locals
-    launch_merge_build(s, c->mg_segs.p, (uint32_t)segs.size(), c->mg_groups.p, (uint32_t)n_groups, c->raw_depth.p, n_total, n_dev,
-                       w, w + n_total, w + 2 * (size_t)n_total, w + 3 * (size_t)n_total, radix, gbits, c->merged_list.p, c->merged_map.p);
+    D.h_n64.p[0] = n_total;
+    HIP_TRY(c, hipMemcpyAsync(n_dev, D.h_n64.p, 8, hipMemcpyHostToDevice, s));
+    launch_merge_build(s, c->mg_segs.p, (uint32_t)n_segs, c->mg_groups.p, (uint32_t)n_groups, c->raw_depth.p, n_total, n_dev,
+                       w, w + n_total, w + 2 * (size_t)n_total, w + 3 * (size_t)n_total, radix, gbits, D.merged_list.p, D.merged_map.p);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(s));
+    HIP_TRY(c, hipEventRecord(D.ev_up, s));
+    D.ev_up_pending = true;
     c->draws_ready = true;
     return GSWT_OK;
 } GSWT_CATCH("gswt_set_draws_merge_groups")
@@ -599,14 +689,15 @@ try {
 int gswt_debug_read_merged(gswt_ctx* c, uint32_t* packed_list, uint32_t* map_id, size_t capacity, size_t* n)
 try {
     if (!c || !n) return GSWT_ERR_BAD_ARG;
-    *n = c->n_merged;
+    const DrawSet& D = c->sets[c->cur_set];
+    *n = D.n_merged;
     if (!packed_list || !map_id) return GSWT_OK;
-    if (capacity < c->n_merged) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu entries, need %zu", capacity, c->n_merged);
+    if (capacity < D.n_merged) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu entries, need %zu", capacity, D.n_merged);
     hipSetDevice(c->device);
     HIP_TRY(c, sync_all(c));
-    if (c->n_merged) {
-        HIP_TRY(c, hipMemcpy(packed_list, c->merged_list.p, c->n_merged * 4, hipMemcpyDeviceToHost));
-        HIP_TRY(c, hipMemcpy(map_id, c->merged_map.p, c->n_merged * 4, hipMemcpyDeviceToHost));
+    if (D.n_merged) {
+        HIP_TRY(c, hipMemcpy(packed_list, D.merged_list.p, D.n_merged * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(map_id, D.merged_map.p, D.n_merged * 4, hipMemcpyDeviceToHost));
     }
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_read_merged")
@@ -665,22 +756,19 @@ static int validate_frame(gswt_ctx* c, const gswt_camera_uniforms* cam, const gs
 static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
 {
     const FrameArgs& a = sl.args;
+    DrawSet& D = c->sets[sl.set];
     const gswt_camera_uniforms* cam = &a.cam;
     const gswt_scene_uniforms* su = &a.su;
     const gswt_render_config* cfg = &a.cfg;
     const int width = a.width, height = a.height;
     hipStream_t s = sl.stream;
     const int sc = cfg->shard_count <= 1 ? 1 : cfg->shard_count;
-    // the frame starts after everything submitted to the ctx stream so far (inputs produced there, earlier
-    // readers of the output buffer), and runs on the slot's own stream
-    HIP_TRY(c, hipEventRecord(sl.ev_in, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(s, sl.ev_in, 0));
     {
-        const size_t n_slots_all = (size_t)c->n_chunks * kChunk;
+        const size_t n_slots_all = (size_t)D.n_chunks * kChunk;
         HIP_TRY(c, sl.rects.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
-        HIP_TRY(c, sl.block_sums.ensure((size_t)c->n_chunks + 1));
-        HIP_TRY(c, sl.draw_culled.ensure((size_t)c->n_draws + 1));
+        HIP_TRY(c, sl.block_sums.ensure((size_t)D.n_chunks + 1));
+        HIP_TRY(c, sl.draw_culled.ensure((size_t)D.n_draws + 1));
         if (su->draw_mode != 0u) HIP_TRY(c, sl.col_f.ensure(n_slots_all + 1));
     }
 
@@ -736,8 +824,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     float4* const d_out = a.d_out;
     HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1));
     const bool dbg = c->opt_debug_varyings != 0;
-    if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)c->n_entries + 1));
-    if (sc > 1 && out_px > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
+    if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)D.n_entries + 1));
 
     // The pair count P is only known on the device.  Everything downstream of k_project is launched
     // for a capacity `pair_cap` (blocks past the real P do nothing), so a frame needs no host round
@@ -745,19 +832,19 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // the buffers grow and the frame is re-run by finish_frame (first frame / sudden scene change only).
     int key_bits = 1;
     while ((1 << key_bits) < n_tiles) key_bits++;
-    if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(c->n_entries / 4, 1u << 20), 0xFFFFFF00ull);
+    if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(D.n_entries / 4, 1u << 20), 0xFFFFFF00ull);
     const uint32_t cap = c->pair_cap;
     sl.cap = cap;
     HIP_TRY(c, sl.keys_a.ensure((size_t)cap + 4)); HIP_TRY(c, sl.keys_b.ensure((size_t)cap + 4));     // k_ranges reads whole quads
     HIP_TRY(c, sl.vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure((size_t)cap + 1));
-    const size_t n_super2 = 3 * ((size_t)c->n_chunks / 256 + 1);     // pair sums, visible sums, exclusive pair prefix (k_totals)
+    const size_t n_super2 = 3 * ((size_t)D.n_chunks / 256 + 1);     // pair sums, visible sums, exclusive pair prefix (k_totals)
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
-    const uint32_t n_slots = c->n_chunks * (uint32_t)kChunk;
+    const uint32_t n_slots = D.n_chunks * (uint32_t)kChunk;
     const size_t depth_radix_words = depth_order ? radix_ws_words(n_slots, 32) : 0;
     const size_t radix_words = radix_ws_words(cap, key_bits) + depth_radix_words;
     if (depth_order) {
-        HIP_TRY(c, sl.depth_ws.ensure(4 * (size_t)n_slots + (size_t)c->n_chunks + 16));
-        HIP_TRY(c, sl.scan_ws.ensure((size_t)c->n_chunks / 1024 + 4096));
+        HIP_TRY(c, sl.depth_ws.ensure(4 * (size_t)n_slots + (size_t)D.n_chunks + 16));
+        HIP_TRY(c, sl.scan_ws.ensure((size_t)D.n_chunks / 1024 + 4096));
     }
     // one contiguous u32 region cleared by k_cull: [counters: 16][super_sums: n_super2][radix histograms]
     HIP_TRY(c, sl.ghist.ensure(16 + n_super2 + radix_words + 16));
@@ -772,31 +859,39 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     unsigned long long* const d_P = d_counters + 1;
     hipEvent_t* ev = sl.ev;
     // ---- cull (+ clears the frame's accumulators) + project
-    if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
     if (f.band_cull) {
-        // bounds of every draw's splat centres: per sort event, and again when the uniforms that place merged members move
+        // bounds of every draw's splat centres: per sort event, and again when the uniforms that place merged members move.
+        // Computed on the CTX stream before this frame's start event is recorded there, so this frame and every later one
+        // is ordered behind it without any host wait; frames already in flight on this set computed theirs earlier.
         uint32_t key[6] = {su->map_half_wh[0], su->map_half_wh[1], (uint32_t)su->center_coord[0], (uint32_t)su->center_coord[1], 0u, su->surface_type};
         memcpy(&key[4], &su->tile_width, 4);
-        if (!c->bounds_valid || memcmp(key, c->bounds_key, sizeof(key)) != 0) {
-            for (auto& other : c->slots)                       // the other slot's frame may still be reading the old bounds
-                if (&other != &sl && other.stream) HIP_TRY(c, hipStreamSynchronize(other.stream));
-            HIP_TRY(c, c->draw_bounds.ensure((size_t)c->n_draws + 1));
-            launch_draw_bounds(s, f, c->draws.p, c->n_draws, c->chunk_tab.p, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
-                               c->tex.p, c->draw_bounds.p);
-            HIP_TRY(c, hipStreamSynchronize(s));               // the other slot may enqueue right after us on its own stream
-            memcpy(c->bounds_key, key, sizeof(key));
-            c->bounds_valid = true;
+        const bool stale = D.bounds_valid && memcmp(key, D.bounds_key, sizeof(key)) != 0;
+        if (!D.bounds_valid || stale) {
+            if (stale)                                          // earlier frames on this set may still read the old bounds (rare:
+                for (auto& other : c->slots)                   // the placing uniforms normally change with a sort event = a new set)
+                    if (&other != &sl && other.set == sl.set && other.stream) HIP_TRY(c, hipStreamSynchronize(other.stream));
+            HIP_TRY(c, D.draw_bounds.ensure((size_t)D.n_draws + 1));
+            launch_draw_bounds(c->stream, f, D.draws.p, D.n_draws, D.chunk_tab.p, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
+                               c->tex.p, D.draw_bounds.p);
+            memcpy(D.bounds_key, key, sizeof(key));
+            D.bounds_valid = true;
         }
     }
-    launch_cull(s, f, c->draws.p, c->n_draws, sl.draw_culled.p, c->draw_bounds.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
+    // the frame starts after everything submitted to the ctx stream so far (inputs produced there, earlier readers of
+    // the output buffer, the device-side merged-list build and the draw bounds of its draw set), on the slot's own stream
+    HIP_TRY(c, hipEventRecord(sl.ev_in, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(s, sl.ev_in, 0));
+    if (sc > 1 && out_px > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
+    if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
+    launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, D.draw_bounds.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
-    launch_project(s, dbg, f, c->draws.p, c->chunk_tab_xcd.p, c->n_launch, c->n_chunks, c->static_list.p, c->merged_list.p, c->merged_map.p,
+    launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p, sl.col_f.p, cap);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
     // ---- emit
     if (!depth_order) {
-        launch_emit(s, f, c->n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     } else {
         // d_counters[4] = n_slots (the radix kernels read their item count from device memory)
         sl.hc[7] = n_slots;
@@ -861,7 +956,7 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
         HIP_TRY(c, hipEventElapsedTime(&t.ms_total, ev[0], ev[6]));
         HIP_TRY(c, hipEventElapsedTime(&t.ms_composite_kernel, ev[7], ev[8]));
     }
-    t.n_draws = c->n_draws; t.n_instanced = c->n_entries; t.n_visible = sl.hc[0]; t.n_pairs = P; t.n_tiles = (uint32_t)sl.n_tiles;
+    t.n_draws = c->sets[sl.set].n_draws; t.n_instanced = c->sets[sl.set].n_entries; t.n_visible = sl.hc[0]; t.n_pairs = P; t.n_tiles = (uint32_t)sl.n_tiles;
     return GSWT_OK;
 }
 
@@ -900,6 +995,7 @@ try {
     for (int k = 0; k < kFrameSlots; k++) if (!c->slots[k].pending) { si0 = k; break; }
     FrameSlot& sl = c->slots[si0];
     if (sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render: every frame slot holds an uncollected gswt_render_async ticket");
+    sl.set = c->cur_set;
     fill_args(sl.args, cam, su, cfg, width, height, d_bg, d_bgd, d_out);
     rc = enqueue_frame(c, sl);
     if (rc != GSWT_OK) return rc;
@@ -934,6 +1030,7 @@ try {
         if (rc != GSWT_OK) return rc;
     }
     sl.seq = ++c->frame_seq;
+    sl.set = c->cur_set;
     fill_args(sl.args, cam, su, cfg, width, height, reinterpret_cast<const float4*>(bg_rgba_dev), bg_depth_dev,
               reinterpret_cast<float4*>(out_rgba_dev));
     rc = enqueue_frame(c, sl);
@@ -1136,13 +1233,13 @@ try {
 int gswt_debug_read_projected(gswt_ctx* c, void* out, size_t capacity_entries, size_t* n_entries)
 try {
     if (!c || !n_entries) return GSWT_ERR_BAD_ARG;
-    *n_entries = (size_t)c->n_entries;
+    *n_entries = (size_t)c->sets[c->cur_set].n_entries;
     if (!out) return GSWT_OK;
     if (!c->opt_debug_varyings || !c->dbg.p) return fail(c, GSWT_ERR_STATE, "enable GSWT_OPT_DEBUG_VARYINGS and render first");
-    if (capacity_entries < c->n_entries) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu entries, need %llu", capacity_entries, (unsigned long long)c->n_entries);
+    if (capacity_entries < c->sets[c->cur_set].n_entries) return fail(c, GSWT_ERR_CAPACITY, "buffer holds %zu entries, need %llu", capacity_entries, (unsigned long long)c->sets[c->cur_set].n_entries);
     hipSetDevice(c->device);
     HIP_TRY(c, sync_all(c));
-    HIP_TRY(c, hipMemcpy(out, c->dbg.p, (size_t)c->n_entries * sizeof(Varyings), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out, c->dbg.p, (size_t)c->sets[c->cur_set].n_entries * sizeof(Varyings), hipMemcpyDeviceToHost));
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_read_projected")
 

@@ -252,6 +252,24 @@ __global__ __launch_bounds__(256) void k_draw_bounds_init(DrawBounds* __restrict
     bounds[i] = b;
 }
 
+// Chunk tables of a draw set, written on the device from the draw records (per sort event): a chunk = 256 list entries of
+// one draw.  chunk_tab is in slot order (chunk c = slots c * 256 ...); chunk_tab_xcd is k_project's launch order: the
+// chunks of draw d sit in the list of XCD d % 8, lists interleaved so that launch position p runs on XCD p % 8 (short
+// lists are padded with 0xFFFFFFFF by a memset before this kernel).  One workgroup per draw.
+__global__ __launch_bounds__(256) void k_chunk_tabs(const DrawDev* __restrict__ draws, const uint32_t* __restrict__ xcd_first, uint32_t n_draws,
+                                                    uint2* __restrict__ chunk_tab, uint2* __restrict__ chunk_tab_xcd)
+{
+    const uint32_t d = blockIdx.x;
+    if (d >= n_draws) return;
+    const uint32_t nch = (draws[d].count + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
+    const uint32_t c0 = draws[d].slot_base / (uint32_t)kChunk, x0 = xcd_first[d];
+    for (uint32_t k = threadIdx.x; k < nch; k += 256u) {
+        const uint2 e = make_uint2(d, k * (uint32_t)kChunk);
+        chunk_tab[c0 + k] = e;
+        chunk_tab_xcd[(size_t)(x0 + k) * 8u + (d & 7u)] = e;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // k_cull: the CPU viewport culling + lod_enable skip of renderer.rs:472-497, one thread per draw.
 // ------------------------------------------------------------------------------------
@@ -1613,6 +1631,11 @@ __global__ void k_unshard(const float4* __restrict__ gathered, float4* __restric
 }
 
 // ---- launch wrappers (called from gswt_api.hip) -------------------------------------
+void launch_chunk_tabs(hipStream_t s, const DrawDev* draws, const uint32_t* xcd_first, uint32_t n_draws, uint2* chunk_tab, uint2* chunk_tab_xcd)
+{
+    if (n_draws) hipLaunchKernelGGL(k_chunk_tabs, dim3(n_draws), dim3(256), 0, s, draws, xcd_first, n_draws, chunk_tab, chunk_tab_xcd);
+}
+
 void launch_draw_bounds(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, const uint2* chunk_tab, uint32_t n_chunks,
                         const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
                         DrawBounds* bounds)

@@ -417,6 +417,23 @@ class WangTile:
         return SortData(tiles, arr(sd.merged_gs_index), arr(sd.merged_map_id), arr(sd.merged_lod_id),
                         [draws[i] for i in range(sd.n_tiles)], groups, members)
 
+    def sort_tiles_raw(self, cam_pos, view_proj):
+        """sort_tiles + gswt_renderer_build_draws without per-tile Python objects (the worker thread of a frame loop calls
+        this once per sort event): -> (draws C array, n_draws, groups C array, n_groups, members C array, n_members); the
+        arrays are copies owned by the caller, so the next sort_tiles may run while they are being uploaded."""
+        vp = np.ascontiguousarray(view_proj, dtype=np.float32)
+        sd = SortDataC()
+        _check(self._lib.gswt_wang_sort_tiles(self._h, _f3(cam_pos), _ptr(vp), C.byref(sd)))
+        draws = (L.Draw * max(1, sd.n_tiles))()
+        _check(self._lib.gswt_renderer_build_draws(C.byref(sd), draws))
+        groups = (L.MergeGroup * max(1, sd.n_groups))()
+        members = (L.MergeMember * max(1, sd.n_members))()
+        if sd.n_groups:
+            C.memmove(groups, sd.groups, sd.n_groups * C.sizeof(L.MergeGroup))
+        if sd.n_members:
+            C.memmove(members, sd.members, sd.n_members * C.sizeof(L.MergeMember))
+        return draws, int(sd.n_tiles), groups, int(sd.n_groups), members, int(sd.n_members)
+
     def scene_uniforms(self, *, splat_scale=1.0, scene_scale=(1.0, 1.0, 1.0), height_map_scale_v=1.0) -> L.SceneUniforms:
         """SceneUniforms::from_data, renderer.rs:631-672"""
         su = L.SceneUniforms()

@@ -125,6 +125,10 @@ class GSWTRenderer:
         arr = (L.Draw * max(1, len(draws)))(*draws)
         self._check(self._lib.gswt_set_draws_merge_groups(self._h, arr, len(draws), groups_ptr, n_groups, members_ptr, n_members))
 
+    def set_draws_merge_groups_raw(self, draws_arr, n_draws: int, groups_arr, n_groups: int, members_arr, n_members: int):
+        """The same from C arrays (WangTile.sort_tiles_raw): no per-draw Python work on the render thread."""
+        self._check(self._lib.gswt_set_draws_merge_groups(self._h, draws_arr, n_draws, groups_arr, n_groups, members_arr, n_members))
+
     def read_merged(self):
         n = C.c_size_t(0)
         self._check(self._lib.gswt_debug_read_merged(self._h, None, None, 0, C.byref(n)))

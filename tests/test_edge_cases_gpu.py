@@ -248,5 +248,5 @@ def test_pair_total_is_carried_in_64_bits(renderer):
         total = int(pairs.astype(np.uint64).sum())
         assert cnt[1] == total and cnt[0] == int(vis.astype(np.uint64).sum())
         assert (cnt[3] != 0) == (total > cap)
-        want = np.concatenate([[0], np.cumsum(pairs.astype(np.uint64))[:-1]]) & 0xFFFFFFFF
+        want = np.concatenate([np.zeros(1, np.uint64), np.cumsum(pairs.astype(np.uint64))[:-1]]) & np.uint64(0xFFFFFFFF)
         assert np.array_equal(excl.astype(np.uint64), want)
