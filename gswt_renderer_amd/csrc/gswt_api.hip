@@ -28,21 +28,21 @@ void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, u
 void launch_draw_bounds(hipStream_t, const Frame&, const DrawDev*, uint32_t, const uint2*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
                         const uint4*, DrawBounds*);
 size_t radix_ws_words(uint32_t, int);
-void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long long*, const uint2*, const Rec*, const uint32_t*,
+void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long long*, const uint2*, const float*, const uint32_t*,
                        uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                        unsigned long long*, uint32_t*, uint32_t*);
 void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uint32_t*);
-void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
+void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, uint32_t, const uint32_t*, const uint32_t*,
-                    const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, uint32_t*, uint32_t*,
+                    const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
                     unsigned long long*, Varyings*, float4*, uint32_t);
 void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
                  uint32_t*, uint32_t*);
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*);
 void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
-void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float4*, const float4*, const float*, float4*, int, int,
+void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, const unsigned long long*, unsigned long long*);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
@@ -117,6 +117,7 @@ struct DrawSet {
     HostBuf<uint32_t> h_xcd_first;
     HostBuf<MergeSeg> h_segs;
     HostBuf<MergeGroup> h_groups;
+    HostBuf<uint2> h_blocks;               // (segment, first entry) of every <= 1024-entry block of the merged-list build
     HostBuf<unsigned long long> h_n64;
     hipEvent_t ev_up = nullptr;
     bool ev_up_pending = false;
@@ -129,7 +130,7 @@ struct DrawSet {
     void release()
     {
         draws.release(); chunk_tab.release(); chunk_tab_xcd.release(); merged_list.release(); merged_map.release(); draw_bounds.release();
-        xcd_first.release(); h_draws.release(); h_xcd_first.release(); h_segs.release(); h_groups.release(); h_n64.release();
+        xcd_first.release(); h_draws.release(); h_xcd_first.release(); h_segs.release(); h_groups.release(); h_blocks.release(); h_n64.release();
         if (ev_up) hipEventDestroy(ev_up);
         ev_up = nullptr;
     }
@@ -173,11 +174,12 @@ struct FrameSlot {
     DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x n_slots key/val ping-pong + per-block counts
     DevBuf<float4> partials;
     DevBuf<float4> col_f;                  // debug draw modes: float colours per slot
+    DevBuf<float> depths;                  // per-slot depth: frames with a proxy depth buffer or GSWT_ORDER_DEPTH only
     void release_buffers()
     {
         rects.release(); recs.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
         keys_b.release(); vals_a.release(); vals_b.release(); ghist.release(); ranges.release(); item_base.release();
-        depth_ws.release(); partials.release(); item_tab.release(); col_f.release();
+        depth_ws.release(); partials.release(); item_tab.release(); col_f.release(); depths.release();
     }
 };
 
@@ -212,6 +214,7 @@ struct gswt_ctx {
     std::vector<uint32_t> raw_cnt, raw_merge_offset;   // [lod*n_tile + tile]
     DevBuf<MergeSeg> mg_segs;
     DevBuf<MergeGroup> mg_groups;
+    DevBuf<uint2> mg_blocks;
     DevBuf<uint32_t> mg_ws;
     bool draws_ready = false;
     // frame (the per-frame buffers live in the slots)
@@ -338,7 +341,7 @@ void gswt_destroy(gswt_ctx* c)
     hipSetDevice(c->device);
     sync_all(c);
     c->tex.release(); c->static_list.release(); c->hmap.release(); for (auto& ds : c->sets) ds.release();
-    c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release();
+    c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release(); c->mg_blocks.release();
     c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
     for (auto& sl : c->slots) {
         sl.release_buffers();
@@ -667,6 +670,17 @@ try {
     // finished lists.  (A grown scratch buffer is the exception: hipFree waits for the device.)
     HIP_TRY(c, c->mg_segs.ensure(n_segs + 1));
     HIP_TRY(c, c->mg_groups.ensure((size_t)n_groups + 1));
+    // block table: every segment cut into runs of <= 1024 entries (what one workgroup of k_mg_minmax / k_mg_keys handles)
+    size_t n_blocks = 0;
+    for (size_t q = 0; q < n_segs; q++) n_blocks += ((size_t)segs[q].len + 1023) / 1024;
+    HIP_TRY(c, D.h_blocks.ensure(n_blocks + 1));
+    {
+        size_t b = 0;
+        for (size_t q = 0; q < n_segs; q++)
+            for (uint32_t off = 0; off < segs[q].len; off += 1024u) D.h_blocks.p[b++] = make_uint2((uint32_t)q, off);
+    }
+    HIP_TRY(c, c->mg_blocks.ensure(n_blocks + 1));
+    HIP_TRY(c, hipMemcpyAsync(c->mg_blocks.p, D.h_blocks.p, n_blocks * sizeof(uint2), hipMemcpyHostToDevice, s));
     const size_t radix_words = radix_ws_words(n_total, 16 + gbits);
     HIP_TRY(c, c->mg_ws.ensure(4 * (size_t)n_total + radix_words + 16));
     HIP_TRY(c, hipMemcpyAsync(c->mg_segs.p, segs, n_segs * sizeof(MergeSeg), hipMemcpyHostToDevice, s));
@@ -677,7 +691,7 @@ try {
     unsigned long long* n_dev = reinterpret_cast<unsigned long long*>(radix + radix_words + (radix_words & 1));   // 8-byte aligned, followed by zeros
     D.h_n64.p[0] = n_total;
     HIP_TRY(c, hipMemcpyAsync(n_dev, D.h_n64.p, 8, hipMemcpyHostToDevice, s));
-    launch_merge_build(s, c->mg_segs.p, (uint32_t)n_segs, c->mg_groups.p, (uint32_t)n_groups, c->raw_depth.p, n_total, n_dev,
+    launch_merge_build(s, c->mg_segs.p, (uint32_t)n_segs, c->mg_blocks.p, (uint32_t)n_blocks, c->mg_groups.p, (uint32_t)n_groups, c->raw_depth.p, n_total, n_dev,
                        w, w + n_total, w + 2 * (size_t)n_total, w + 3 * (size_t)n_total, radix, gbits, D.merged_list.p, D.merged_map.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(D.ev_up, s));
@@ -770,6 +784,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         HIP_TRY(c, sl.block_sums.ensure((size_t)D.n_chunks + 1));
         HIP_TRY(c, sl.draw_culled.ensure((size_t)D.n_draws + 1));
         if (su->draw_mode != 0u) HIP_TRY(c, sl.col_f.ensure(n_slots_all + 1));
+        if (a.d_bgd || cfg->order_mode == GSWT_ORDER_DEPTH) HIP_TRY(c, sl.depths.ensure(n_slots_all + 1));
     }
 
     Frame f;
@@ -824,6 +839,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     float4* const d_out = a.d_out;
     HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1));
     const bool dbg = c->opt_debug_varyings != 0;
+    const bool need_depths = a.d_bgd != nullptr || cfg->order_mode == GSWT_ORDER_DEPTH;
     if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)D.n_entries + 1));
 
     // The pair count P is only known on the device.  Everything downstream of k_project is launched
@@ -886,7 +902,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, D.draw_bounds.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
-                   c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, sl.block_sums.p, d_super,
+                   c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p, sl.col_f.p, cap);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
     // ---- emit
@@ -897,7 +913,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         sl.hc[7] = n_slots;
         HIP_TRY(c, hipMemcpyAsync(d_counters + 4, &sl.hc[7], 8, hipMemcpyHostToDevice, s));
         uint32_t* dw = sl.depth_ws.p;
-        launch_emit_depth(s, f, n_slots, d_counters + 4, sl.rects.p, sl.recs.p, sl.block_sums.p, dw, dw + n_slots, dw + 2 * (size_t)n_slots,
+        launch_emit_depth(s, f, n_slots, d_counters + 4, sl.rects.p, sl.depths.p, sl.block_sums.p, dw, dw + n_slots, dw + 2 * (size_t)n_slots,
                           dw + 3 * (size_t)n_slots, d_radix + radix_ws_words(cap, key_bits), dw + 4 * (size_t)n_slots, sl.scan_ws.p,
                           reinterpret_cast<uint32_t*>(d_counters + 2), cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     }
@@ -911,7 +927,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     launch_ranges(s, keys_sorted, cap, d_P, sl.ranges.p, (uint32_t)n_tiles);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[5], s));
     // ---- composite
-    launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
+    launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.depths.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
                      sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr,
                      d_counters, sl.hc_dev);
     c->last_n_tiles = (uint32_t)n_tiles;

@@ -2,6 +2,7 @@
 // Internal to libgswt_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include <stdint.h>
 
 namespace gswt {
@@ -75,14 +76,14 @@ struct DrawBounds {
     int32_t _pad;
 };
 
-// Projected splat record consumed by the compositor (48 B, three 16-B words).
-//   q0 = (iux, iuy, cxp, alpha)   q1 = (ivx, ivy, cyp, depth)   q2 = (rgba8 bits, hx, hy, 0)
-// iu / iv: rows of the inverse affine map pixel -> quad space (F2); (cxp, cyp): pixel-space centre (F1);
-// (hx, hy): conservative pixel half extents of |p| <= 2.
-struct __attribute__((aligned(16))) Rec {
-    float iux, iuy, cxp, alpha;
-    float ivx, ivy, cyp, depth;
-    float rgba8, hx, hy, pad;
+// Projected splat record consumed by the compositor (32 B, two 16-B words; one 32-B-aligned sector per gather).
+//   q0 = (iux, iuy, ivx, ivy)   q1 = (cxp, cyp, alpha, rgba8 bits)
+// iu / iv: rows of the inverse affine map pixel -> quad space (F2); (cxp, cyp): pixel-space centre (F1).
+// The conservative pixel half extents of |p| <= 2 are re-derived from iu / iv by the compositor's staging lane; the depth
+// lives in a side array (4 B per slot) that only depth-tested (proxy depth bound) and depth-ordered frames touch.
+struct __attribute__((aligned(32))) Rec {
+    float iux, iuy, ivx, ivy;
+    float cxp, cyp, alpha, rgba8;
 };
 
 // Device-side merged-list building (see k_mg_* in gswt_kernels.hip)

@@ -25,14 +25,13 @@ __device__ __forceinline__ float clampf(float e, float lo, float hi) { return fm
 
 // halfToFloat, gswt.wgsl:478-494: normals as IEEE; subnormals scale 2^-15 (f * 2^-25);
 // Inf/NaN -> 0.
+// (v_cvt_f32_f16 is exact for every finite half, subnormals included: the shader's subnormal scale is half of IEEE's, and its
+// Inf / NaN are 0 -- two selects on the exponent field instead of a branchy bit construction.)
 __device__ __forceinline__ float half_decode(uint32_t h)
 {
-    uint32_t e = (h >> 10) & 0x1Fu;
-    uint32_t f = h & 0x3FFu;
-    uint32_t s = (h & 0x8000u) << 16;
-    if (e == 0u) return u2f(s | __float_as_uint((float)f * 2.98023223876953125e-08f));  // 2^-25
-    if (e == 31u) return 0.0f;
-    return u2f(s | ((e + 112u) << 23) | (f << 13));
+    const uint32_t e = h & 0x7C00u;
+    const float x = __half2float(__ushort_as_half((unsigned short)h));
+    return e == 0x7C00u ? 0.0f : (e == 0u ? x * 0.5f : x);
 }
 
 // x mod w for the repeat sampler, identical to ((x % w) + w) % w in integer arithmetic but without the 64-bit
@@ -356,7 +355,7 @@ __global__ __launch_bounds__(256) void k_project(
     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
     const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, uint2* __restrict__ rects,
-    Rec* __restrict__ recs, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
+    Rec* __restrict__ recs, float* __restrict__ depths, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
     Varyings* __restrict__ dbg, float4* __restrict__ col_f)
 {
     __shared__ uint32_t s_wsum[4], s_wvis[4];
@@ -501,11 +500,12 @@ __global__ __launch_bounds__(256) void k_project(
                 t_ratio = clampf((cam_dist - td) / thw + 0.5f, 0.0f, 1.0f);
                 if ((lod_id == higher_lod + 1u && t_ratio == 0.0f) || (lod_id == higher_lod && t_ratio == 1.0f)) break;
             }
-            // A6 :152-167
+            // A6 :152-167 -- canonical sequence v2: dot products are fma chains, quotients are products
+            // with one correctly rounded reciprocal; the CPU checker evaluates exactly the same operations
             float cv[4], q[4];
-            for (int rr = 0; rr < 4; rr++) cv[rr] = ((f.V[rr] * c0 + f.V[4 + rr] * c1) + f.V[8 + rr] * c2) + f.V[12 + rr];
+            for (int rr = 0; rr < 4; rr++) cv[rr] = fmaf(f.V[8 + rr], c2, fmaf(f.V[4 + rr], c1, f.V[rr] * c0)) + f.V[12 + rr];
             for (int rr = 0; rr < 4; rr++)
-                q[rr] = ((f.GP[rr] * cv[0] + f.GP[4 + rr] * cv[1]) + f.GP[8 + rr] * cv[2]) + f.GP[12 + rr] * cv[3];
+                q[rr] = fmaf(f.GP[12 + rr], cv[3], fmaf(f.GP[8 + rr], cv[2], fmaf(f.GP[4 + rr], cv[1], f.GP[rr] * cv[0])));
             float clip = 1.2f * q[3];
             if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) break;
             if (f.dbg_flags & 16) break;               // ablation: stop after the frustum cull
@@ -526,10 +526,10 @@ __global__ __launch_bounds__(256) void k_project(
                 float FK[9], R[9];
                 for (int cc = 0; cc < 3; cc++)
                     for (int rr = 0; rr < 3; rr++)
-                        FK[3 * cc + rr] = (F[rr] * K[3 * cc] + F[3 + rr] * K[3 * cc + 1]) + F[6 + rr] * K[3 * cc + 2];
+                        FK[3 * cc + rr] = fmaf(F[6 + rr], K[3 * cc + 2], fmaf(F[3 + rr], K[3 * cc + 1], F[rr] * K[3 * cc]));
                 for (int cc = 0; cc < 3; cc++)
                     for (int rr = 0; rr < 3; rr++)
-                        R[3 * cc + rr] = (FK[rr] * F[cc] + FK[3 + rr] * F[3 + cc]) + FK[6 + rr] * F[6 + cc];
+                        R[3 * cc + rr] = fmaf(FK[6 + rr], F[6 + cc], fmaf(FK[3 + rr], F[3 + cc], FK[rr] * F[cc]));
                 for (int k = 0; k < 9; k++) K[k] = R[k];
             }
             for (int cc = 0; cc < 3; cc++)
@@ -537,44 +537,47 @@ __global__ __launch_bounds__(256) void k_project(
             // A8 :207-258
             float d0 = c0 - f.cam_pos[0], d1 = c1 - f.cam_pos[1], d2 = c2 - f.cam_pos[2];
             float t[3];
-            for (int rr = 0; rr < 3; rr++) t[rr] = (f.V[rr] * d0 + f.V[4 + rr] * d1) + f.V[8 + rr] * d2;
-            float txtz = t[0] / t[2], tytz = t[1] / t[2];
+            for (int rr = 0; rr < 3; rr++) t[rr] = fmaf(f.V[8 + rr], d2, fmaf(f.V[4 + rr], d1, f.V[rr] * d0));
+            const float rz = 1.0f / t[2];
+            float txtz = t[0] * rz, tytz = t[1] * rz;
             float limx = 1.3f * f.htan[0], limy = 1.3f * f.htan[1];
             t[0] = clampf(txtz, -limx, limx) * t[2];
             t[1] = clampf(tytz, -limy, limy) * t[2];
-            float tz2 = t[2] * t[2];
-            float j00 = f.focal[0] / t[2], j02 = -((f.focal[0] * t[0]) / tz2);
-            float j11 = f.focal[1] / t[2], j12 = -((f.focal[1] * t[1]) / tz2);
+            const float rz2 = rz * rz;
+            float j00 = f.focal[0] * rz, j02 = -((f.focal[0] * t[0]) * rz2);
+            float j11 = f.focal[1] * rz, j12 = -((f.focal[1] * t[1]) * rz2);
             float T0[3], T1[3];
             for (int rr = 0; rr < 3; rr++) {
-                T0[rr] = f.V[4 * rr + 0] * j00 + f.V[4 * rr + 2] * j02;
-                T1[rr] = f.V[4 * rr + 1] * j11 + f.V[4 * rr + 2] * j12;
+                T0[rr] = fmaf(f.V[4 * rr + 2], j02, f.V[4 * rr + 0] * j00);
+                T1[rr] = fmaf(f.V[4 * rr + 2], j12, f.V[4 * rr + 1] * j11);
             }
             float A0[3], A1[3];
             for (int k = 0; k < 3; k++) {
-                A0[k] = (T0[0] * K[3 * k] + T0[1] * K[3 * k + 1]) + T0[2] * K[3 * k + 2];
-                A1[k] = (T1[0] * K[3 * k] + T1[1] * K[3 * k + 1]) + T1[2] * K[3 * k + 2];
+                A0[k] = fmaf(T0[2], K[3 * k + 2], fmaf(T0[1], K[3 * k + 1], T0[0] * K[3 * k]));
+                A1[k] = fmaf(T1[2], K[3 * k + 2], fmaf(T1[1], K[3 * k + 1], T1[0] * K[3 * k]));
             }
-            float c00 = (A0[0] * T0[0] + A0[1] * T0[1]) + A0[2] * T0[2];
-            float c01 = (A1[0] * T0[0] + A1[1] * T0[1]) + A1[2] * T0[2];
-            float c11 = (A1[0] * T1[0] + A1[1] * T1[1]) + A1[2] * T1[2];
+            float c00 = fmaf(A0[2], T0[2], fmaf(A0[1], T0[1], A0[0] * T0[0]));
+            float c01 = fmaf(A1[2], T0[2], fmaf(A1[1], T0[1], A1[0] * T0[0]));
+            float c11 = fmaf(A1[2], T1[2], fmaf(A1[1], T1[1], A1[0] * T1[0]));
             float mid = 0.5f * (c00 + c11);
             float hxx = 0.5f * (c00 - c11);
-            float radius = sqrtf(hxx * hxx + c01 * c01);
+            float radius = sqrtf(fmaf(hxx, hxx, c01 * c01));
             float l1 = mid + radius, l2 = mid - radius;
             if (l2 < 0.0f) break;
             float vx = c01, vy = l1 - c00;
-            float vlen = sqrtf(vx * vx + vy * vy);
-            float ex = vx / vlen, ey = vy / vlen;
+            float vlen = sqrtf(fmaf(vx, vx, vy * vy));
+            const float rv = 1.0f / vlen;
+            float ex = vx * rv, ey = vy * rv;
             float smaj = fminf(sqrtf(2.0f * l1), 1024.0f);
             float smin = fminf(sqrtf(2.0f * l2), 1024.0f);
             float majx = smaj * ex, majy = smaj * ey;
             float minx = smin * ey, miny = smin * -ex;
-            // A9 :260-265, 402-410
-            float cr = (float)(w1.w & 0xFFu) / 255.0f;
-            float cg = (float)((w1.w >> 8) & 0xFFu) / 255.0f;
-            float cb = (float)((w1.w >> 16) & 0xFFu) / 255.0f;
-            float ca = (float)((w1.w >> 24) & 0xFFu) / 255.0f;
+            // A9 :260-265, 402-410 (byte / 255 as byte * fl(1 / 255))
+            const float k255 = 1.0f / 255.0f;
+            float cr = (float)(w1.w & 0xFFu) * k255;
+            float cg = (float)((w1.w >> 8) & 0xFFu) * k255;
+            float cb = (float)((w1.w >> 16) & 0xFFu) * k255;
+            float ca = (float)((w1.w >> 24) & 0xFFu) * k255;
             if (FULL && f.draw_mode != 0u) debug_draw_color(f, d, u2f(w0.x), u2f(w0.y), lod_id, t_ratio, cr, cg, cb);   // :268-399
             if (d.changing == 1u) {
                 if (lod_id != higher_lod) ca = ca * t_ratio;
@@ -582,31 +585,33 @@ __global__ __launch_bounds__(256) void k_project(
             }
             // rgba *= clamp(z/w + 1, 0, 1): identically 1 for 0 <= z/w, kept for the debug output only
             // A10 :415-419
-            float ndcx = q[0] / q[3], ndcy = q[1] / q[3], depth = q[2] / q[3];
+            const float rq = 1.0f / q[3];
+            float ndcx = q[0] * rq, ndcy = q[1] * rq, depth = q[2] * rq;
             if (DEBUG) {
-                float fade = clampf(q[2] / q[3] + 1.0f, 0.0f, 1.0f);
+                float fade = clampf(fmaf(q[2], rq, 1.0f), 0.0f, 1.0f);
                 vout.ndc[0] = ndcx; vout.ndc[1] = ndcy; vout.depth = depth;
                 vout.major[0] = majx; vout.major[1] = majy; vout.minor[0] = minx; vout.minor[1] = miny;
                 vout.rgba[0] = cr * fade; vout.rgba[1] = cg * fade; vout.rgba[2] = cb * fade; vout.rgba[3] = ca * fade;
             }
             if (!(depth >= 0.0f && depth <= 1.0f)) break;
             // Fragment setup F1, F2: pixel-space centre and inverse affine map
-            float cxp = (0.5f * ndcx + 0.5f) * f.W;
-            float cyp = (0.5f - 0.5f * ndcy) * f.H;
+            float cxp = fmaf(0.5f, ndcx, 0.5f) * f.W;
+            float cyp = fmaf(-0.5f, ndcy, 0.5f) * f.H;
             float hs = 0.5f * f.splat_scale;
             float ux = hs * majx, uy = -(hs * majy);
             float wx = hs * minx, wy = -(hs * miny);
-            float uu = ux * ux + uy * uy;
-            float ww = wx * wx + wy * wy;
+            float uu = fmaf(uy, uy, ux * ux);
+            float ww = fmaf(wy, wy, wx * wx);
             if (!((uu > 0.0f) && (ww > 0.0f) && (uu < __builtin_inff()) && (ww < __builtin_inff()))) break;
             if (DEBUG) vout.visible = 1;
             visible = true;
             // depth_compare Less against the 1.0 clear when no proxy depth is bound (renderer.rs:182,436)
             if (!f.has_depth && !(depth < 1.0f)) { visible = false; break; }
-            const float r_iux = ux / uu, r_iuy = uy / uu, r_ivx = wx / ww, r_ivy = wy / ww;
+            const float ruu = 1.0f / uu, rww = 1.0f / ww;
+            const float r_iux = ux * ruu, r_iuy = uy * ruu, r_ivx = wx * rww, r_ivy = wy * rww;
             // half extents of |p| <= 2, inflated by 1e-5 relative + 1e-3 px (conservative under f32 rounding)
-            float hx = 2.0f * sqrtf(ux * ux + wx * wx) * 1.00001f + 0.001f;
-            float hy = 2.0f * sqrtf(uy * uy + wy * wy) * 1.00001f + 0.001f;
+            float hx = fmaf(2.0f * sqrtf(fmaf(wx, wx, ux * ux)), 1.00001f, 0.001f);
+            float hy = fmaf(2.0f * sqrtf(fmaf(wy, wy, uy * uy)), 1.00001f, 0.001f);
             // pixels whose CENTRE lies inside the box: x in [ceil(c - h - 0.5), floor(c + h - 0.5)]
             float fx0 = ceilf(cxp - hx - 0.5f), fx1 = floorf(cxp + hx - 0.5f);
             float fy0 = ceilf(cyp - hy - 0.5f), fy1 = floorf(cyp + hy - 0.5f);
@@ -620,12 +625,13 @@ __global__ __launch_bounds__(256) void k_project(
                 if (f.dbg_flags & 8) count = 0;        // ablation: no record / rect stores, no pairs
                 if (count) {
                     my_rect = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
-                    // colour stays packed (bytes / 255 is re-evaluated by the compositor's staging lane, same
-                    // correctly rounded division); the two freed words carry the pixel half extents
+                    // 32-byte record: the inverse map, the centre, alpha and the packed colour (unpacked by the compositor's blend);
+                    // the pixel half extents are re-derived from the inverse map by the compositor's staging lane, the depth
+                    // goes to a side array that only depth-tested / depth-ordered frames read
                     Rec* dst = recs + slot;
-                    reinterpret_cast<float4*>(dst)[0] = make_float4(r_iux, r_iuy, cxp, ca);
-                    reinterpret_cast<float4*>(dst)[1] = make_float4(r_ivx, r_ivy, cyp, depth);
-                    reinterpret_cast<float4*>(dst)[2] = make_float4(__uint_as_float(w1.w), hx, hy, 0.0f);
+                    reinterpret_cast<float4*>(dst)[0] = make_float4(r_iux, r_iuy, r_ivx, r_ivy);
+                    reinterpret_cast<float4*>(dst)[1] = make_float4(cxp, cyp, ca, __uint_as_float(w1.w));
+                    if (depths) depths[slot] = depth;
                     if (FULL && f.draw_mode != 0u) col_f[slot] = make_float4(cr, cg, cb, 0.0f);   // debug colours are not bytes
                 }
             }
@@ -1002,7 +1008,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
 // equal depths keep composite order), and k_emit_perm emits the pairs in that order; the tile-bit sort
 // and the compositor are unchanged.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ rects, const Rec* __restrict__ recs,
+__global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ rects, const float* __restrict__ depths,
                                                     const uint32_t* __restrict__ block_sums, uint32_t n_slots,
                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
@@ -1011,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ re
     uint32_t key = 0xFFFFFFFFu;
     if (block_sums[slot >> 8] != 0u) {
         const uint2 rc = rects[slot];
-        if ((rc.x >> 16) >= (rc.x & 0xFFFFu)) key = __float_as_uint(recs[slot].depth);   // depth in [0, 1]: bit order = value order
+        if ((rc.x >> 16) >= (rc.x & 0xFFFFu)) key = __float_as_uint(depths[slot]);   // depth in [0, 1]: bit order = value order
     }
     keys[slot] = key;
     vals[slot] = slot;
@@ -1094,52 +1100,55 @@ __global__ __launch_bounds__(256) void k_mg_init(MergeGroup* __restrict__ groups
     if (g < n_groups) { groups[g].mn = 2147483647; groups[g].mx = -2147483647 - 1; }
 }
 
-__global__ __launch_bounds__(256) void k_mg_minmax(const MergeSeg* __restrict__ segs, uint32_t n_segs, const int32_t* __restrict__ raw,
-                                                   uint32_t n_total, MergeGroup* __restrict__ groups)
+// Both passes over the concatenation run on a block table built with the segments: block = (segment, first entry of up to
+// 1024 inside it), so a workgroup reads ONE segment record instead of binary-searching the segment of every entry
+// (k_mg_minmax was 75 us for 1.24 M entries that way: nine dependent loads per entry plus per-lane atomics).
+__global__ __launch_bounds__(256) void k_mg_minmax(const MergeSeg* __restrict__ segs, const uint2* __restrict__ blocks, const int32_t* __restrict__ raw,
+                                                   MergeGroup* __restrict__ groups)
 {
-    // each lane folds up to four entries (they may straddle groups), then the lanes that share the wave's
-    // first group reduce with shuffles -> about one atomic pair per wave
-    const uint32_t e0 = blockIdx.x * 1024u;
+    __shared__ int32_t s_mn[4], s_mx[4];
+    const uint2 b = blocks[blockIdx.x];
+    const MergeSeg sg = segs[b.x];
     int32_t mn = 2147483647, mx = -2147483647 - 1;
-    uint32_t cur_group = 0xFFFFFFFFu;
-    for (uint32_t k = 0; k < 4; k++) {
-        const uint32_t e = e0 + k * 256u + threadIdx.x;
-        if (e >= n_total) break;
-        const MergeSeg sg = segs[mg_find_seg(segs, n_segs, e)];
-        const int32_t d = raw[sg.src + (e - sg.start)];
-        if (sg.group != cur_group) {
-            if (cur_group != 0xFFFFFFFFu) { atomicMin(&groups[cur_group].mn, mn); atomicMax(&groups[cur_group].mx, mx); }
-            cur_group = sg.group; mn = d; mx = d;
-        } else { mn = min(mn, d); mx = max(mx, d); }
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t i = b.y + k * 256u + threadIdx.x;
+        const int32_t d = raw[sg.src + min(i, sg.len - 1u)];             // clamped, unmasked: the duplicate changes neither min nor max
+        mn = min(mn, d); mx = max(mx, d);
     }
-    const uint32_t wg = __shfl(cur_group, 0, 64);
-    const bool same = cur_group == wg && cur_group != 0xFFFFFFFFu;
-    int32_t rmn = same ? mn : 2147483647, rmx = same ? mx : (-2147483647 - 1);
-    for (int off = 32; off > 0; off >>= 1) { rmn = min(rmn, __shfl_down(rmn, off, 64)); rmx = max(rmx, __shfl_down(rmx, off, 64)); }
-    if ((threadIdx.x & 63u) == 0 && wg != 0xFFFFFFFFu) { atomicMin(&groups[wg].mn, rmn); atomicMax(&groups[wg].mx, rmx); }
-    if (!same && cur_group != 0xFFFFFFFFu) { atomicMin(&groups[cur_group].mn, mn); atomicMax(&groups[cur_group].mx, mx); }
+    for (int off = 32; off > 0; off >>= 1) { mn = min(mn, __shfl_down(mn, off, 64)); mx = max(mx, __shfl_down(mx, off, 64)); }
+    if ((threadIdx.x & 63u) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&groups[sg.group].mn, min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3])));
+        atomicMax(&groups[sg.group].mx, max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])));
+    }
 }
 
-__global__ __launch_bounds__(256) void k_mg_keys(const MergeSeg* __restrict__ segs, uint32_t n_segs, const int32_t* __restrict__ raw,
-                                                 uint32_t n_total, const MergeGroup* __restrict__ groups, uint32_t* __restrict__ keys,
-                                                 uint32_t* __restrict__ vals)
+__global__ __launch_bounds__(256) void k_mg_keys(const MergeSeg* __restrict__ segs, const uint2* __restrict__ blocks, const int32_t* __restrict__ raw,
+                                                 const MergeGroup* __restrict__ groups, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
-    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
-    if (e >= n_total) return;
-    const MergeSeg sg = segs[mg_find_seg(segs, n_segs, e)];
+    const uint2 b = blocks[blockIdx.x];
+    const MergeSeg sg = segs[b.x];
     const MergeGroup g = groups[sg.group];
-    const int32_t d = raw[sg.src + (e - sg.start)];
     // scene.rs:669-676: depth_inv = 65535 / (max - min) (f32), bucket = floor((d - min) as f32 * depth_inv) as i32, clamped
     const float depth_inv = 65535.0f / (float)(int32_t)(g.mx - g.mn);
-    const float v = floorf((float)(int32_t)(d - g.mn) * depth_inv);
-    int32_t b;
-    if (v != v) b = 0;                                   // NaN (max == min: 0 * inf) -> 0
-    else if (v >= 2147483648.0f) b = 2147483647;
-    else if (v <= -2147483648.0f) b = -2147483647 - 1;
-    else b = (int32_t)v;
-    b = min(max(b, 0), 65535);
-    keys[e] = (sg.group << 16) | (uint32_t)b;
-    vals[e] = e;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t i = b.y + k * 256u + threadIdx.x;
+        if (i >= sg.len) break;
+        const int32_t d = raw[sg.src + i];
+        const float v = floorf((float)(int32_t)(d - g.mn) * depth_inv);
+        int32_t bk;
+        if (v != v) bk = 0;                                  // NaN (max == min: 0 * inf) -> 0
+        else if (v >= 2147483648.0f) bk = 2147483647;
+        else if (v <= -2147483648.0f) bk = -2147483647 - 1;
+        else bk = (int32_t)v;
+        bk = min(max(bk, 0), 65535);
+        const uint32_t e = sg.start + i;
+        keys[e] = (sg.group << 16) | (uint32_t)bk;
+        vals[e] = e;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_mg_final(const MergeSeg* __restrict__ segs, uint32_t n_segs, const MergeGroup* __restrict__ groups,
@@ -1435,7 +1444,7 @@ template <bool EARLY, bool DEPTH, bool COLF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || COLF) ? 7 : 8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
                                                    uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
-                                                   const float4* __restrict__ col_f,
+                                                   const float* __restrict__ depths, const float4* __restrict__ col_f,
                                                    const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
                                                    float4* __restrict__ out, float4* __restrict__ partials,
                                                    int n_tiles, int out_rows)
@@ -1491,54 +1500,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     // it): a load under a lane mask would be merged back through register copies that wait for it on the spot.
     // (only the words the staging needs are kept in registers: the depth word rides along with a depth buffer only, the
     // pad word of the third quad never)
-    struct F3 { float x, y, z; };
-    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rd = ra;
-    F3 rb = {0.f, 0.f, 0.f}, rc = {0.f, 0.f, 0.f};
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rd = ra;
     float rbw = 0.f;
 #define GSWT_LOAD_REC(SLOT)                                                                          \
         {                                                                                           \
-            const float* rp = reinterpret_cast<const float*>(recs + (SLOT));                        \
-            ra = *reinterpret_cast<const float4*>(rp);                                              \
-            if (DEPTH) { const float4 t4 = *reinterpret_cast<const float4*>(rp + 4); rb.x = t4.x; rb.y = t4.y; rb.z = t4.z; rbw = t4.w; } \
-            else rb = *reinterpret_cast<const F3*>(rp + 4);                                         \
-            rc = *reinterpret_cast<const F3*>(rp + 8);                                              \
+            const float4* rp = reinterpret_cast<const float4*>(recs + (SLOT));                      \
+            ra = rp[0];                                                                             \
+            rb = rp[1];                                                                             \
+            if (DEPTH) rbw = depths[(SLOT)];                                                        \
         }
     uint32_t slot_nxt = 0;
     const uint32_t last_pair = rg.y - 1u;
+    // profiling ablations of the gather chain (output is wrong): 32 = no `vals` level (the pair index stands in for the slot),
+    // 64 = no record gather (every pair reads record 0)
+    const bool abl_vals = (f.dbg_flags & 32) != 0, abl_recs = (f.dbg_flags & 64) != 0;
+#define GSWT_VAL(I) (abl_vals ? (I) : vals[(I)])
     if (rg.x < rg.y && !(f.dbg_flags & 4)) {
-        const uint32_t slot0 = vals[min(rg.x + tid, last_pair)];
+        uint32_t slot0 = GSWT_VAL(min(rg.x + tid, last_pair));
+        if (abl_recs) slot0 = 0u;
         GSWT_LOAD_REC(slot0)
         if (COLF) rd = col_f[slot0];
-        slot_nxt = vals[min(rg.x + 256u + tid, last_pair)];
+        slot_nxt = GSWT_VAL(min(rg.x + 256u + tid, last_pair));
     }
     for (uint32_t base = rg.x; base < rg.y; base += 256u) {
         const uint32_t n = min(256u, rg.y - base);
         if (f.dbg_flags & 4) break;                       // ablation: no staging at all
         if (tid < n) {
             // F3: per-(splat, tile) constants
-            const float ox = ra.z - fbx, oy = rb.z - fby;
+            const float ox = rb.x - fbx, oy = rb.y - fby;
             const float nku = -fmaf(ra.x, ox, ra.y * oy);
-            const float nkv = -fmaf(rb.x, ox, rb.y * oy);
-            s_q0[tid] = make_float4(ra.x, ra.y, nku, __builtin_amdgcn_logf(ra.w));   // v_log_f32 = log2; log2(0) = -inf -> B = 0
-            s_q1[tid] = make_float4(rb.x, rb.y, nkv, rc.x);
+            const float nkv = -fmaf(ra.z, ox, ra.w * oy);
+            s_q0[tid] = make_float4(ra.x, ra.y, nku, __builtin_amdgcn_logf(rb.z));   // v_log_f32 = log2; log2(0) = -inf -> B = 0
+            s_q1[tid] = make_float4(ra.z, ra.w, nkv, rb.w);
+            // Pixel half extents of |p| <= 2 from the inverse map: the quad axes are u = iu / |iu|^2, w = iv / |iv|^2 and the
+            // box is 2 sqrt(u.x^2 + w.x^2) by 2 sqrt(u.y^2 + w.y^2).  Approximate reciprocals / roots (1 ulp) under a 1e-4
+            // relative + 2e-3 px margin: the box only has to CONTAIN every pixel centre with r^2 <= 4 (it decides which
+            // sub-block lists a pair enters, never a pixel's coverage), and k_project's own box decided the pair's tiles.
+            const float ria = __builtin_amdgcn_rcpf(fmaf(ra.y, ra.y, ra.x * ra.x)), rib = __builtin_amdgcn_rcpf(fmaf(ra.w, ra.w, ra.z * ra.z));
+            const float qux = ra.x * ria, quy = ra.y * ria, qwx = ra.z * rib, qwy = ra.w * rib;
+            const float bhx = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwx, qwx, qux * qux)), 1.0001f, 0.002f);
+            const float bhy = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwy, qwy, quy * quy)), 1.0001f, 0.002f);
             // Pixel box, tile-local, as the integer pixel ranges whose centres it holds: x_lo <= k + 0.5  <=>  ceil(x_lo - 0.5) <= k and
             // x_hi >= k + 0.5  <=>  floor(x_hi - 0.5) >= k for every integer k (x - 0.5 is exact in binary32 wherever the
             // outcome can depend on it), so the byte form bins exactly like the float box did; 16 -> 4 bytes of LDS per pair.
             // Clamped to [-2, 17]: only 0..15 are ever compared.
-            const int xa = min(max((int)ceilf((ox - rc.y) - 0.5f), -2), 17), xb = min(max((int)floorf((ox + rc.y) - 0.5f), -2), 17);
-            const int ya = min(max((int)ceilf((oy - rc.z) - 0.5f), -2), 17), yb = min(max((int)floorf((oy + rc.z) - 0.5f), -2), 17);
+            const int xa = min(max((int)ceilf((ox - bhx) - 0.5f), -2), 17), xb = min(max((int)floorf((ox + bhx) - 0.5f), -2), 17);
+            const int ya = min(max((int)ceilf((oy - bhy) - 0.5f), -2), 17), yb = min(max((int)floorf((oy + bhy) - 0.5f), -2), 17);
             s_bb[tid] = (uint32_t)(xa & 0xFF) | ((uint32_t)(xb & 0xFF) << 8) | ((uint32_t)(ya & 0xFF) << 16) | ((uint32_t)(yb & 0xFF) << 24);
             if (DEPTH) s_dep[tid] = rbw;
             if (COLF) s_q2[tid] = rd;
         }
         __syncthreads();
         {
+            if (abl_recs) slot_nxt = 0u;
             GSWT_LOAD_REC(slot_nxt)
             if (COLF) rd = col_f[slot_nxt];
-            slot_nxt = vals[min(base + 512u + tid, last_pair)];
+            slot_nxt = GSWT_VAL(min(base + 512u + tid, last_pair));
         }
         if (wave_live && !(f.dbg_flags & 2))               // ablation bit 2: stage only
             composite_bin_walk<EARLY, DEPTH, COLF>(f, cl, n, s_q0, s_q1, s_q2, s_bb, s_dep, wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
+        if (base + 256u >= rg.y) break;                     // last batch of the item: nothing is staged after it, no barrier needed
         if (EARLY) { if (__syncthreads_and(wave_live ? 0 : 1)) break; }
         else __syncthreads();
     }
@@ -1655,7 +1676,7 @@ void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
-                    const float* hmap, const uint32_t* draw_culled, uint2* rects, Rec* recs, uint32_t* block_sums,
+                    const float* hmap, const uint32_t* draw_culled, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
                     uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap)
 {
     if (n_chunks == 0) return;
@@ -1663,7 +1684,7 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
 #define GSWT_LAUNCH_PROJECT(D, F)                                                                                              \
     hipLaunchKernelGGL((k_project<D, F>), dim3(n_launch), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,        \
-                       merged_map, tex, hmap, draw_culled, rects, recs, block_sums, super_sums, n_super, dbg, col_f)
+                       merged_map, tex, hmap, draw_culled, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f)
     if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
     else if (debug) { GSWT_LAUNCH_PROJECT(true, false); }
     else if (full) { GSWT_LAUNCH_PROJECT(false, true); }
@@ -1738,13 +1759,13 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
 // GSWT_ORDER_DEPTH front end: depth keys -> 32-bit radix sort -> per-block counts -> scan -> emission in depth order.
 // dk_a/dv_a/dk_b/dv_b: n_slots u32 each; ws: radix_ws_words(n_slots, 32) zeroed words; n_slots_dev: device u64 = n_slots.
 void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_slots, const unsigned long long* n_slots_dev, const uint2* rects,
-                       const Rec* recs, const uint32_t* block_sums, uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b,
+                       const float* depths, const uint32_t* block_sums, uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b,
                        uint32_t* radix_ws, uint32_t* block_cnt, uint32_t* scan_ws, uint32_t* scratch_total, uint32_t pair_cap,
                        unsigned long long* counters, uint32_t* keys, uint32_t* vals)
 {
     if (n_slots == 0) return;
     const uint32_t nb = (n_slots + 255) / 256;
-    hipLaunchKernelGGL(k_depth_keys, dim3(nb), dim3(256), 0, s, rects, recs, block_sums, n_slots, dk_a, dv_a);
+    hipLaunchKernelGGL(k_depth_keys, dim3(nb), dim3(256), 0, s, rects, depths, block_sums, n_slots, dk_a, dv_a);
     const int where = launch_sort(s, dk_a, dv_a, dk_b, dv_b, n_slots, n_slots_dev, 32, radix_ws);
     const uint32_t* sk = where ? dk_b : dk_a;
     const uint32_t* perm = where ? dv_b : dv_a;
@@ -1755,14 +1776,14 @@ void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_slots, const un
 
 // Builds every merged group's (gs_index | lod, map_id) list on the device.  keys/vals a,b: n_total u32 each;
 // ws: radix_ws_words(n_total, 16 + group_bits) zeroed words; n_total_dev: device u64 = n_total (+ two zero words after it).
-void launch_merge_build(hipStream_t s, const MergeSeg* segs, uint32_t n_segs, MergeGroup* groups, uint32_t n_groups,
+void launch_merge_build(hipStream_t s, const MergeSeg* segs, uint32_t n_segs, const uint2* blocks, uint32_t n_blocks, MergeGroup* groups, uint32_t n_groups,
                         const int32_t* raw, uint32_t n_total, const unsigned long long* n_total_dev, uint32_t* ka, uint32_t* va,
                         uint32_t* kb, uint32_t* vb, uint32_t* radix_ws, int group_bits, uint32_t* merged_list, uint32_t* merged_map)
 {
-    if (n_total == 0 || n_groups == 0) return;
+    if (n_total == 0 || n_groups == 0 || n_blocks == 0) return;
     hipLaunchKernelGGL(k_mg_init, dim3((n_groups + 255) / 256), dim3(256), 0, s, groups, n_groups);
-    hipLaunchKernelGGL(k_mg_minmax, dim3((n_total + 1023) / 1024), dim3(256), 0, s, segs, n_segs, raw, n_total, groups);
-    hipLaunchKernelGGL(k_mg_keys, dim3((n_total + 255) / 256), dim3(256), 0, s, segs, n_segs, raw, n_total, groups, ka, va);
+    hipLaunchKernelGGL(k_mg_minmax, dim3(n_blocks), dim3(256), 0, s, segs, blocks, raw, groups);
+    hipLaunchKernelGGL(k_mg_keys, dim3(n_blocks), dim3(256), 0, s, segs, blocks, raw, groups, ka, va);
     const int where = launch_sort(s, ka, va, kb, vb, n_total, n_total_dev, 16 + group_bits, radix_ws);
     hipLaunchKernelGGL(k_mg_final, dim3((n_total + 255) / 256), dim3(256), 0, s, segs, n_segs, groups, where ? kb : ka, where ? vb : va,
                        n_total, merged_list, merged_map);
@@ -1778,7 +1799,7 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const un
 
 // ranges -> per-tile segment counts -> item_base (exclusive scan, item_base[n_tiles] = #items) ->
 // k_composite over an upper bound of items -> k_combine.
-void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs,
+void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs, const float* depths,
                       const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
                       hipEvent_t ev_begin, hipEvent_t ev_end, const unsigned long long* counters, unsigned long long* host_counters)
@@ -1794,7 +1815,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     if (ev_begin) hipEventRecord(ev_begin, s);
 #define GSWT_LAUNCH_COMPOSITE(E, D, C)                                                                                         \
     hipLaunchKernelGGL((k_composite<E, D, C>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, item_tab, seg, vals, recs, \
-                       col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
+                       depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
     if (colf) {                       // debug draw modes: float colours from the side buffer
         if (depth) GSWT_LAUNCH_COMPOSITE(false, true, true);
         else GSWT_LAUNCH_COMPOSITE(false, false, true);

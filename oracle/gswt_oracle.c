@@ -574,10 +574,14 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
         if ((lod_id == higher_lod + 1u && t_ratio == 0.0f) || (lod_id == higher_lod && t_ratio == 1.0f))
             return 0;
     }
-    /* A6 :152-167.  pos2d = (opengl_to_wgpu * projection) * (view * center) */
+    /* A6 :152-167.  pos2d = (opengl_to_wgpu * projection) * (view * center).
+     * Canonical sequence v2 (round 2): dot products are fma chains (first product rounded, then one fma per further
+     * term, the translation column last), quotients are products with ONE correctly rounded reciprocal (1/t.z, 1/q.w,
+     * 1/|v|, 1/(s*|major|), 1/(s*|minor|)) -- WGSL allows both (fused multiply-add; division to 2.5 ULP).  What
+     * matters is that this file and k_project evaluate the same IEEE binary32 operations in the same order. */
     const float *V = cam->view, *P = cam->projection;
     float cv[4];
-    for (int r = 0; r < 4; r++) cv[r] = ((V[r] * c[0] + V[4 + r] * c[1]) + V[8 + r] * c[2]) + V[12 + r];
+    for (int r = 0; r < 4; r++) cv[r] = fmaf(V[8 + r], c[2], fmaf(V[4 + r], c[1], V[r] * c[0])) + V[12 + r];
     float GP[16];
     for (int cc = 0; cc < 4; cc++) {
         GP[4 * cc + 0] = P[4 * cc + 0];
@@ -587,7 +591,7 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
     }
     float q[4];
     for (int r = 0; r < 4; r++)
-        q[r] = ((GP[r] * cv[0] + GP[4 + r] * cv[1]) + GP[8 + r] * cv[2]) + GP[12 + r] * cv[3];
+        q[r] = fmaf(GP[12 + r], cv[3], fmaf(GP[8 + r], cv[2], fmaf(GP[4 + r], cv[1], GP[r] * cv[0])));
     float clip = 1.2f * q[3];
     if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) return 0;
     /* A7 :169-205 */
@@ -606,11 +610,11 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
         float FK[9], R[9];
         for (int cc = 0; cc < 3; cc++)
             for (int r = 0; r < 3; r++)
-                FK[3 * cc + r] = (F[r] * K[3 * cc] + F[3 + r] * K[3 * cc + 1]) + F[6 + r] * K[3 * cc + 2];
+                FK[3 * cc + r] = fmaf(F[6 + r], K[3 * cc + 2], fmaf(F[3 + r], K[3 * cc + 1], F[r] * K[3 * cc]));
         /* (FK * F^T)[c][r] = sum_k FK[k][r] * F^T[c][k] = sum_k FK[k][r] * F[k][c] */
         for (int cc = 0; cc < 3; cc++)
             for (int r = 0; r < 3; r++)
-                R[3 * cc + r] = (FK[r] * F[cc] + FK[3 + r] * F[3 + cc]) + FK[6 + r] * F[6 + cc];
+                R[3 * cc + r] = fmaf(FK[6 + r], F[6 + cc], fmaf(FK[3 + r], F[3 + cc], FK[r] * F[cc]));
         memcpy(K, R, sizeof(K));
     }
     for (int cc = 0; cc < 3; cc++)          /* S * Vrk * S^T, S = diag(scene_scale) */
@@ -619,58 +623,62 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
     /* A8 :207-258 */
     float dd[3] = { c[0] - cam->cam_pos[0], c[1] - cam->cam_pos[1], c[2] - cam->cam_pos[2] };
     float t[3];
-    for (int r = 0; r < 3; r++) t[r] = (V[r] * dd[0] + V[4 + r] * dd[1]) + V[8 + r] * dd[2];
-    float txtz = t[0] / t[2], tytz = t[1] / t[2];
+    for (int r = 0; r < 3; r++) t[r] = fmaf(V[8 + r], dd[2], fmaf(V[4 + r], dd[1], V[r] * dd[0]));
+    const float rz = 1.0f / t[2];
+    float txtz = t[0] * rz, tytz = t[1] * rz;
     float limx = 1.3f * cam->htan_fov[0], limy = 1.3f * cam->htan_fov[1];
     t[0] = clampf(txtz, -limx, limx) * t[2];
     t[1] = clampf(tytz, -limy, limy) * t[2];
-    float tz2 = t[2] * t[2];
-    float j00 = cam->focal[0] / t[2], j02 = -((cam->focal[0] * t[0]) / tz2);
-    float j11 = cam->focal[1] / t[2], j12 = -((cam->focal[1] * t[1]) / tz2);
+    const float rz2 = rz * rz;
+    float j00 = cam->focal[0] * rz, j02 = -((cam->focal[0] * t[0]) * rz2);
+    float j11 = cam->focal[1] * rz, j12 = -((cam->focal[1] * t[1]) * rz2);
     /* T = transpose(view3) * J_T ; T col0 = (dot(view3 col r, J col0))_r etc. */
     float T0[3], T1[3];
     for (int r = 0; r < 3; r++) {
-        T0[r] = V[4 * r + 0] * j00 + V[4 * r + 2] * j02;
-        T1[r] = V[4 * r + 1] * j11 + V[4 * r + 2] * j12;
+        T0[r] = fmaf(V[4 * r + 2], j02, V[4 * r + 0] * j00);
+        T1[r] = fmaf(V[4 * r + 2], j12, V[4 * r + 1] * j11);
     }
     /* A = T^T * Vrk : A[k][r] = dot(T_r, Vrk col k) ; cov2d[c][r] = sum_k A[k][r]*T_c[k] */
     float A0[3], A1[3];
     for (int k = 0; k < 3; k++) {
-        A0[k] = (T0[0] * K[3 * k] + T0[1] * K[3 * k + 1]) + T0[2] * K[3 * k + 2];
-        A1[k] = (T1[0] * K[3 * k] + T1[1] * K[3 * k + 1]) + T1[2] * K[3 * k + 2];
+        A0[k] = fmaf(T0[2], K[3 * k + 2], fmaf(T0[1], K[3 * k + 1], T0[0] * K[3 * k]));
+        A1[k] = fmaf(T1[2], K[3 * k + 2], fmaf(T1[1], K[3 * k + 1], T1[0] * K[3 * k]));
     }
-    float c00 = (A0[0] * T0[0] + A0[1] * T0[1]) + A0[2] * T0[2];
-    float c01 = (A1[0] * T0[0] + A1[1] * T0[1]) + A1[2] * T0[2];   /* cov2d[0][1] */
-    float c11 = (A1[0] * T1[0] + A1[1] * T1[1]) + A1[2] * T1[2];
+    float c00 = fmaf(A0[2], T0[2], fmaf(A0[1], T0[1], A0[0] * T0[0]));
+    float c01 = fmaf(A1[2], T0[2], fmaf(A1[1], T0[1], A1[0] * T0[0]));   /* cov2d[0][1] */
+    float c11 = fmaf(A1[2], T1[2], fmaf(A1[1], T1[1], A1[0] * T1[0]));
     float mid = 0.5f * (c00 + c11);
     float hx = 0.5f * (c00 - c11);
-    float radius = sqrtf(hx * hx + c01 * c01);
+    float radius = sqrtf(fmaf(hx, hx, c01 * c01));
     float l1 = mid + radius, l2 = mid - radius;
     if (l2 < 0.0f) return 0;
     float vx = c01, vy = l1 - c00;
-    float vlen = sqrtf(vx * vx + vy * vy);
-    float ex = vx / vlen, ey = vy / vlen;       /* normalize(): 0/0 -> NaN -> nothing drawn */
+    float vlen = sqrtf(fmaf(vx, vx, vy * vy));
+    const float rv = 1.0f / vlen;
+    float ex = vx * rv, ey = vy * rv;           /* normalize(): 0 * (1/0) -> NaN -> nothing drawn */
     float smaj = fminf(sqrtf(2.0f * l1), 1024.0f);
     float smin = fminf(sqrtf(2.0f * l2), 1024.0f);
     out->major[0] = smaj * ex; out->major[1] = smaj * ey;
     out->minor[0] = smin * ey; out->minor[1] = smin * -ex;
-    /* A9 :260-265, 402-410 */
+    /* A9 :260-265, 402-410 (byte / 255 as byte * fl(1/255)) */
+    const float k255 = 1.0f / 255.0f;
     uint32_t cw = rec[7];
-    out->rgba[0] = (float)(cw & 0xFFu) / 255.0f;
-    out->rgba[1] = (float)((cw >> 8) & 0xFFu) / 255.0f;
-    out->rgba[2] = (float)((cw >> 16) & 0xFFu) / 255.0f;
-    out->rgba[3] = (float)((cw >> 24) & 0xFFu) / 255.0f;
+    out->rgba[0] = (float)(cw & 0xFFu) * k255;
+    out->rgba[1] = (float)((cw >> 8) & 0xFFu) * k255;
+    out->rgba[2] = (float)((cw >> 16) & 0xFFu) * k255;
+    out->rgba[3] = (float)((cw >> 24) & 0xFFu) * k255;
     if (s->draw_mode != 0u) debug_draw_color(s, u, pos, lod_id, t_ratio, out->rgba);   /* :268-399 */
     if (u->changing == 1u) {
         if (lod_id != higher_lod) out->rgba[3] = out->rgba[3] * t_ratio;
         else out->rgba[3] = out->rgba[3] * (1.0f - t_ratio);
     }
-    float fade = clampf(q[2] / q[3] + 1.0f, 0.0f, 1.0f);
+    const float rq = 1.0f / q[3];
+    float fade = clampf(fmaf(q[2], rq, 1.0f), 0.0f, 1.0f);
     for (int k = 0; k < 4; k++) out->rgba[k] = out->rgba[k] * fade;
     /* A10 :415-419.  Hardware clip keeps 0 <= z <= w with w_out = 1. */
-    out->ndc[0] = q[0] / q[3];
-    out->ndc[1] = q[1] / q[3];
-    out->depth = q[2] / q[3];
+    out->ndc[0] = q[0] * rq;
+    out->ndc[1] = q[1] * rq;
+    out->depth = q[2] * rq;
     if (!(out->depth >= 0.0f && out->depth <= 1.0f)) return 0;
     out->visible = 1;
     return 1;
@@ -697,23 +705,25 @@ typedef struct {
 static void frag_setup(const orc_splat *sp, float splat_scale, float W, float H, orc_frag_setup *fs)
 {
     /* F1: pixel-space centre */
-    fs->cxp = (0.5f * sp->ndc[0] + 0.5f) * W;
-    fs->cyp = (0.5f - 0.5f * sp->ndc[1]) * H;
-    /* F2: pixel-space image of the unit quad axes (framebuffer y is down) */
+    fs->cxp = fmaf(0.5f, sp->ndc[0], 0.5f) * W;
+    fs->cyp = fmaf(-0.5f, sp->ndc[1], 0.5f) * H;
+    /* F2: pixel-space image of the unit quad axes (framebuffer y is down); the rows of the inverse affine map are
+     * iu = u / |u|^2, iv = w / |w|^2, each with ONE reciprocal */
     float hs = 0.5f * splat_scale;
     float ux = hs * sp->major[0], uy = -(hs * sp->major[1]);
     float vx = hs * sp->minor[0], vy = -(hs * sp->minor[1]);
-    float uu = ux * ux + uy * uy;
-    float vv = vx * vx + vy * vy;
+    float uu = fmaf(uy, uy, ux * ux);
+    float vv = fmaf(vy, vy, vx * vx);
     fs->ok = (uu > 0.0f) && (vv > 0.0f) && (uu < INFINITY) && (vv < INFINITY);  /* false for NaN */
     if (!fs->ok) return;
-    fs->iux = ux / uu; fs->iuy = uy / uu;
-    fs->ivx = vx / vv; fs->ivy = vy / vv;
+    const float ruu = 1.0f / uu, rvv = 1.0f / vv;
+    fs->iux = ux * ruu; fs->iuy = uy * ruu;
+    fs->ivx = vx * rvv; fs->ivy = vy * rvv;
     /* extent of |p| <= 2 : |dX| <= 2 sqrt(ux^2 + vx^2), inflated by 1e-3 px + 1e-5 relative so the
      * box is conservative under f32 rounding of F3/F4.  A pixel can be covered only if its CENTRE
      * lies inside [c - h, c + h]. */
-    fs->hx = 2.0f * sqrtf(ux * ux + vx * vx) * 1.00001f + 0.001f;
-    fs->hy = 2.0f * sqrtf(uy * uy + vy * vy) * 1.00001f + 0.001f;
+    fs->hx = fmaf(2.0f * sqrtf(fmaf(vx, vx, ux * ux)), 1.00001f, 0.001f);
+    fs->hy = fmaf(2.0f * sqrtf(fmaf(vy, vy, uy * uy)), 1.00001f, 0.001f);
 }
 
 /* Rasterise one projected splat into rows [y_lo, y_hi) with "over" blending
