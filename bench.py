@@ -265,6 +265,18 @@ def main():
     r.set_draws(sort0.draws, sort0.merged_gs_index, sort0.merged_map_id, sort0.merged_lod_id)
     su0 = wang.scene_uniforms()
     use_dist = world > 1 or force_dist
+    # The collective lives behind the C ABI (gswt_comm_init / gswt_render_gather: RCCL all-gather + re-assembly on the ctx
+    # stream); torch.distributed only ships the 128-byte RCCL id.  GSWT_BENCH_TORCH_GATHER=1 (or a failed communicator
+    # set-up) falls back to torch.distributed.all_gather_into_tensor + gswt_unshard_mode.
+    abi_comm = False
+    if use_dist and dist is not None and os.environ.get("GSWT_BENCH_TORCH_GATHER") != "1":
+        try:
+            box = [GSWTRenderer.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            r.comm_init(box[0], rank, world)
+            abi_comm = True
+        except Exception as e:      # noqa: BLE001 - reported in the JSON line
+            print(f"[bench] communicator behind the ABI unavailable ({e}); using torch.distributed for the gather", file=sys.stderr)
     if fake_world > 1 and world == 1:
         world, use_dist = fake_world, True
     shard = (rank, world, "cols") if world > 1 else (0, 1)
@@ -338,7 +350,9 @@ def main():
 
     def collect():
         ticket, o, timed = inflight.pop(0)
-        if use_dist:
+        if use_dist and abi_comm:
+            r.render_gather(ticket, frame.data_ptr())
+        elif use_dist:
             r.render_fence(ticket)
             with torch.cuda.stream(stream):
                 if fake_world > 1:
@@ -430,13 +444,16 @@ def main():
         # the all-gathered frame against the same camera rendered unsharded on this rank, bit for bit
         tk = r.render_async(cu_l, su_l, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, shard=shard,
                             bg_rgba_ptr=bgs[0].data_ptr() if use_passes else 0, bg_depth_ptr=depths[0].data_ptr() if use_passes else 0)
-        r.render_fence(tk)
-        with torch.cuda.stream(stream):
-            if fake_world > 1:
-                gathered.zero_(); gathered[:rows].copy_(outs[0], non_blocking=True)
-            else:
-                dist.all_gather_into_tensor(gathered, outs[0])
-            r.unshard_mode(gathered.data_ptr(), W, H, world, "cols", frame.data_ptr())
+        if abi_comm:
+            r.render_gather(tk, frame.data_ptr())
+        else:
+            r.render_fence(tk)
+            with torch.cuda.stream(stream):
+                if fake_world > 1:
+                    gathered.zero_(); gathered[:rows].copy_(outs[0], non_blocking=True)
+                else:
+                    dist.all_gather_into_tensor(gathered, outs[0])
+                r.unshard_mode(gathered.data_ptr(), W, H, world, "cols", frame.data_ptr())
         r.render_wait(tk)
         stream.synchronize()
         full = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
@@ -528,6 +545,7 @@ def main():
         }
         if use_dist:
             res["dist_check_max_abs_diff"] = dist_check
+            res["collective"] = "gswt_render_gather (ncclAllGather behind the C ABI)" if abi_comm else "torch.distributed.all_gather_into_tensor + gswt_unshard_mode"
         if world == 1 and not args.no_cpu_baseline:
             # the oracle renders the LAST fly-path camera from the product host's current draw list (one frame)
             wang.set_device_merge(False)
@@ -550,6 +568,8 @@ def main():
                                    "max_abs_diff_vs_gpu": float(np.max(np.abs(gpu_img.astype(np.float64) - img_cpu.astype(np.float64))))}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    if abi_comm:
+        r.comm_destroy()
     if dist:
         dist.destroy_process_group()
 

@@ -17,6 +17,8 @@ GSWT_ERR_BAD_ARG = -1
 GSWT_ERR_CAPACITY = -2
 GSWT_ERR_HIP = -3
 GSWT_ERR_STATE = -4
+GSWT_ERR_RCCL = -6
+GSWT_COMM_ID_BYTES = 128
 GSWT_ORDER_REFERENCE = 0
 GSWT_ORDER_DEPTH = 1
 GSWT_OPT_NO_LOD_PREFILTER = 1
@@ -127,6 +129,12 @@ SYMBOLS = {
     "gswt_unshard": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "gswt_unshard_mode": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gswt_shard_cols_padded": (C.c_int, [C.c_int, C.c_int]),
+    "gswt_comm_unique_id": (C.c_int, [_P]),
+    "gswt_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "gswt_comm_destroy": (C.c_int, [_P]),
+    "gswt_render_gather": (C.c_int, [_P, C.c_int, _P]),
+    "gswt_group_init": (C.c_int, [_P, C.c_int]),
+    "gswt_group_render_gather": (C.c_int, [_P, _P, _P, C.c_int]),
     "gswt_synchronize": (C.c_int, [_P]),
     "gswt_last_timings": (C.c_int, [_P, _P]),
     "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -15,6 +15,8 @@
 #include "../../include/gswt_hip.h"
 #include "gswt_device.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -104,7 +106,7 @@ constexpr int kFrameSlots = 3;
 // The per-sort-event state (GSWTRenderer's swap-in of a SortData, state.rs:361-376): draw descriptors, chunk tables, merged
 // lists, band-cull bounds.  Double-buffered: gswt_set_draws* fills the set that is NOT current while the frames in flight
 // keep reading the one they were submitted with, so a sort event does not drain the frame pipeline.
-constexpr int kDrawSets = 2;
+constexpr int kDrawSets = 4;     // frames in flight + 1: the set being refilled is never one a frame in flight still reads
 struct DrawSet {
     DevBuf<DrawDev> draws;
     DevBuf<uint2> chunk_tab;
@@ -232,6 +234,13 @@ struct gswt_ctx {
     int opt_fixed_pair_cap = 0;   // test hook (GSWT_OPT_PAIR_CAP): the pair capacity is pinned until a frame overflows it
     uint32_t last_n_tiles = 0;
     gswt_timings timings = {};
+    // multi-GPU gather: RCCL communicator (one process per GPU) or a local group of contexts (one process, peer copies)
+    void* comm = nullptr;                  // ncclComm_t
+    int comm_rank = 0, comm_world = 0;
+    std::vector<gswt_ctx*> group;          // non-empty: hipMemcpyPeerAsync transport; group[r] is rank r
+    int group_rank = 0;
+    DevBuf<float4> gather_buf;             // world x shard image, as an all-gather delivers them
+    hipEvent_t ev_push = nullptr;          // local group: this rank's shard has been pushed to every peer
 };
 
 namespace {
@@ -277,6 +286,65 @@ void mat4_mul(const float* a, const float* b, float* out)
             for (int k = 1; k < 4; k++) acc = acc + a[4 * k + r] * b[4 * c + k];
             out[4 * c + r] = acc;
         }
+}
+
+}  // namespace
+
+// ---- multi-GPU gather: transport state (the entry points are at the end of the file) ---------------------------------
+namespace {
+
+// RCCL through dlopen: a single-GPU host never needs the library, and a process that already holds one (PyTorch-ROCm bundles
+// its own librccl.so) gets that copy instead of a second one.
+struct Id128 { char b[GSWT_COMM_ID_BYTES]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, /* ncclUniqueId by value: 128 bytes */ Id128, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    bool tried = false;
+};
+RcclApi g_rccl;
+
+const char* rccl_load()
+{
+    if (g_rccl.lib) return nullptr;
+    if (g_rccl.tried) return "librccl.so could not be loaded";
+    g_rccl.tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) return "librccl.so could not be loaded";
+    g_rccl.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(g_rccl.lib, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, Id128, int)>(dlsym(g_rccl.lib, "ncclCommInitRank"));
+    g_rccl.AllGather = reinterpret_cast<int (*)(const void*, void*, size_t, int, void*, hipStream_t)>(dlsym(g_rccl.lib, "ncclAllGather"));
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(g_rccl.lib, "ncclCommDestroy"));
+    g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy) {
+        dlclose(g_rccl.lib); g_rccl.lib = nullptr;
+        return "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+    }
+    return nullptr;
+}
+
+constexpr int kNcclFloat = 7;      // ncclFloat32 (rccl.h ncclDataType_t)
+
+// geometry of a slot's shard image (what its frame wrote to args.d_out)
+struct ShardGeom { int world, mode, out_rows, out_w; size_t px; };
+ShardGeom shard_geom(const FrameSlot& sl)
+{
+    ShardGeom g;
+    const gswt_render_config& cfg = sl.args.cfg;
+    g.world = cfg.shard_count <= 1 ? 1 : cfg.shard_count;
+    g.mode = cfg.shard_mode;
+    const bool cols = g.world > 1 && g.mode == GSWT_SHARD_COLUMNS;
+    g.out_rows = g.world > 1 && !cols ? gswt_shard_rows_padded(sl.args.height, g.world) : sl.args.height;
+    g.out_w = cols ? gswt_shard_cols_padded(sl.args.width, g.world) : sl.args.width;
+    g.px = (size_t)g.out_rows * g.out_w;
+    return g;
 }
 
 }  // namespace
@@ -340,6 +408,9 @@ void gswt_destroy(gswt_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     sync_all(c);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->ev_push) hipEventDestroy(c->ev_push);
+    c->gather_buf.release();
     c->tex.release(); c->static_list.release(); c->hmap.release(); for (auto& ds : c->sets) ds.release();
     c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release(); c->mg_blocks.release();
     c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
@@ -1198,6 +1269,133 @@ try {
     HIP_TRY(c, hipGetLastError());
     return GSWT_OK;
 } GSWT_CATCH("gswt_unshard_mode")
+
+// ---- multi-GPU gather ------------------------------------------------------------------------------------------------
+int gswt_comm_unique_id(void* id_out)
+try {
+    if (!id_out) return GSWT_ERR_BAD_ARG;
+    if (rccl_load()) return GSWT_ERR_RCCL;
+    return g_rccl.GetUniqueId(id_out) == 0 ? GSWT_OK : GSWT_ERR_RCCL;
+} catch (...) { return GSWT_ERR_RCCL; }
+
+int gswt_comm_init(gswt_ctx* c, const void* unique_id, int rank, int world)
+try {
+    if (!c || !unique_id || world < 1 || rank < 0 || rank >= world) return fail(c, GSWT_ERR_BAD_ARG, "gswt_comm_init: bad rank / world");
+    if (c->comm || !c->group.empty()) return fail(c, GSWT_ERR_STATE, "gswt_comm_init: the ctx already has a communicator (gswt_comm_destroy first)");
+    if (const char* e = rccl_load()) return fail(c, GSWT_ERR_RCCL, "gswt_comm_init: %s", e);
+    hipSetDevice(c->device);
+    Id128 id;
+    memcpy(id.b, unique_id, GSWT_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (rc != 0) return fail(c, GSWT_ERR_RCCL, "ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    c->comm = comm; c->comm_rank = rank; c->comm_world = world;
+    return GSWT_OK;
+} GSWT_CATCH("gswt_comm_init")
+
+int gswt_comm_destroy(gswt_ctx* c)
+try {
+    if (!c) return GSWT_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    HIP_TRY(c, collect_pending(c));
+    if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; c->comm_world = 0; }
+    c->group.clear();
+    return GSWT_OK;
+} GSWT_CATCH("gswt_comm_destroy")
+
+int gswt_group_init(gswt_ctx* const* ctxs, int n)
+try {
+    if (!ctxs || n < 1) return GSWT_ERR_BAD_ARG;
+    for (int r = 0; r < n; r++) {
+        if (!ctxs[r]) return GSWT_ERR_BAD_ARG;
+        if (ctxs[r]->comm || !ctxs[r]->group.empty()) return fail(ctxs[r], GSWT_ERR_STATE, "gswt_group_init: rank %d already has a communicator", r);
+    }
+    for (int r = 0; r < n; r++) {
+        gswt_ctx* c = ctxs[r];
+        hipSetDevice(c->device);
+        for (int p = 0; p < n; p++)
+            if (ctxs[p]->device != c->device) {
+                int can = 0;
+                HIP_TRY(c, hipDeviceCanAccessPeer(&can, c->device, ctxs[p]->device));
+                if (can) { hipError_t e = hipDeviceEnablePeerAccess(ctxs[p]->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(c, e); (void)hipGetLastError(); }
+            }
+        if (!c->ev_push) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_push, hipEventDisableTiming));
+        c->group.assign(ctxs, ctxs + n);
+        c->group_rank = r;
+    }
+    return GSWT_OK;
+} catch (...) { return GSWT_ERR_HIP; }
+
+int gswt_render_gather(gswt_ctx* c, int ticket, float* frame_out_dev)
+try {
+    if (!c || ticket < 0 || ticket >= kFrameSlots || !frame_out_dev) return GSWT_ERR_BAD_ARG;
+    if (!c->comm) return fail(c, GSWT_ERR_STATE, "gswt_render_gather before gswt_comm_init");
+    int rc = gswt_render_fence(c, ticket);               // overflow-safe: the gathered shard is complete
+    if (rc != GSWT_OK) return rc;
+    FrameSlot& sl = c->slots[ticket];
+    const ShardGeom g = shard_geom(sl);
+    if (g.world != c->comm_world || sl.args.cfg.shard_index != c->comm_rank)
+        return fail(c, GSWT_ERR_BAD_ARG, "gswt_render_gather: the frame was rendered as shard %d of %d, the communicator is rank %d of %d",
+                    sl.args.cfg.shard_index, g.world, c->comm_rank, c->comm_world);
+    hipSetDevice(c->device);
+    if (g.world == 1) {                                   // nothing to gather: the shard is the frame
+        if (reinterpret_cast<float4*>(frame_out_dev) != sl.args.d_out)
+            HIP_TRY(c, hipMemcpyAsync(frame_out_dev, sl.args.d_out, g.px * 16, hipMemcpyDeviceToDevice, c->stream));
+        return GSWT_OK;
+    }
+    HIP_TRY(c, c->gather_buf.ensure((size_t)g.world * g.px));
+    const int nrc = g_rccl.AllGather(sl.args.d_out, c->gather_buf.p, g.px * 4, kNcclFloat, c->comm, c->stream);
+    if (nrc != 0) return fail(c, GSWT_ERR_RCCL, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "error");
+    launch_unshard(c->stream, c->gather_buf.p, reinterpret_cast<float4*>(frame_out_dev), sl.args.width, sl.args.height, g.world,
+                   gswt_shard_rows_padded(sl.args.height, g.world), g.mode == GSWT_SHARD_COLUMNS ? g.out_w : 0);
+    HIP_TRY(c, hipGetLastError());
+    return GSWT_OK;
+} GSWT_CATCH("gswt_render_gather")
+
+int gswt_group_render_gather(gswt_ctx* const* ctxs, const int* tickets, float* const* frames_out_dev, int n)
+try {
+    if (!ctxs || !tickets || !frames_out_dev || n < 1) return GSWT_ERR_BAD_ARG;
+    for (int r = 0; r < n; r++)
+        if (!ctxs[r] || (int)ctxs[r]->group.size() != n || ctxs[r]->group[r] != ctxs[r] || !frames_out_dev[r] || tickets[r] < 0 || tickets[r] >= kFrameSlots)
+            return GSWT_ERR_BAD_ARG;
+    // 1. every rank's frame is complete (overflow-safe fence) and the ctx streams are ordered behind them
+    for (int r = 0; r < n; r++) { int rc = gswt_render_fence(ctxs[r], tickets[r]); if (rc != GSWT_OK) return rc; }
+    ShardGeom g0 = shard_geom(ctxs[0]->slots[tickets[0]]);
+    for (int r = 0; r < n; r++) {
+        gswt_ctx* c = ctxs[r];
+        const FrameSlot& sl = c->slots[tickets[r]];
+        const ShardGeom g = shard_geom(sl);
+        if (g.world != n || sl.args.cfg.shard_index != r || g.mode != g0.mode || g.px != g0.px || sl.args.width != ctxs[0]->slots[tickets[0]].args.width)
+            return fail(c, GSWT_ERR_BAD_ARG, "gswt_group_render_gather: rank %d rendered shard %d of %d", r, sl.args.cfg.shard_index, g.world);
+        hipSetDevice(c->device);
+        HIP_TRY(c, c->gather_buf.ensure((size_t)n * g.px));
+    }
+    // 2. push: rank r copies its shard into slot r of every peer's gather buffer (xGMI peer copies; a plain copy on one device)
+    for (int r = 0; r < n; r++) {
+        gswt_ctx* c = ctxs[r];
+        hipSetDevice(c->device);
+        const FrameSlot& sl = c->slots[tickets[r]];
+        for (int p = 0; p < n; p++)
+            HIP_TRY(c, hipMemcpyPeerAsync(ctxs[p]->gather_buf.p + (size_t)r * g0.px, ctxs[p]->device, sl.args.d_out, c->device, g0.px * 16, c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_push, c->stream));
+    }
+    // 3. every rank waits (on the device) for all pushes, then re-assembles the frame
+    for (int p = 0; p < n; p++) {
+        gswt_ctx* c = ctxs[p];
+        hipSetDevice(c->device);
+        const FrameSlot& sl = c->slots[tickets[p]];
+        for (int r = 0; r < n; r++) HIP_TRY(c, hipStreamWaitEvent(c->stream, ctxs[r]->ev_push, 0));
+        if (n == 1) {
+            if (reinterpret_cast<float4*>(frames_out_dev[p]) != sl.args.d_out)
+                HIP_TRY(c, hipMemcpyAsync(frames_out_dev[p], c->gather_buf.p, g0.px * 16, hipMemcpyDeviceToDevice, c->stream));
+        } else {
+            launch_unshard(c->stream, c->gather_buf.p, reinterpret_cast<float4*>(frames_out_dev[p]), sl.args.width, sl.args.height, n,
+                           gswt_shard_rows_padded(sl.args.height, n), g0.mode == GSWT_SHARD_COLUMNS ? g0.out_w : 0);
+            HIP_TRY(c, hipGetLastError());
+        }
+    }
+    return GSWT_OK;
+} catch (...) { return GSWT_ERR_HIP; }
 
 int gswt_synchronize(gswt_ctx* c)
 try {

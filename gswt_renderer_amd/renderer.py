@@ -238,6 +238,44 @@ class GSWTRenderer:
         self._check(self._lib.gswt_unshard(self._h, C.c_void_p(gathered_device_ptr), width, height, shard_count,
                                            C.c_void_p(out_device_ptr)))
 
+    # -- multi-GPU gather behind the ABI -------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the 128-byte RCCL id every rank passes to comm_init (ship it by any means)."""
+        buf = (C.c_char * L.GSWT_COMM_ID_BYTES)()
+        rc = L.load().gswt_comm_unique_id(buf)
+        if rc != 0:
+            raise GSWTError(rc, "gswt_comm_unique_id: RCCL is not available")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        self._check(self._lib.gswt_comm_init(self._h, C.c_char_p(unique_id), rank, world))
+
+    def comm_destroy(self):
+        self._check(self._lib.gswt_comm_destroy(self._h))
+
+    def render_gather(self, ticket: int, frame_device_ptr: int):
+        """Overflow-safe fence + ncclAllGather of the shard images + re-assembly, on the ctx stream."""
+        self._check(self._lib.gswt_render_gather(self._h, ticket, C.c_void_p(frame_device_ptr)))
+
+    @staticmethod
+    def group_init(renderers):
+        """All ranks in one process (peer copies instead of RCCL): rank r = renderers[r]."""
+        arr = (C.c_void_p * len(renderers))(*[r._h for r in renderers])
+        rc = L.load().gswt_group_init(arr, len(renderers))
+        if rc != 0:
+            raise GSWTError(rc, "gswt_group_init failed")
+
+    @staticmethod
+    def group_render_gather(renderers, tickets, frame_device_ptrs):
+        n = len(renderers)
+        arr = (C.c_void_p * n)(*[r._h for r in renderers])
+        tk = (C.c_int * n)(*tickets)
+        fr = (C.c_void_p * n)(*frame_device_ptrs)
+        rc = L.load().gswt_group_render_gather(arr, tk, fr, n)
+        if rc != 0:
+            raise GSWTError(rc, renderers[0]._lib.gswt_last_error(renderers[0]._h).decode())
+
     def synchronize(self):
         self._check(self._lib.gswt_synchronize(self._h))
 

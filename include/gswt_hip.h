@@ -34,7 +34,9 @@ enum {
                                 / 10 M merged splats (renderer.rs:253,273); here buffers
                                 grow on demand, this code only reports a failed grow     */
     GSWT_ERR_HIP = -3,       /* any HIP runtime error                                    */
-    GSWT_ERR_STATE = -4      /* call order violated (e.g. render before upload_scene)    */
+    GSWT_ERR_STATE = -4,     /* call order violated (e.g. render before upload_scene)    */
+    /* -5 is GSWT_ERR_IO of gswt_host.h */
+    GSWT_ERR_RCCL = -6       /* RCCL missing / a collective failed (text in gswt_last_error) */
 };
 
 /* Composite order.  REFERENCE reproduces the reference's order exactly: draw rank
@@ -313,6 +315,27 @@ GSWT_API int gswt_unshard(gswt_ctx *ctx, const float *gathered, int width, int h
 /* The same for either shard mode (GSWT_SHARD_COLUMNS: the gathered shards are H x gswt_shard_cols_padded images). */
 GSWT_API int gswt_unshard_mode(gswt_ctx *ctx, const float *gathered, int width, int height,
                                int shard_count, int shard_mode, float *out_rgba);
+
+/* ---- multi-GPU: the framebuffer all-gather behind the ABI (new; the reference is single-GPU) ---------------------
+ * One ctx per GPU.  Every rank renders its shard (cfg->shard_index = rank, shard_count = world) with gswt_render_async,
+ * then gswt_render_gather(ticket, frame) = overflow-safe fence + all-gather of the equal-sized shard images + the index
+ * permutation of gswt_unshard_mode, all on the ctx stream: `frame` (W*H*4 f32, device) then holds the whole image on
+ * every rank.  Two transports:
+ *   RCCL (one process per GPU, xGMI): rank 0 calls gswt_comm_unique_id, ships the 128 bytes to the other ranks by any
+ *     means (MPI, a file, torch.distributed ...), every rank calls gswt_comm_init(ctx, id, rank, world) ->
+ *     ncclCommInitRank; the gather is one ncclAllGather.  librccl is loaded on first use (dlopen), so a single-GPU host
+ *     does not need it; GSWT_ERR_RCCL reports a missing library or a failed collective.
+ *   hipMemcpyPeerAsync (all GPUs in ONE process, no RCCL): gswt_group_init binds n contexts into a group;
+ *     gswt_group_render_gather pushes every rank's shard into every peer's gather buffer (n x n peer copies), orders the
+ *     peers' streams behind them with events and runs the permutation on each.  Also what the single-GPU tests use
+ *     (several contexts on one device). */
+#define GSWT_COMM_ID_BYTES 128
+GSWT_API int gswt_comm_unique_id(void *id_out /* GSWT_COMM_ID_BYTES */);
+GSWT_API int gswt_comm_init(gswt_ctx *ctx, const void *unique_id, int rank, int world);
+GSWT_API int gswt_comm_destroy(gswt_ctx *ctx);
+GSWT_API int gswt_render_gather(gswt_ctx *ctx, int ticket, float *frame_out_dev);
+GSWT_API int gswt_group_init(gswt_ctx *const *ctxs, int n);          /* rank r = ctxs[r]; undone by gswt_comm_destroy on each */
+GSWT_API int gswt_group_render_gather(gswt_ctx *const *ctxs, const int *tickets, float *const *frames_out_dev, int n);
 
 GSWT_API int gswt_synchronize(gswt_ctx *ctx);
 GSWT_API int gswt_last_timings(const gswt_ctx *ctx, gswt_timings *out);
