@@ -220,6 +220,9 @@ def main():
                     "slot's buffers exceed 2 GB)")
     ap.add_argument("--timing-every", type=int, default=2, help="frames between timed ones: the events of a frame are recorded on "
                     "every N-th frame of the timed region (on every frame they cost ~3 %% of the frame rate)")
+    ap.add_argument("--static-at", type=int, default=-1, help="static mode: use fly-path camera number K instead of the workload's own")
+    ap.add_argument("--freeze-sort", action="store_true", help="fly path cameras without the worker: the first SortData stays (\"Lock (Sort)\" of the "
+                    "reference GUI, gui.rs:599-605); separates the per-view workload from the cost of the sort events")
     ap.add_argument("--static-steps", type=int, default=100, help="flypath mode: frames of the static-camera comparison run (0: skip)")
     args = ap.parse_args()
 
@@ -316,6 +319,13 @@ def main():
         # the fly path uses the device-side merged-list build: a sort event uploads O(#tiles), not 12 B per merged splat
         wang.upload_raw_depth_to(r)
         wang.set_device_merge(True)
+    elif args.static_at >= 0:
+        pos, tgt = flypath.sample(flypath.load(path_name), args.path_frames)[args.static_at % args.path_frames]
+        cu_k, vp_k = host.camera_uniforms(pos, tgt, cam0["up"], cam0["fovy"], cam0["near"], cam0["far"], W, H)
+        cams = [(tuple(float(x) for x in pos), cu_k, vp_k)]
+        wk = Worker(wang); res_k = wk.step(cams[0][0], np.asarray(vp_k, dtype=np.float32)); wk.close()
+        wang.upload_raw_depth_to(r); wang.set_device_merge(True)
+        res_k = (wang.sort_tiles_raw(cams[0][0], vp_k), wang.scene_uniforms())
     else:
         cams = [(tuple(cam0["pos"]), cu0, vp0)]
 
@@ -408,17 +418,23 @@ def main():
         return dt
 
     worker = None
+    if args.mode == "static" and args.static_at >= 0:
+        swap_in(res_k)
     if args.mode == "flypath":
         worker = Worker(wang)
         res = worker.step(cams[0][0], cams[0][2])            # the first SortData, synchronously (State::new + first frames)
         if res is not None:
             swap_in(res)
-    dt = timed_run(args.steps, worker, args.warmup)
+    if args.freeze_sort and worker is not None:
+        worker.close()
+    dt = timed_run(args.steps, None if args.freeze_sort else worker, args.warmup)
     main_stats = {k: (list(v) if isinstance(v, list) else v) for k, v in stats.items()}
+    mg_built, mg_reused = r.merge_stats()
     swaps, swap_ms = state["swaps"], list(state["swap_ms"])
     worker_ms = None
     if worker is not None:
-        worker.close()
+        if not args.freeze_sort:
+            worker.close()
         worker_ms = {"build_tiles_ms_mean": float(np.mean(worker.build_ms)) if worker.build_ms else None, "build_tiles_events": len(worker.build_ms),
                      "sort_tiles_ms_mean": float(np.mean(worker.sort_ms)) if worker.sort_ms else None, "sort_tiles_events": len(worker.sort_ms),
                      "threads": 1, "note": "libgswt_host (C++ WangTile) on one host thread beside the render thread, as state.rs:478-561; "
@@ -530,6 +546,7 @@ def main():
                        "parallelism": f"screen-tile-column bands x{world} (projection culled per band) + RCCL all-gather" if world > 1 else "single GPU"},
             "frames_in_flight": slots,
             "sort_events": {"swapped_in": swaps, "swap_in_ms_mean": float(np.mean(swap_ms)) if swap_ms else None,
+                            "merged_groups_sorted": mg_built, "merged_groups_copied_from_previous_event": mg_reused,
                             "note": "SortData swap-ins inside the timed region (gswt_set_draws_merge_groups: draw-list upload into the spare draw set + merged lists built on the device)"},
             "worker_ms": worker_ms,
             "host_submit_ms_mean": float(np.mean(st["submit_ms"])) if st["submit_ms"] else None,

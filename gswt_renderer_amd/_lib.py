@@ -27,6 +27,7 @@ GSWT_OPT_SEGMENT = 3
 GSWT_OPT_DEBUG_FLAGS = 4
 GSWT_OPT_TIMING = 5
 GSWT_OPT_PAIR_CAP = 6
+GSWT_OPT_NO_MERGE_REUSE = 7
 GSWT_SHARD_ROWS = 0
 GSWT_SHARD_COLUMNS = 1
 
@@ -139,6 +140,7 @@ SYMBOLS = {
     "gswt_last_timings": (C.c_int, [_P, _P]),
     "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gswt_debug_read_ranges": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gswt_debug_merge_stats": (C.c_int, [_P, _P]),
     "gswt_debug_totals": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
 }
 

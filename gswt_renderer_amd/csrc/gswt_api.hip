@@ -22,13 +22,13 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace gswt {
-void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, const DrawBounds*, uint32_t*, uint32_t, uint32_t*, uint32_t);
-void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*);
-void launch_draw_bounds(hipStream_t, const Frame&, const DrawDev*, uint32_t, const uint2*, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*,
-                        const uint4*, DrawBounds*);
+void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t);
+void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
 void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long long*, const uint2*, const float*, const uint32_t*,
                        uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
@@ -37,7 +37,7 @@ void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uin
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, uint32_t, const uint32_t*, const uint32_t*,
-                    const uint32_t*, const uint4*, const float*, const uint32_t*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
+                    const uint32_t*, const uint4*, const float*, const uint32_t*, const uint32_t*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
                     unsigned long long*, Varyings*, float4*, uint32_t);
 void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
@@ -107,32 +107,59 @@ constexpr int kFrameSlots = 3;
 // lists, band-cull bounds.  Double-buffered: gswt_set_draws* fills the set that is NOT current while the frames in flight
 // keep reading the one they were submitted with, so a sort event does not drain the frame pipeline.
 constexpr int kDrawSets = 4;     // frames in flight + 1: the set being refilled is never one a frame in flight still reads
+template <typename T>
+struct Ref { T* p = nullptr; };
+
 struct DrawSet {
-    DevBuf<DrawDev> draws;
+    // Everything a sort event uploads lives in ONE pinned host block mirrored by one device block of the same layout (a
+    // single asynchronous copy on the ctx stream per event): draw records, per-draw XCD positions, and the tables of the
+    // device-side merged-list step (groups to sort, their segments and block table; groups to copy, their block table and
+    // map-id remap pairs; the sort's item count).  The views below point into the device block.
+    HostBuf<uint8_t> h_blob;
+    DevBuf<uint8_t> d_blob;
+    size_t blob_bytes = 0;
+    size_t off_draws = 0, off_xcd = 0, off_groups = 0, off_jobs = 0, off_remap = 0, off_segs = 0, off_blocks = 0, off_cblocks = 0, off_n64 = 0;
+    template <typename T> T* hp(size_t off) { return reinterpret_cast<T*>(h_blob.p + off); }
+    template <typename T> T* dp(size_t off) { return reinterpret_cast<T*>(d_blob.p + off); }
+    hipError_t plan(size_t n_draws, size_t n_groups, size_t n_members, size_t total_entries)
+    {
+        size_t o = 0;
+        auto take = [&o](size_t bytes) { const size_t at = o; o = (o + bytes + 255) & ~(size_t)255; return at; };
+        const size_t n_blk = total_entries / 1024 + 2 * n_members + 2;          // upper bound of either block table
+        off_draws = take((n_draws + 1) * sizeof(DrawDev)); off_xcd = take((n_draws + 1) * 4);
+        off_groups = take((n_groups + 1) * sizeof(MergeGroup)); off_jobs = take((n_groups + 1) * sizeof(MergeCopy));
+        off_remap = take((n_members + 1) * sizeof(uint2)); off_segs = take((2 * n_members + 1) * sizeof(MergeSeg));
+        off_blocks = take(n_blk * sizeof(uint2)); off_cblocks = take(n_blk * sizeof(uint2)); off_n64 = take(64);
+        blob_bytes = o;
+        hipError_t e = h_blob.ensure(o);
+        if (e != hipSuccess) return e;
+        e = d_blob.ensure(o);
+        if (e != hipSuccess) return e;
+        draws.p = dp<DrawDev>(off_draws); xcd_first.p = dp<uint32_t>(off_xcd);
+        return hipSuccess;
+    }
+    uint64_t per_xcd[8] = {};              // chunks per XCD launch list, and the longest of them
+    uint64_t longest = 0;
+    Ref<DrawDev> draws;
     DevBuf<uint2> chunk_tab;
     DevBuf<uint2> chunk_tab_xcd;           // chunk_tab in k_project's launch order: all chunks of a draw on XCD (draw % 8)
     DevBuf<uint32_t> merged_list, merged_map;
-    DevBuf<DrawBounds> draw_bounds;        // per draw, for the band cull of column-sharded frames
-    DevBuf<uint32_t> xcd_first;            // per draw: position of its first chunk in its XCD's launch list
-    // pinned staging of the per-sort-event upload (one asynchronous copy each on the ctx stream) + the event behind them
-    HostBuf<DrawDev> h_draws;
-    HostBuf<uint32_t> h_xcd_first;
-    HostBuf<MergeSeg> h_segs;
-    HostBuf<MergeGroup> h_groups;
-    HostBuf<uint2> h_blocks;               // (segment, first entry) of every <= 1024-entry block of the merged-list build
-    HostBuf<unsigned long long> h_n64;
-    hipEvent_t ev_up = nullptr;
+    Ref<uint32_t> xcd_first;               // per draw: position of its first chunk in its XCD's launch list
+    // what the merged arrays of this set hold, for the next sort event's reuse test (device-built sets only)
+    struct GroupDesc { uint32_t view, base, len, first, n; uint64_t hash; };
+    std::vector<GroupDesc> g_desc;
+    std::vector<gswt_merge_member> g_members;
+    bool g_valid = false;
+    hipEvent_t ev_up = nullptr;            // behind the upload: the pinned block may be refilled once it has fired
     bool ev_up_pending = false;
     size_t n_merged = 0;
-    bool bounds_valid = false;
-    uint32_t bounds_key[6] = {};           // map_half_wh, center_coord, tile_width bits, surface_type the merged offsets were formed with
     uint32_t n_launch = 0;                 // length of chunk_tab_xcd (>= n_chunks: short per-XCD lists are padded)
     uint32_t n_draws = 0, n_chunks = 0;
     uint64_t n_entries = 0;
     void release()
     {
-        draws.release(); chunk_tab.release(); chunk_tab_xcd.release(); merged_list.release(); merged_map.release(); draw_bounds.release();
-        xcd_first.release(); h_draws.release(); h_xcd_first.release(); h_segs.release(); h_groups.release(); h_blocks.release(); h_n64.release();
+        chunk_tab.release(); chunk_tab_xcd.release(); merged_list.release(); merged_map.release(); h_blob.release(); d_blob.release();
+        draws.p = nullptr; xcd_first.p = nullptr;
         if (ev_up) hipEventDestroy(ev_up);
         ev_up = nullptr;
     }
@@ -169,6 +196,7 @@ struct FrameSlot {
     // per-frame HBM buffers
     DevBuf<uint2> rects;
     DevBuf<Rec> recs;
+    DevBuf<uint32_t> cell_culled;          // column-band shards: per map cell, 1 = no splat of that tile instance can reach the band
     DevBuf<uint32_t> block_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
     DevBuf<uint2> ranges;
     DevBuf<uint32_t> item_base;
@@ -179,7 +207,7 @@ struct FrameSlot {
     DevBuf<float> depths;                  // per-slot depth: frames with a proxy depth buffer or GSWT_ORDER_DEPTH only
     void release_buffers()
     {
-        rects.release(); recs.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
+        rects.release(); recs.release(); cell_culled.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
         keys_b.release(); vals_a.release(); vals_b.release(); ghist.release(); ranges.release(); item_base.release();
         depth_ws.release(); partials.release(); item_tab.release(); col_f.release(); depths.release();
     }
@@ -195,6 +223,7 @@ struct gswt_ctx {
     // scene
     DevBuf<uint4> tex;
     size_t n_splats = 0;
+    float loc_lo[3] = {}, loc_hi[3] = {}, loc_max_trace = 0.0f;      // tile-local bounds of the splat centres, largest covariance trace
     DevBuf<uint32_t> static_list;
     std::vector<ListRef> lists;
     int n_lod = 0, n_tile = 0, n_view = 0;
@@ -214,9 +243,9 @@ struct gswt_ctx {
     DevBuf<int32_t> raw_depth;
     std::vector<uint32_t> raw_off;          // [(lod*n_tile + tile)*n_view + view] -> offset in raw_depth
     std::vector<uint32_t> raw_cnt, raw_merge_offset;   // [lod*n_tile + tile]
-    DevBuf<MergeSeg> mg_segs;
-    DevBuf<MergeGroup> mg_groups;
-    DevBuf<uint2> mg_blocks;
+
+    int opt_no_merge_reuse = 0;            // GSWT_OPT_NO_MERGE_REUSE: every merged group is re-sorted at every sort event
+    unsigned long long stat_groups_built = 0, stat_groups_reused = 0;
     DevBuf<uint32_t> mg_ws;
     bool draws_ready = false;
     // frame (the per-frame buffers live in the slots)
@@ -412,7 +441,7 @@ void gswt_destroy(gswt_ctx* c)
     if (c->ev_push) hipEventDestroy(c->ev_push);
     c->gather_buf.release();
     c->tex.release(); c->static_list.release(); c->hmap.release(); for (auto& ds : c->sets) ds.release();
-    c->raw_depth.release(); c->mg_segs.release(); c->mg_groups.release(); c->mg_blocks.release();
+    c->raw_depth.release(); 
     c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
     for (auto& sl : c->slots) {
         sl.release_buffers();
@@ -447,6 +476,7 @@ try {
     case GSWT_OPT_DEBUG_VARYINGS: c->opt_debug_varyings = value; return GSWT_OK;
     case GSWT_OPT_DEBUG_FLAGS: c->opt_dbg_flags = value; return GSWT_OK;
     case GSWT_OPT_TIMING: c->opt_timing = value; return GSWT_OK;
+    case GSWT_OPT_NO_MERGE_REUSE: c->opt_no_merge_reuse = value; return GSWT_OK;
     case GSWT_OPT_PAIR_CAP:
         if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "pair capacity must be >= 0");
         c->opt_fixed_pair_cap = value > 0; if (value > 0) c->pair_cap = (uint32_t)value;
@@ -472,6 +502,32 @@ try {
     HIP_TRY(c, c->tex.ensure(2 * n_splats));
     HIP_TRY(c, hipMemcpy(c->tex.p, tex_data, n_splats * 32, hipMemcpyHostToDevice));
     c->n_splats = n_splats;
+    {   // tile-local bounds of every splat centre and the largest covariance trace: what the band cull of column-sharded frames
+        // places at a map cell's origin (every Wang-tile instance is the same tile-local content)
+        float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+        float tr_max = 0.0f;
+        bool odd = false;
+        auto half_val = [](uint32_t h) -> float {           // halfToFloat of the shader (gswt.wgsl:478-494), upper bound is enough
+            const uint32_t e = (h >> 10) & 0x1Fu, fr = h & 0x3FFu;
+            if (e == 31u) return 0.0f;
+            const float m = e == 0u ? (float)fr * 2.98023223876953125e-08f : ldexpf(1.0f + (float)fr / 1024.0f, (int)e - 15);
+            return (h & 0x8000u) ? -m : m;
+        };
+        for (size_t i = 0; i < n_splats; i++) {
+            const uint32_t* r = tex_data + 8 * i;
+            float p[3];
+            memcpy(p, r, 12);
+            for (int k = 0; k < 3; k++) {
+                if (!(p[k] == p[k]) || p[k] > 3e38f || p[k] < -3e38f) { odd = true; continue; }
+                lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]);
+            }
+            const float tr = half_val(r[4] & 0xFFFFu) + half_val(r[5] >> 16) + half_val(r[6] >> 16);      // xx + yy + zz
+            if (tr == tr) tr_max = std::max(tr_max, tr);
+        }
+        if (odd || lo[0] > hi[0]) { for (int k = 0; k < 3; k++) { lo[k] = -3.402823466e+38f; hi[k] = 3.402823466e+38f; } }    // never cull
+        for (int k = 0; k < 3; k++) { c->loc_lo[k] = lo[k]; c->loc_hi[k] = hi[k]; }
+        c->loc_max_trace = tr_max;
+    }
     const size_t nl = (size_t)n_lod * n_tile * n_view;
     c->lists.assign(nl, ListRef{});
     std::vector<uint32_t> arena;
@@ -518,6 +574,8 @@ try {
 
 // Shared by gswt_set_draws (merged arrays from the host) and gswt_set_draws_merge_groups (built on the device:
 // merged_gs_index == nullptr && device_merge).
+// `device_merge`: called by gswt_set_draws_merge_groups, which has already planned the target set's upload block (it holds the
+// merge tables too) and issues the one copy + the chunk-table kernel itself once its own tables are in place.
 static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint32_t* merged_gs_index,
                           const uint32_t* merged_map_id, const uint32_t* merged_lod_id, size_t n_merged, bool device_merge)
 {
@@ -537,9 +595,9 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     // the set's pinned staging is free again once its previous upload has been consumed
     if (D.ev_up_pending) { HIP_TRY(c, hipEventSynchronize(D.ev_up)); D.ev_up_pending = false; }
     if (!D.ev_up) HIP_TRY(c, hipEventCreateWithFlags(&D.ev_up, hipEventDisableTiming));
-    HIP_TRY(c, D.h_draws.ensure((size_t)n_draws + 1));
-    HIP_TRY(c, D.h_xcd_first.ensure((size_t)n_draws + 1));
-    DrawDev* const dd = D.h_draws.p;
+    if (!device_merge) HIP_TRY(c, D.plan((size_t)n_draws, 0, 0, 0));
+    DrawDev* const dd = D.hp<DrawDev>(D.off_draws);
+    uint32_t* const h_xcd_first = D.hp<uint32_t>(D.off_xcd);
     uint64_t entries = 0;
     for (int i = 0; i < n_draws; i++) {
         const gswt_draw& g = draws[i];
@@ -588,7 +646,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
         DrawDev& d = dd[i];
         d.slot_base = (uint32_t)slot;
         const uint32_t nch = (d.count + kChunk - 1) / kChunk;
-        D.h_xcd_first.p[i] = (uint32_t)per_xcd[i & 7];
+        h_xcd_first[i] = (uint32_t)per_xcd[i & 7];
         per_xcd[i & 7] += nch;
         slot += (uint64_t)nch * kChunk;
     }
@@ -597,19 +655,15 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     size_t longest = 0;
     for (int x = 0; x < 8; x++) longest = std::max<size_t>(longest, (size_t)per_xcd[x]);
     if (longest * 8 >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: chunk table too large");
-    HIP_TRY(c, D.draws.ensure((size_t)n_draws + 1));
-    HIP_TRY(c, D.xcd_first.ensure((size_t)n_draws + 1));
     HIP_TRY(c, D.chunk_tab.ensure(n_chunks + 1));
     HIP_TRY(c, D.chunk_tab_xcd.ensure(longest * 8 + 1));
     D.n_launch = (uint32_t)(longest * 8);
-    {
+    for (int x = 0; x < 8; x++) D.per_xcd[x] = per_xcd[x];
+    D.longest = longest;
+    if (!device_merge) {
         hipStream_t s = c->stream;
-        if (n_draws) {
-            HIP_TRY(c, hipMemcpyAsync(D.draws.p, dd, (size_t)n_draws * sizeof(DrawDev), hipMemcpyHostToDevice, s));
-            HIP_TRY(c, hipMemcpyAsync(D.xcd_first.p, D.h_xcd_first.p, (size_t)n_draws * 4, hipMemcpyHostToDevice, s));
-        }
-        if (longest) HIP_TRY(c, hipMemsetAsync(D.chunk_tab_xcd.p, 0xFF, longest * 8 * sizeof(uint2), s));      // padding of short per-XCD lists
-        launch_chunk_tabs(s, D.draws.p, D.xcd_first.p, (uint32_t)n_draws, D.chunk_tab.p, D.chunk_tab_xcd.p);
+        HIP_TRY(c, hipMemcpyAsync(D.d_blob.p, D.h_blob.p, D.blob_bytes, hipMemcpyHostToDevice, s));      // the one upload of the event
+        launch_chunk_tabs(s, D.draws.p, D.xcd_first.p, (uint32_t)n_draws, D.chunk_tab.p, D.chunk_tab_xcd.p, D.per_xcd, D.longest);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(D.ev_up, s));
         D.ev_up_pending = true;
@@ -638,7 +692,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     }
     D.n_draws = (uint32_t)n_draws;
     D.n_chunks = (uint32_t)n_chunks;
-    D.bounds_valid = false;
+    D.g_valid = false;
     D.n_entries = entries;
     c->cur_set = target;
     c->draws_ready = true;       // the per-frame buffers are sized by enqueue_frame, per slot
@@ -682,88 +736,148 @@ try {
     if (n_groups < 0 || n_members < 0 || (n_groups && (!groups || !members))) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: bad groups");
     if (n_groups && c->raw_cnt.empty()) return fail(c, GSWT_ERR_STATE, "gswt_set_draws_merge_groups before gswt_upload_raw_depth");
     if (n_groups > 32768) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws_merge_groups: more than 32768 merged groups");
-    // segments and group ranges (the concatenation order IS the merged-arena order), staged in the target set's pinned memory
+    // Group ranges in the merged arrays (the concatenation order IS the merged-arena order).  A group whose view and ordered
+    // member tids equal a group of the PREVIOUS sort event keeps that event's list: it is copied on the device from the
+    // previous draw set with the members' map ids rewritten -- the reference's LRU hit (wangtile.rs:575-593) -- and only
+    // the other groups go through the segmented sort.  Everything is staged in the target set's pinned memory.
     hipSetDevice(c->device);
     const int target = c->draws_ready ? (c->cur_set + 1) % kDrawSets : c->cur_set;
     collect_set(c, target);
     DrawSet& D = c->sets[target];
+    const DrawSet* prev = (c->draws_ready && target != c->cur_set && c->sets[c->cur_set].g_valid && !c->opt_no_merge_reuse) ? &c->sets[c->cur_set] : nullptr;
     if (D.ev_up_pending) { HIP_TRY(c, hipEventSynchronize(D.ev_up)); D.ev_up_pending = false; }
-    HIP_TRY(c, D.h_groups.ensure((size_t)n_groups + 1));
-    HIP_TRY(c, D.h_n64.ensure(1));
-    size_t seg_cap = 0;
-    for (int g = 0; g < n_groups; g++) seg_cap += 2 * (size_t)groups[g].n_members;
-    HIP_TRY(c, D.h_segs.ensure(seg_cap + 1));
-    MergeSeg* const segs = D.h_segs.p;
-    MergeGroup* const grp = D.h_groups.p;
-    size_t n_segs = 0;
-    uint64_t total = 0;
+    {   // upper bound of the merged entries (sizes the block tables of the upload block)
+        size_t total_upper = 0;
+        for (int q = 0; q < n_members; q++) {
+            const gswt_merge_member& M = members[q];
+            if ((int)M.lod < c->n_lod && (int)M.tile < c->n_tile) total_upper += c->raw_cnt[(size_t)M.lod * c->n_tile + M.tile];
+            if (M.other_lod >= 0 && M.other_lod < c->n_lod && (int)M.tile < c->n_tile) total_upper += c->raw_cnt[(size_t)M.other_lod * c->n_tile + M.tile];
+        }
+        HIP_TRY(c, D.plan((size_t)std::max(n_draws, 0), (size_t)n_groups, (size_t)n_members, total_upper));
+    }
+    MergeSeg* const segs = D.hp<MergeSeg>(D.off_segs);
+    MergeGroup* const grp = D.hp<MergeGroup>(D.off_groups);       // build space: only the groups that are sorted
+    MergeCopy* const jobs = D.hp<MergeCopy>(D.off_jobs);
+    uint2* const h_remap = D.hp<uint2>(D.off_remap);
+    std::unordered_multimap<uint64_t, uint32_t> prev_by_hash;
+    if (prev) for (uint32_t q = 0; q < prev->g_desc.size(); q++) prev_by_hash.emplace(prev->g_desc[q].hash, q);
+    std::vector<DrawSet::GroupDesc> desc((size_t)n_groups);
+    size_t n_segs = 0, n_build = 0, n_jobs = 0, n_remap = 0;
+    uint64_t total = 0, build_total = 0;
     const size_t nv = (size_t)c->n_view;
     for (int g = 0; g < n_groups; g++) {
         const gswt_merge_group& G = groups[g];
         if ((uint64_t)G.first_member + G.n_members > (uint64_t)n_members || (int)G.view_id >= c->n_view)
             return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: group %d out of range", g);
-        grp[g].base = (uint32_t)total; grp[g].mn = 0; grp[g].mx = 0;
+        uint64_t h = 1469598103934665603ull ^ G.view_id, len = 0;
         for (uint32_t m = 0; m < G.n_members; m++) {
             const gswt_merge_member& M = members[G.first_member + m];
             const int lods[2] = {(int)M.lod, M.other_lod};
             for (int k = 0; k < 2; k++) {
                 if (lods[k] < 0) continue;
                 if (lods[k] >= c->n_lod || (int)M.tile >= c->n_tile) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: member tid out of range");
-                const size_t lt = (size_t)lods[k] * c->n_tile + M.tile;
-                MergeSeg sg;
-                sg.group = (uint32_t)g; sg.src = c->raw_off[lt * nv + G.view_id]; sg.len = c->raw_cnt[lt]; sg.start = (uint32_t)total;
-                sg.gs_offset = c->raw_merge_offset[lt]; sg.map_index = M.map_index; sg.lod = (uint32_t)lods[k]; sg._pad = 0;
-                if (sg.len) segs[n_segs++] = sg;
-                total += sg.len;
+                len += c->raw_cnt[(size_t)lods[k] * c->n_tile + M.tile];
+            }
+            h = (h ^ (((uint64_t)M.lod << 40) | ((uint64_t)M.tile << 8) | (uint64_t)(uint8_t)(M.other_lod + 1))) * 1099511628211ull;
+        }
+        DrawSet::GroupDesc& d = desc[g];
+        d.view = G.view_id; d.base = (uint32_t)total; d.len = (uint32_t)len; d.first = G.first_member; d.n = G.n_members; d.hash = h;
+        int match = -1;
+        if (prev && len) {
+            auto range = prev_by_hash.equal_range(h);
+            for (auto it = range.first; it != range.second && match < 0; ++it) {
+                const DrawSet::GroupDesc& p = prev->g_desc[it->second];
+                if (p.view != G.view_id || p.n != G.n_members || p.len != (uint32_t)len) continue;
+                bool same = true;
+                for (uint32_t m = 0; m < G.n_members && same; m++) {
+                    const gswt_merge_member& a = members[G.first_member + m];
+                    const gswt_merge_member& b = prev->g_members[p.first + m];
+                    same = a.lod == b.lod && a.tile == b.tile && a.other_lod == b.other_lod;
+                }
+                if (same && G.n_members <= 256u) match = (int)it->second;
             }
         }
-        grp[g].len = (uint32_t)(total - grp[g].base);
+        if (match >= 0) {
+            const DrawSet::GroupDesc& p = prev->g_desc[match];
+            MergeCopy jb;
+            jb.src = p.base; jb.dst = (uint32_t)total; jb.len = (uint32_t)len; jb.first_pair = (uint32_t)n_remap; jb.n_pairs = 0; jb._pad[0] = jb._pad[1] = jb._pad[2] = 0;
+            bool moved = false;
+            for (uint32_t m = 0; m < G.n_members; m++) moved = moved || members[G.first_member + m].map_index != prev->g_members[p.first + m].map_index;
+            if (moved) {
+                for (uint32_t m = 0; m < G.n_members; m++)
+                    h_remap[n_remap++] = make_uint2(prev->g_members[p.first + m].map_index, members[G.first_member + m].map_index);
+                jb.n_pairs = G.n_members;
+            }
+            jobs[n_jobs++] = jb;
+        } else if (len) {
+            MergeGroup& B = grp[n_build];
+            B.base = (uint32_t)build_total; B.len = (uint32_t)len; B.mn = 0; B.mx = 0; B.out_base = (uint32_t)total; B._pad[0] = B._pad[1] = B._pad[2] = 0;
+            for (uint32_t m = 0; m < G.n_members; m++) {
+                const gswt_merge_member& M = members[G.first_member + m];
+                const int lods[2] = {(int)M.lod, M.other_lod};
+                for (int k = 0; k < 2; k++) {
+                    if (lods[k] < 0) continue;
+                    const size_t lt = (size_t)lods[k] * c->n_tile + M.tile;
+                    MergeSeg sg;
+                    sg.group = (uint32_t)n_build; sg.src = c->raw_off[lt * nv + G.view_id]; sg.len = c->raw_cnt[lt]; sg.start = (uint32_t)build_total;
+                    sg.gs_offset = c->raw_merge_offset[lt]; sg.map_index = M.map_index; sg.lod = (uint32_t)lods[k]; sg._pad = 0;
+                    if (sg.len) segs[n_segs++] = sg;
+                    build_total += sg.len;
+                }
+            }
+            n_build++;
+        }
+        total += len;
     }
     if (total >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws_merge_groups: merged lists exceed 2^32 entries");
     for (int i = 0; i < n_draws; i++)
         if (draws[i].merged) {
             const uint32_t g = draws[i].merged_group;
-            if ((int)g >= n_groups || draws[i].merged_offset != grp[g].base || draws[i].merged_count != grp[g].len)
+            if ((int)g >= n_groups || draws[i].merged_offset != desc[g].base || draws[i].merged_count != desc[g].len)
                 return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: draw %d does not match group %u (offset %u/%u count %u/%u)", i, g,
-                            draws[i].merged_offset, (int)g < n_groups ? grp[g].base : 0u, draws[i].merged_count, (int)g < n_groups ? grp[g].len : 0u);
+                            draws[i].merged_offset, (int)g < n_groups ? desc[g].base : 0u, draws[i].merged_count, (int)g < n_groups ? desc[g].len : 0u);
         }
+    const uint32_t* const prev_list = prev ? prev->merged_list.p : nullptr;      // (set_draws_impl below may grow the target's arrays, not these)
+    const uint32_t* const prev_map = prev ? prev->merged_map.p : nullptr;
     int rc = set_draws_impl(c, draws, n_draws, nullptr, nullptr, nullptr, (size_t)total, true);       // fills the same target set
     if (rc != GSWT_OK) return rc;
-    if (total == 0) return GSWT_OK;
+    D.g_desc.swap(desc);
+    D.g_members.assign(members, members + n_members);
+    D.g_valid = true;
+    c->stat_groups_built += n_build; c->stat_groups_reused += n_jobs;
     c->draws_ready = false;
     hipStream_t s = c->stream;
-    const uint32_t n_total = (uint32_t)total;
-    int gbits = 1;
-    while ((1 << gbits) < n_groups) gbits++;
-    // The build's device scratch (segments, groups, sort workspace) is shared by all sort events; everything below is ordered
-    // on the ctx stream, so the previous build is through with it by the time this one's copies run.  Nothing is waited for:
-    // every frame submitted from now on starts behind an event recorded on that stream (enqueue_frame), i.e. behind the
-    // finished lists.  (A grown scratch buffer is the exception: hipFree waits for the device.)
-    HIP_TRY(c, c->mg_segs.ensure(n_segs + 1));
-    HIP_TRY(c, c->mg_groups.ensure((size_t)n_groups + 1));
-    // block table: every segment cut into runs of <= 1024 entries (what one workgroup of k_mg_minmax / k_mg_keys handles)
-    size_t n_blocks = 0;
-    for (size_t q = 0; q < n_segs; q++) n_blocks += ((size_t)segs[q].len + 1023) / 1024;
-    HIP_TRY(c, D.h_blocks.ensure(n_blocks + 1));
-    {
-        size_t b = 0;
-        for (size_t q = 0; q < n_segs; q++)
-            for (uint32_t off = 0; off < segs[q].len; off += 1024u) D.h_blocks.p[b++] = make_uint2((uint32_t)q, off);
+    // block tables: every copy job / segment cut into runs of <= 1024 entries (what one workgroup handles)
+    uint2* const h_cblocks = D.hp<uint2>(D.off_cblocks);
+    uint2* const h_blocks = D.hp<uint2>(D.off_blocks);
+    size_t n_cb = 0, n_blocks = 0;
+    for (size_t q = 0; q < n_jobs; q++)
+        for (uint32_t off = 0; off < jobs[q].len; off += 1024u) h_cblocks[n_cb++] = make_uint2((uint32_t)q, off);
+    for (size_t q = 0; q < n_segs; q++)
+        for (uint32_t off = 0; off < segs[q].len; off += 1024u) h_blocks[n_blocks++] = make_uint2((uint32_t)q, off);
+    const uint32_t n_total = (uint32_t)build_total;
+    memset(D.hp<uint8_t>(D.off_n64), 0, 64);              // the sort reads its item count and an overflow word 16 bytes behind it
+    *D.hp<unsigned long long>(D.off_n64) = n_total;
+    // ONE upload for the whole event, then the chunk tables, the copies and (for the groups that changed) the segmented sort, all
+    // on the ctx stream.  Nothing is waited for: every frame submitted from now on starts behind an event recorded on that
+    // stream (enqueue_frame), i.e. behind the finished lists.  (A grown buffer is the exception: hipFree waits for the device.)
+    HIP_TRY(c, hipMemcpyAsync(D.d_blob.p, D.h_blob.p, D.blob_bytes, hipMemcpyHostToDevice, s));
+    launch_chunk_tabs(s, D.draws.p, D.xcd_first.p, D.n_draws, D.chunk_tab.p, D.chunk_tab_xcd.p, D.per_xcd, D.longest);
+    if (n_jobs)
+        launch_merge_copy(s, D.dp<MergeCopy>(D.off_jobs), D.dp<uint2>(D.off_cblocks), (uint32_t)n_cb, D.dp<uint2>(D.off_remap), prev_list, prev_map,
+                          D.merged_list.p, D.merged_map.p);
+    if (n_build) {
+        int gbits = 1;
+        while ((1u << gbits) < n_build) gbits++;
+        const size_t radix_words = radix_ws_words(n_total, 16 + gbits);
+        HIP_TRY(c, c->mg_ws.ensure(4 * (size_t)n_total + radix_words + 16));        // sort workspace, shared by all events (stream-ordered)
+        uint32_t* w = c->mg_ws.p;
+        uint32_t* radix = w + 4 * (size_t)n_total;
+        HIP_TRY(c, hipMemsetAsync(radix, 0, (radix_words + 16) * 4, s));
+        launch_merge_build(s, D.dp<MergeSeg>(D.off_segs), (uint32_t)n_segs, D.dp<uint2>(D.off_blocks), (uint32_t)n_blocks, D.dp<MergeGroup>(D.off_groups),
+                           (uint32_t)n_build, c->raw_depth.p, n_total, D.dp<unsigned long long>(D.off_n64), w, w + n_total, w + 2 * (size_t)n_total,
+                           w + 3 * (size_t)n_total, radix, gbits, D.merged_list.p, D.merged_map.p);
     }
-    HIP_TRY(c, c->mg_blocks.ensure(n_blocks + 1));
-    HIP_TRY(c, hipMemcpyAsync(c->mg_blocks.p, D.h_blocks.p, n_blocks * sizeof(uint2), hipMemcpyHostToDevice, s));
-    const size_t radix_words = radix_ws_words(n_total, 16 + gbits);
-    HIP_TRY(c, c->mg_ws.ensure(4 * (size_t)n_total + radix_words + 16));
-    HIP_TRY(c, hipMemcpyAsync(c->mg_segs.p, segs, n_segs * sizeof(MergeSeg), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipMemcpyAsync(c->mg_groups.p, grp, (size_t)n_groups * sizeof(MergeGroup), hipMemcpyHostToDevice, s));
-    uint32_t* w = c->mg_ws.p;
-    uint32_t* radix = w + 4 * (size_t)n_total;
-    HIP_TRY(c, hipMemsetAsync(radix, 0, (radix_words + 16) * 4, s));
-    unsigned long long* n_dev = reinterpret_cast<unsigned long long*>(radix + radix_words + (radix_words & 1));   // 8-byte aligned, followed by zeros
-    D.h_n64.p[0] = n_total;
-    HIP_TRY(c, hipMemcpyAsync(n_dev, D.h_n64.p, 8, hipMemcpyHostToDevice, s));
-    launch_merge_build(s, c->mg_segs.p, (uint32_t)n_segs, c->mg_blocks.p, (uint32_t)n_blocks, c->mg_groups.p, (uint32_t)n_groups, c->raw_depth.p, n_total, n_dev,
-                       w, w + n_total, w + 2 * (size_t)n_total, w + 3 * (size_t)n_total, radix, gbits, D.merged_list.p, D.merged_map.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(D.ev_up, s));
     D.ev_up_pending = true;
@@ -898,6 +1012,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         // band culling needs positions that are the list positions: no surface mapping, no point-cloud covariance
         f.band_cull = (su->surface_type == 0u && !(su->point_cloud_radius > 0.0f)) ? 1 : 0;
     }
+    for (int k = 0; k < 3; k++) { f.loc_lo[k] = c->loc_lo[k]; f.loc_hi[k] = c->loc_hi[k]; }
+    f.loc_max_trace = c->loc_max_trace;
     f.hm_w = c->hm_w; f.hm_h = c->hm_h;
     f.dbg_flags = c->opt_dbg_flags;
 
@@ -946,34 +1062,18 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     unsigned long long* const d_P = d_counters + 1;
     hipEvent_t* ev = sl.ev;
     // ---- cull (+ clears the frame's accumulators) + project
-    if (f.band_cull) {
-        // bounds of every draw's splat centres: per sort event, and again when the uniforms that place merged members move.
-        // Computed on the CTX stream before this frame's start event is recorded there, so this frame and every later one
-        // is ordered behind it without any host wait; frames already in flight on this set computed theirs earlier.
-        uint32_t key[6] = {su->map_half_wh[0], su->map_half_wh[1], (uint32_t)su->center_coord[0], (uint32_t)su->center_coord[1], 0u, su->surface_type};
-        memcpy(&key[4], &su->tile_width, 4);
-        const bool stale = D.bounds_valid && memcmp(key, D.bounds_key, sizeof(key)) != 0;
-        if (!D.bounds_valid || stale) {
-            if (stale)                                          // earlier frames on this set may still read the old bounds (rare:
-                for (auto& other : c->slots)                   // the placing uniforms normally change with a sort event = a new set)
-                    if (&other != &sl && other.set == sl.set && other.stream) HIP_TRY(c, hipStreamSynchronize(other.stream));
-            HIP_TRY(c, D.draw_bounds.ensure((size_t)D.n_draws + 1));
-            launch_draw_bounds(c->stream, f, D.draws.p, D.n_draws, D.chunk_tab.p, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
-                               c->tex.p, D.draw_bounds.p);
-            memcpy(D.bounds_key, key, sizeof(key));
-            D.bounds_valid = true;
-        }
-    }
     // the frame starts after everything submitted to the ctx stream so far (inputs produced there, earlier readers of
     // the output buffer, the device-side merged-list build and the draw bounds of its draw set), on the slot's own stream
     HIP_TRY(c, hipEventRecord(sl.ev_in, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(s, sl.ev_in, 0));
     if (sc > 1 && out_px > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
-    launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, D.draw_bounds.p, zero_a, (uint32_t)(16 + n_super2 + radix_words),
+    const uint32_t n_cells = f.band_cull ? (2u * su->map_half_wh[0] + 1u) * (2u * su->map_half_wh[1] + 1u) : 0u;
+    HIP_TRY(c, sl.cell_culled.ensure((size_t)n_cells + 1));
+    launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)(16 + n_super2 + radix_words),
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
-                   c->tex.p, c->hmap.p, sl.draw_culled.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
+                   c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p, sl.col_f.p, cap);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
     // ---- emit
@@ -1431,6 +1531,13 @@ try {
     buf.release();
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_totals")
+
+int gswt_debug_merge_stats(const gswt_ctx* c, unsigned long long out[2])
+{
+    if (!c || !out) return GSWT_ERR_BAD_ARG;
+    out[0] = c->stat_groups_built; out[1] = c->stat_groups_reused;
+    return GSWT_OK;
+}
 
 int gswt_debug_read_ranges(gswt_ctx* c, uint32_t* out, size_t capacity_tiles, size_t* n_tiles)
 try {

@@ -62,18 +62,11 @@ struct Frame {
     // contiguous tile-column band (off: col0 = 0, col1 = all columns).  tiles_x is the number of columns THIS ctx composites.
     int32_t col0, col1;
     int32_t out_w, out_x0;                 // width of the output image in pixels and the frame pixel column of its column 0
-    int32_t band_cull;                     // 1: k_cull drops draws whose splats cannot reach the band (needs draw bounds)
+    int32_t band_cull;                     // 1: k_cull drops the draws / merged-group members whose splats cannot reach the band
+    float loc_lo[3], loc_hi[3];            // tile-local bounds of every splat centre of the scene (gswt_upload_scene)
+    float loc_max_trace;                   // largest trace of a stored covariance (>= its largest eigenvalue)
     int32_t hm_w, hm_h;
     int32_t dbg_flags;       // profiling ablations (GSWT_OPT_DEBUG_FLAGS); 0 in normal operation
-};
-
-// Per-draw bounds for band culling (computed on the device by k_draw_bounds, not part of the ABI): AABB of the splat
-// centres in the space of `pos + offset` (before scene_scale) and the largest trace of a stored covariance (>= its
-// largest eigenvalue).  Stored as order-preserving integers so that integer atomic min / max apply.
-struct DrawBounds {
-    int32_t lo[3], hi[3];
-    int32_t max_trace;
-    int32_t _pad;
 };
 
 // Projected splat record consumed by the compositor (32 B, two 16-B words; one 32-B-aligned sector per gather).
@@ -91,8 +84,17 @@ struct MergeSeg {
     uint32_t group, src, len, start, gs_offset, map_index, lod, _pad;
 };
 struct MergeGroup {
-    uint32_t base, len;
+    uint32_t base, len;       // range in the BUILD space (the concatenation of the groups that are sorted this event)
     int32_t mn, mx;
+    uint32_t out_base;        // first entry of the group in the merged arrays
+    uint32_t _pad[3];
+};
+// A group whose (view, ordered member tids) equal a group of the previous sort event: its list is copied from the previous
+// draw set, map ids rewritten member by member (the reference's LRU hit, wangtile.rs:575-593).
+struct MergeCopy {
+    uint32_t src, dst, len;   // ranges in the previous / new merged arrays
+    uint32_t first_pair, n_pairs;   // (old map index, new map index) pairs of its members in the remap table; n_pairs = 0: map ids unchanged
+    uint32_t _pad[3];
 };
 
 // vs_main varyings for the debug/parity hook (48 B, same layout as the oracle's orc_splat)

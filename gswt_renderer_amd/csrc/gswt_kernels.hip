@@ -1,7 +1,6 @@
 // gswt_kernels.hip -- hand-written CDNA4 (gfx950) kernels of the GSWT hot path.
 //
 //   k_cull        : per-draw viewport cull + lod_enable skip (renderer.rs:472-497), column-band cull; clears the frame counters
-//   k_draw_bounds : per-draw bounds of the splat centres / covariance traces (per sort event; band cull of sharded frames)
 //   k_project     : Wang-tile instancing + vs_main (gswt.wgsl:27-422) per list entry: None / HeightMap / Sphere surface,
 //                   LOD blend, EWA projection, debug draw modes
 //   k_totals/k_emit : (splat, 16x16 screen tile) pair emission in composite order, no scan launches
@@ -192,74 +191,20 @@ __device__ __forceinline__ int owned_rows(int ty0, int ty1, int index, int count
     return (ty1 - first) / count + 1;
 }
 
-// float <-> int with the same ordering (for integer atomicMin / atomicMax on floats)
-__device__ __forceinline__ int32_t f2ord(float x) { const int32_t i = __float_as_int(x); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
-__device__ __forceinline__ float ord2f(int32_t i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
-
-// Bounds of every draw's splat centres (pos + instancing offset, before scene_scale) and the largest covariance trace:
-// what the band cull of a column-sharded frame needs to drop, per rank, the draws whose splats cannot reach its band.
-// Per sort event (and when the merged-offset uniforms change), not per frame.  One workgroup per 256-entry chunk.
-__global__ __launch_bounds__(256) void k_draw_bounds(const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
-                                                     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
-                                                     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
-                                                     DrawBounds* __restrict__ bounds)
-{
-    __shared__ int32_t s_lo[3], s_hi[3], s_tr;
-    if (threadIdx.x < 3) { s_lo[threadIdx.x] = 0x7FFFFFFF; s_hi[threadIdx.x] = (int32_t)0x80000000; }
-    if (threadIdx.x == 3) s_tr = (int32_t)0x80000000;
-    __syncthreads();
-    const uint2 ct = chunk_tab[blockIdx.x];
-    const DrawDev& d = draws[ct.x];
-    const uint32_t r = ct.y + threadIdx.x;
-    if (r < d.count) {
-        const uint32_t j = d.count - 1u - r;
-        const uint32_t* list = d.merged ? merged_list : static_list;
-        const uint32_t entry = list[d.list_base + j];
-        const uint32_t gs_index = entry & kIdxMask;
-        const uint4 w0 = tex[2 * (size_t)gs_index];
-        const uint4 w1 = tex[2 * (size_t)gs_index + 1];
-        float ox = d.off[0], oy = d.off[1], oz = d.off[2];
-        if (d.single_draw == 1u) {                 // gswt.wgsl:52-63, same expression as k_project
-            const uint32_t map_id = merged_map[d.list_base + j];
-            uint32_t map_wh_y = 2u * f.map_half_wh[1];
-            if (f.surface_type != 2u) map_wh_y += 1u;
-            ox = (float)((int32_t)(map_id / map_wh_y - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
-            oy = (float)((int32_t)(map_id % map_wh_y - f.map_half_wh[1]) + f.center_coord[1]) * f.tile_width;
-            oz = 0.0f;
-        }
-        const float px = u2f(w0.x) + ox, py = u2f(w0.y) + oy, pz = u2f(w0.z) + oz;
-        const float tr = (half_decode(w1.x & 0xFFFFu) + half_decode(w1.y >> 16)) + half_decode(w1.z >> 16);   // xx + yy + zz
-        atomicMin(&s_lo[0], f2ord(px)); atomicMax(&s_hi[0], f2ord(px));
-        atomicMin(&s_lo[1], f2ord(py)); atomicMax(&s_hi[1], f2ord(py));
-        atomicMin(&s_lo[2], f2ord(pz)); atomicMax(&s_hi[2], f2ord(pz));
-        atomicMax(&s_tr, f2ord(tr == tr ? tr : __builtin_inff()));
-    }
-    __syncthreads();
-    DrawBounds* b = bounds + ct.x;
-    if (threadIdx.x < 3) { atomicMin(&b->lo[threadIdx.x], s_lo[threadIdx.x]); atomicMax(&b->hi[threadIdx.x], s_hi[threadIdx.x]); }
-    if (threadIdx.x == 3) atomicMax(&b->max_trace, s_tr);
-}
-
-__global__ __launch_bounds__(256) void k_draw_bounds_init(DrawBounds* __restrict__ bounds, uint32_t n_draws)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n_draws) return;
-    DrawBounds b;
-    b.lo[0] = b.lo[1] = b.lo[2] = 0x7FFFFFFF;
-    b.hi[0] = b.hi[1] = b.hi[2] = (int32_t)0x80000000;
-    b.max_trace = (int32_t)0x80000000; b._pad = 0;
-    bounds[i] = b;
-}
-
 // Chunk tables of a draw set, written on the device from the draw records (per sort event): a chunk = 256 list entries of
 // one draw.  chunk_tab is in slot order (chunk c = slots c * 256 ...); chunk_tab_xcd is k_project's launch order: the
 // chunks of draw d sit in the list of XCD d % 8, lists interleaved so that launch position p runs on XCD p % 8 (short
-// lists are padded with 0xFFFFFFFF by a memset before this kernel).  One workgroup per draw.
+// lists are padded with 0xFFFFFFFF by the eight extra workgroups at the end of the grid).  One workgroup per draw.
+struct XcdLens { uint32_t len[8]; uint32_t longest; };
 __global__ __launch_bounds__(256) void k_chunk_tabs(const DrawDev* __restrict__ draws, const uint32_t* __restrict__ xcd_first, uint32_t n_draws,
-                                                    uint2* __restrict__ chunk_tab, uint2* __restrict__ chunk_tab_xcd)
+                                                    uint2* __restrict__ chunk_tab, uint2* __restrict__ chunk_tab_xcd, const XcdLens xl)
 {
     const uint32_t d = blockIdx.x;
-    if (d >= n_draws) return;
+    if (d >= n_draws) {
+        const uint32_t x = d - n_draws;              // 0..7: padding of XCD x's list up to the longest one
+        for (uint32_t k = xl.len[x & 7u] + threadIdx.x; k < xl.longest; k += 256u) chunk_tab_xcd[(size_t)k * 8u + x] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        return;
+    }
     const uint32_t nch = (draws[d].count + (uint32_t)kChunk - 1u) / (uint32_t)kChunk;
     const uint32_t c0 = draws[d].slot_base / (uint32_t)kChunk, x0 = xcd_first[d];
     for (uint32_t k = threadIdx.x; k < nch; k += 256u) {
@@ -272,15 +217,57 @@ __global__ __launch_bounds__(256) void k_chunk_tabs(const DrawDev* __restrict__ 
 // ------------------------------------------------------------------------------------
 // k_cull: the CPU viewport culling + lod_enable skip of renderer.rs:472-497, one thread per draw.
 // ------------------------------------------------------------------------------------
+// Column-band sharding: can any splat whose centre lies in the box [lo, hi] (world space, before scene_scale) reach this
+// rank's pixel columns?  Conservative: the centres lie in the convex hull of the 8 projected box corners (all in front of
+// the camera, else keep), and a splat's pixel half extent is <= 2 s sqrt(lambda1) with lambda1 <= |J|_F^2 max(scene_scale)^2
+// trace(Vrk) at the nearest depth, capped by the 1024-px axis clamp (gswt.wgsl:257-258); 25 % + 2 px of slack on top.
+__device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], const float hi[3])
+{
+    float xmin = 3.402823466e+38f, xmax = -3.402823466e+38f, wmin = 3.402823466e+38f;
+    for (int k = 0; k < 8; k++) {
+        const float px = ((k & 1) ? hi[0] : lo[0]) * f.scene_scale[0];
+        const float py = ((k & 2) ? hi[1] : lo[1]) * f.scene_scale[1];
+        const float pz = ((k & 4) ? hi[2] : lo[2]) * f.scene_scale[2];
+        const float cx = ((f.VP[0] * px + f.VP[4] * py) + f.VP[8] * pz) + f.VP[12];
+        const float cw = ((f.VP[3] * px + f.VP[7] * py) + f.VP[11] * pz) + f.VP[15];
+        wmin = fminf(wmin, cw);
+        const float xp = (0.5f * (cx / cw) + 0.5f) * f.W;
+        xmin = fminf(xmin, xp); xmax = fmaxf(xmax, xp);
+    }
+    if (!(wmin > 1e-6f && xmin == xmin && xmax == xmax)) return false;
+    const float smax = fmaxf(fabsf(f.scene_scale[0]), fmaxf(fabsf(f.scene_scale[1]), fabsf(f.scene_scale[2])));
+    const float hx = 1.3f * f.htan[0], hy = 1.3f * f.htan[1];
+    const float jn2 = (f.focal[0] * f.focal[0] * (1.0f + hx * hx) + f.focal[1] * f.focal[1] * (1.0f + hy * hy)) / (wmin * wmin);
+    const float lam = jn2 * smax * smax * fmaxf(f.loc_max_trace, 0.0f);
+    const float ss = fabsf(f.splat_scale);
+    const float rad = fminf(2.0f * ss * sqrtf(lam), 1448.2f * ss) * 1.25f + 2.0f;
+    if (!(rad == rad)) return false;
+    return xmax + rad < (float)(f.col0 * kTile) || xmin - rad >= (float)(f.col1 * kTile);
+}
+
 // Also clears the per-frame accumulators (first kernel of the frame; saves three memset launches).
+// Band culling works on MAP CELLS: every splat of a Wang-tile instance lies in (cell origin + the scene's tile-local position
+// bounds), f.loc_lo .. f.loc_hi, so a plain / blending draw is tested with its own offset and the members of a merged group
+// through cell_culled[map id] (k_project skips such entries before gathering their records): the heaviest band no longer
+// projects whole merged groups that merely touch it.  No per-sort-event bounds pass.
 __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __restrict__ draws, uint32_t n_draws,
-                                              uint32_t* __restrict__ draw_culled, const DrawBounds* __restrict__ bounds,
+                                              uint32_t* __restrict__ draw_culled, uint32_t* __restrict__ cell_culled, uint32_t n_cells,
                                               uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
                                               uint32_t* __restrict__ zero_b, uint32_t n_zero_b)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     for (uint32_t j = i; j < n_zero_a; j += gridDim.x * 256u) zero_a[j] = 0u;
     for (uint32_t j = i; j < n_zero_b; j += gridDim.x * 256u) zero_b[j] = 0u;
+    if (f.band_cull) {
+        uint32_t map_wh_y = 2u * f.map_half_wh[1] + 1u;                      // plain surface only (band_cull is off otherwise)
+        for (uint32_t j = i; j < n_cells; j += gridDim.x * 256u) {
+            // the merged-member offset of gswt.wgsl:52-63, same expression as k_project
+            const float ox = (float)((int32_t)(j / map_wh_y - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
+            const float oy = (float)((int32_t)(j % map_wh_y - f.map_half_wh[1]) + f.center_coord[1]) * f.tile_width;
+            const float lo[3] = {f.loc_lo[0] + ox, f.loc_lo[1] + oy, f.loc_lo[2]}, hi[3] = {f.loc_hi[0] + ox, f.loc_hi[1] + oy, f.loc_hi[2]};
+            cell_culled[j] = band_misses(f, lo, hi) ? 1u : 0u;
+        }
+    }
     if (i >= n_draws) return;
     const DrawDev& d = draws[i];
     uint32_t culled = 0;
@@ -302,33 +289,11 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
     if (!((f.lod_enable_mask >> (d.lod & 31u)) & 1u)) culled = 1;
     // Column-band sharding: drop the draw when none of its splats can touch this rank's pixel columns.  (Doing the same
     // cull on the host and launching k_project / k_emit over the surviving chunks only was measured: no gain -- the
-    // workgroups of culled chunks exit at once and two frames overlap: 124 us per rank at N = 8 either way.)  Conservative:
-    // the centres lie in the convex hull of the 8 projected bound corners (all in front of the camera, else keep), and a
-    // splat's pixel half extent is <= 2 s sqrt(lambda1) with lambda1 <= |J|_F^2 max(scene_scale)^2 trace(Vrk) at the
-    // nearest depth, capped by the 1024-px axis clamp (gswt.wgsl:257-258); 25 % + 2 px of slack on top.
-    if (!culled && f.band_cull && d.count) {
-        const DrawBounds b = bounds[i];
-        const float lo[3] = {ord2f(b.lo[0]), ord2f(b.lo[1]), ord2f(b.lo[2])}, hi[3] = {ord2f(b.hi[0]), ord2f(b.hi[1]), ord2f(b.hi[2])};
-        float xmin = 3.402823466e+38f, xmax = -3.402823466e+38f, wmin = 3.402823466e+38f;
-        for (int k = 0; k < 8; k++) {
-            const float px = ((k & 1) ? hi[0] : lo[0]) * f.scene_scale[0];
-            const float py = ((k & 2) ? hi[1] : lo[1]) * f.scene_scale[1];
-            const float pz = ((k & 4) ? hi[2] : lo[2]) * f.scene_scale[2];
-            const float cx = ((f.VP[0] * px + f.VP[4] * py) + f.VP[8] * pz) + f.VP[12];
-            const float cw = ((f.VP[3] * px + f.VP[7] * py) + f.VP[11] * pz) + f.VP[15];
-            wmin = fminf(wmin, cw);
-            const float xp = (0.5f * (cx / cw) + 0.5f) * f.W;
-            xmin = fminf(xmin, xp); xmax = fmaxf(xmax, xp);
-        }
-        if (wmin > 1e-6f && xmin == xmin && xmax == xmax) {
-            const float smax = fmaxf(fabsf(f.scene_scale[0]), fmaxf(fabsf(f.scene_scale[1]), fabsf(f.scene_scale[2])));
-            const float hx = 1.3f * f.htan[0], hy = 1.3f * f.htan[1];
-            const float jn2 = (f.focal[0] * f.focal[0] * (1.0f + hx * hx) + f.focal[1] * f.focal[1] * (1.0f + hy * hy)) / (wmin * wmin);
-            const float lam = jn2 * smax * smax * fmaxf(ord2f(b.max_trace), 0.0f);
-            const float ss = fabsf(f.splat_scale);
-            const float rad = fminf(2.0f * ss * sqrtf(lam), 1448.2f * ss) * 1.25f + 2.0f;
-            if (!(rad == rad) || xmax + rad < (float)(f.col0 * kTile) || xmin - rad >= (float)(f.col1 * kTile)) { if (rad == rad) culled = 1; }
-        }
+    // workgroups of culled chunks exit at once and the frames overlap.)
+    if (!culled && f.band_cull && d.count && d.single_draw != 1u) {
+        const float lo[3] = {f.loc_lo[0] + d.off[0], f.loc_lo[1] + d.off[1], f.loc_lo[2] + d.off[2]};
+        const float hi[3] = {f.loc_hi[0] + d.off[0], f.loc_hi[1] + d.off[1], f.loc_hi[2] + d.off[2]};
+        if (band_misses(f, lo, hi)) culled = 1;
     }
     draw_culled[i] = culled;
 }
@@ -354,7 +319,7 @@ __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
-    const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, uint2* __restrict__ rects,
+    const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, const uint32_t* __restrict__ cell_culled, uint2* __restrict__ rects,
     Rec* __restrict__ recs, float* __restrict__ depths, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
     Varyings* __restrict__ dbg, float4* __restrict__ col_f)
 {
@@ -392,6 +357,8 @@ __global__ __launch_bounds__(256) void k_project(
         const uint32_t gs_index = entry & kIdxMask;
         const uint32_t lod_id = entry >> kLodShift;
         do {
+            // column-band shard: the member tile this entry belongs to cannot reach the band (k_cull's cell table)
+            if (f.band_cull && d.single_draw == 1u && cell_culled[map_id_m] != 0u) break;
             // A1 gswt.wgsl:38-42
             if (d.valid_lod_id >= 0 && d.valid_lod_id != (int32_t)lod_id) break;
             // A2 :45-49
@@ -1159,11 +1126,33 @@ __global__ __launch_bounds__(256) void k_mg_final(const MergeSeg* __restrict__ s
     if (p >= n_total) return;
     const uint32_t g = sorted_keys[p] >> 16;
     const MergeGroup gr = groups[g];
-    const uint32_t out = gr.base + (gr.len - 1u - (p - gr.base));          // depth_index.reverse()
+    const uint32_t out = gr.out_base + (gr.len - 1u - (p - gr.base));      // depth_index.reverse()
     const uint32_t e = sorted_vals[p];
     const MergeSeg sg = segs[mg_find_seg(segs, n_segs, e)];
     merged_list[out] = ((e - sg.start) + sg.gs_offset) | (sg.lod << kLodShift);
     merged_map[out] = sg.map_index;
+}
+
+// Groups unchanged since the previous sort event: one workgroup per 1024 entries of a copy job (block table as above).
+__global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ jobs, const uint2* __restrict__ blocks, const uint2* __restrict__ remap,
+                                                 const uint32_t* __restrict__ old_list, const uint32_t* __restrict__ old_map,
+                                                 uint32_t* __restrict__ new_list, uint32_t* __restrict__ new_map)
+{
+    __shared__ uint2 s_pairs[256];
+    const uint2 b = blocks[blockIdx.x];
+    const MergeCopy jb = jobs[b.x];
+    const uint32_t np = min(jb.n_pairs, 256u);
+    if (threadIdx.x < np) s_pairs[threadIdx.x] = remap[jb.first_pair + threadIdx.x];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t i = b.y + k * 256u + threadIdx.x;
+        if (i >= jb.len) break;
+        new_list[jb.dst + i] = old_list[jb.src + i];
+        uint32_t m = old_map[jb.src + i];
+        for (uint32_t q = 0; q < np; q++) if (s_pairs[q].x == m) { m = s_pairs[q].y; break; }
+        new_map[jb.dst + i] = m;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1652,31 +1641,26 @@ __global__ void k_unshard(const float4* __restrict__ gathered, float4* __restric
 }
 
 // ---- launch wrappers (called from gswt_api.hip) -------------------------------------
-void launch_chunk_tabs(hipStream_t s, const DrawDev* draws, const uint32_t* xcd_first, uint32_t n_draws, uint2* chunk_tab, uint2* chunk_tab_xcd)
+void launch_chunk_tabs(hipStream_t s, const DrawDev* draws, const uint32_t* xcd_first, uint32_t n_draws, uint2* chunk_tab, uint2* chunk_tab_xcd,
+                       const uint64_t per_xcd[8], uint64_t longest)
 {
-    if (n_draws) hipLaunchKernelGGL(k_chunk_tabs, dim3(n_draws), dim3(256), 0, s, draws, xcd_first, n_draws, chunk_tab, chunk_tab_xcd);
+    XcdLens xl;
+    for (int x = 0; x < 8; x++) xl.len[x] = (uint32_t)per_xcd[x];
+    xl.longest = (uint32_t)longest;
+    if (n_draws) hipLaunchKernelGGL(k_chunk_tabs, dim3(n_draws + 8u), dim3(256), 0, s, draws, xcd_first, n_draws, chunk_tab, chunk_tab_xcd, xl);
 }
 
-void launch_draw_bounds(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, const uint2* chunk_tab, uint32_t n_chunks,
-                        const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
-                        DrawBounds* bounds)
-{
-    if (n_draws == 0) return;
-    hipLaunchKernelGGL(k_draw_bounds_init, dim3((n_draws + 255u) / 256u), dim3(256), 0, s, bounds, n_draws);
-    if (n_chunks) hipLaunchKernelGGL(k_draw_bounds, dim3(n_chunks), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list, merged_map, tex, bounds);
-}
-
-void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, const DrawBounds* bounds,
+void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, uint32_t* cell_culled, uint32_t n_cells,
                  uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b)
 {
     uint32_t grid = (n_draws + 255) / 256;
     if (grid < 32) grid = 32;
-    hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, bounds, zero_a, n_zero_a, zero_b, n_zero_b);
+    hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
-                    const float* hmap, const uint32_t* draw_culled, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
+                    const float* hmap, const uint32_t* draw_culled, const uint32_t* cell_culled, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
                     uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap)
 {
     if (n_chunks == 0) return;
@@ -1684,7 +1668,7 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
 #define GSWT_LAUNCH_PROJECT(D, F)                                                                                              \
     hipLaunchKernelGGL((k_project<D, F>), dim3(n_launch), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,        \
-                       merged_map, tex, hmap, draw_culled, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f)
+                       merged_map, tex, hmap, draw_culled, cell_culled, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f)
     if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
     else if (debug) { GSWT_LAUNCH_PROJECT(true, false); }
     else if (full) { GSWT_LAUNCH_PROJECT(false, true); }
@@ -1787,6 +1771,12 @@ void launch_merge_build(hipStream_t s, const MergeSeg* segs, uint32_t n_segs, co
     const int where = launch_sort(s, ka, va, kb, vb, n_total, n_total_dev, 16 + group_bits, radix_ws);
     hipLaunchKernelGGL(k_mg_final, dim3((n_total + 255) / 256), dim3(256), 0, s, segs, n_segs, groups, where ? kb : ka, where ? vb : va,
                        n_total, merged_list, merged_map);
+}
+
+void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks, uint32_t n_blocks, const uint2* remap, const uint32_t* old_list,
+                       const uint32_t* old_map, uint32_t* new_list, uint32_t* new_map)
+{
+    if (n_blocks) hipLaunchKernelGGL(k_mg_copy, dim3(n_blocks), dim3(256), 0, s, jobs, blocks, remap, old_list, old_map, new_list, new_map);
 }
 
 // `ranges` must be zero on entry (k_cull clears it each frame)

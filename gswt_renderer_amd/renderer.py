@@ -129,6 +129,12 @@ class GSWTRenderer:
         """The same from C arrays (WangTile.sort_tiles_raw): no per-draw Python work on the render thread."""
         self._check(self._lib.gswt_set_draws_merge_groups(self._h, draws_arr, n_draws, groups_arr, n_groups, members_arr, n_members))
 
+    def merge_stats(self):
+        """(merged groups sorted, merged groups copied from the previous sort event) since the ctx was created."""
+        out = (C.c_ulonglong * 2)()
+        self._check(self._lib.gswt_debug_merge_stats(self._h, out))
+        return int(out[0]), int(out[1])
+
     def read_merged(self):
         n = C.c_size_t(0)
         self._check(self._lib.gswt_debug_read_merged(self._h, None, None, 0, C.byref(n)))

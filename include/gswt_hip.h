@@ -172,7 +172,9 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
        GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 512) */,
        GSWT_OPT_DEBUG_FLAGS = 4 /* ablation bits for profiling; output is wrong when nonzero */,
        GSWT_OPT_TIMING = 5 /* hipEvent timing: 0 none, 1 frame + k_composite, 2 every stage (default) */,
-       GSWT_OPT_PAIR_CAP = 6 /* test hook: pin the pair-buffer capacity to `value` pairs until a frame overflows it (0: automatic) */ };
+       GSWT_OPT_PAIR_CAP = 6 /* test hook: pin the pair-buffer capacity to `value` pairs until a frame overflows it (0: automatic) */,
+       GSWT_OPT_NO_MERGE_REUSE = 7 /* gswt_set_draws_merge_groups re-sorts every merged group at every sort event instead of copying
+                                      the groups that did not change since the previous one (results are identical) */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data
@@ -350,6 +352,9 @@ GSWT_API int gswt_debug_read_projected(gswt_ctx *ctx, void *out, size_t capacity
  * overflow flag} (64-bit) and the exclusive pair prefix per super-group (u32).  Host pointers. */
 GSWT_API int gswt_debug_totals(gswt_ctx *ctx, const uint32_t *pair_sums, const uint32_t *visible_sums, uint32_t n_super,
                                uint32_t pair_cap, unsigned long long counters_out[4], uint32_t *super_excl_out);
+
+/* Merged groups sorted / copied from the previous sort event by gswt_set_draws_merge_groups since gswt_create. */
+GSWT_API int gswt_debug_merge_stats(const gswt_ctx *ctx, unsigned long long out[2]);
 
 /* Test / profiling hook: [start, end) of every screen tile in the sorted pair list of the last
  * gswt_render (2 u32 per tile, shard-local tile order). Host pointer. */

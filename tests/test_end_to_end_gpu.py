@@ -348,3 +348,34 @@ def test_column_bands_follow_a_moving_camera(renderer):
         assert np.array_equal(img, full), k
         assert full[..., 3].max() > 0.2
     assert shifted >= 2
+
+
+def test_merged_group_reuse_across_sort_events(renderer):
+    """gswt_set_draws_merge_groups copies the merged groups that did not change since the previous sort event (the reference's
+    LRU hit, wangtile.rs:575-593) instead of re-sorting them: along a camera path the device lists and the images must equal
+    the ones built with every group re-sorted, entry for entry, and some groups must actually have been reused."""
+    from gswt_renderer_amd import _lib as L
+    cfg = dict(tile_map_half_wh=(4, 4), surface_type=0, lod_max_dist=22.0, tile_sort_type=3, merge_type=2, merge_topk=40)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=900)
+    W, Hh = 320, 200
+    path = [((4.2 + 0.35 * k, 1.0 + 0.5 * k, 1.5), (5.0 + 0.3 * k, 4.0 + 0.55 * k, 1.0)) for k in range(9)]
+    results = {}
+    for reuse in (False, True):
+        renderer.set_option(L.GSWT_OPT_NO_MERGE_REUSE, 0 if reuse else 1)
+        pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer, device_merge=True)
+        built0, reused0 = renderer.merge_stats()
+        out = []
+        for pos, tgt in path:
+            cu, vp = host.camera_uniforms(pos, tgt, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
+            pipe.update(pos, vp, force_sort=True)
+            img = pipe.render(cu, W, Hh)
+            lst, mp = renderer.read_merged()
+            out.append((img, lst.copy(), mp.copy()))
+        built, reused = renderer.merge_stats()
+        results[reuse] = (out, built - built0, reused - reused0)
+    renderer.set_option(L.GSWT_OPT_NO_MERGE_REUSE, 0)
+    assert results[False][2] == 0 and results[True][2] > 0                       # groups were reused
+    assert results[True][1] + results[True][2] == results[False][1]              # ... instead of being sorted
+    for (img_a, l_a, m_a), (img_b, l_b, m_b) in zip(results[False][0], results[True][0]):
+        assert np.array_equal(l_a, l_b) and np.array_equal(m_a, m_b)
+        assert np.array_equal(img_a, img_b)
