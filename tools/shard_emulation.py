@@ -10,7 +10,9 @@ import bench
 from gswt_renderer_amd.renderer import GSWTRenderer
 from gswt_renderer_amd import _lib as L
 
-w, wang, cu, vp, sort = bench.build_workload(sys.argv[1] if len(sys.argv) > 1 else "c3")
+name = sys.argv[1] if len(sys.argv) > 1 else "c3"
+n_frames = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+w, wang, cu, vp, sort = bench.build_workload(name)
 W, H = w["width"], w["height"]
 su = wang.scene_uniforms()
 r = GSWTRenderer(0)
@@ -18,7 +20,10 @@ r.set_option(L.GSWT_OPT_TIMING, 0)
 wang.upload_to(r)
 r.configure(None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
-for mode, N in [("rows", 1), ("rows", 2), ("rows", 4), ("rows", 8), ("cols", 2), ("cols", 4), ("cols", 8)]:
+configs = [("rows", 1), ("rows", 2), ("rows", 4), ("rows", 8), ("cols", 2), ("cols", 4), ("cols", 8)]
+if name == "c5":
+    configs = [("rows", 1), ("rows", 8), ("cols", 2), ("cols", 4), ("cols", 8)]
+for mode, N in configs:
     rows = r.shard_rows_padded(H, N) if (N > 1 and mode == "rows") else H
     cols = r.shard_cols_padded(W, N) if (N > 1 and mode == "cols") else W
     outs = [torch.empty((rows, cols, 4), dtype=torch.float32, device="cuda") for _ in range(r.frame_slots())]
@@ -38,7 +43,7 @@ for mode, N in [("rows", 1), ("rows", 2), ("rows", 4), ("rows", 8), ("cols", 2),
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
         run(10)
-        worst = max(worst, run(100))
+        worst = max(worst, run(n_frames))
         vis.append(r.timings()["n_visible"])
     print(f"{mode} N={N}: slowest rank {worst * 1e6:.0f} us/frame -> <= {1.0 / worst:.0f} frames/s before the all-gather "
           f"({rows * cols * 16 / 1e6:.1f} MB per rank; visible splats per rank {min(vis)}..{max(vis)})", flush=True)
