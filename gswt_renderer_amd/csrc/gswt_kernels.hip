@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ key
 //             sequence F4 and blends under predication; a wave whose ballot of "T >= eps" is empty stops
 // ------------------------------------------------------------------------------------
 // Work items: a tile's pair list is cut into segments of `seg` pairs; item = (tile, segment).
-// seg_count[t] = max(1, ceil(len / seg)) so empty tiles still get one item (they write the background).
+// seg_count[t] = ceil(len / seg): a tile without pairs has no item (k_combine, which visits every tile anyway, writes its background).
 // item_base[t] = exclusive scan of seg_count, item_base[n_tiles] = number of items; item_tab[item] =
 // (tile, segment << 1 | tile has several segments, first pair, end pair): everything k_composite needs in one load.  Single workgroup (n_tiles is a few thousand to a few
 // tens of thousands): one launch instead of count + 3 scan launches.
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
 #pragma unroll
             for (int j = 0; j < kPer; j++) {
                 const uint32_t len = e[j].y - e[j].x;
-                part += len == 0 ? 1u : (seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg);
+                part += seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;
             }
         }
         const uint32_t pi = wave_incl_scan(part, lane);
@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
     for (int j = 0; j < kPer; j++) {
         const uint32_t len = r[j].y - r[j].x;
         const uint32_t q = seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;   // (a 32-bit divide is ~40 VALU)
-        cnt[j] = base + j * 1024 + (int)threadIdx.x < n_tiles ? (len == 0 ? 1u : q) : 0u;
+        cnt[j] = base + j * 1024 + (int)threadIdx.x < n_tiles ? q : 0u;
     }
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
@@ -1579,6 +1579,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     }
 }
 
+// Measured and dropped again in round 2 (the item STREAM: a resident grid of workgroups, each taking items b, b + G, b + 2G, ...
+// as single 256-pair batches with the next item's records and the one-after-next item's slot indices in flight while it bins
+// and walks the current one -- the batch pipeline above carried across items; bit-identical output): c3 120 us at 7 workgroups
+// per CU (72 VGPRs), 133 us at 8 (64 VGPRs, 20 spilled), 146 / 174 us at 4 per CU, against 96 us for one workgroup per item.
+// The phases of this kernel add up (round-2 ablations at c3: 15 us launch + output, 28 us record gathers, 2.5 us binning,
+// 50 us walk), but hiding the gathers behind another item's walk inside a workgroup is not what makes them overlap: the
+// dispatcher's dynamic hand-out of ~16 k short workgroups does that better than a static stride over them.
+
 // Folds the per-segment partials of multi-segment tiles: (C1,T1) o (C2,T2) = (C1 + T1*C2, T1*T2).
 // One workgroup per tile, same lane -> pixel mapping as k_composite.
 __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* __restrict__ item_base,
@@ -1591,7 +1599,7 @@ __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* 
     // separate 32-byte device-to-host copy, ~4 us of stream time and one more API call per frame)
     if (tile == 0 && threadIdx.x < 4u && host_counters) host_counters[threadIdx.x] = counters[threadIdx.x];
     const uint32_t i0 = item_base[tile], n_seg = item_base[tile + 1] - i0;
-    if (n_seg <= 1u) return;
+    if (n_seg == 1u) return;                      // the tile's only work item wrote the pixels itself; n_seg == 0: no pairs, background only
     const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
@@ -1806,7 +1814,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 #define GSWT_LAUNCH_COMPOSITE(E, D, C)                                                                                         \
     hipLaunchKernelGGL((k_composite<E, D, C>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
-    if (colf) {                       // debug draw modes: float colours from the side buffer
+        if (colf) {                       // debug draw modes: float colours from the side buffer
         if (depth) GSWT_LAUNCH_COMPOSITE(false, true, true);
         else GSWT_LAUNCH_COMPOSITE(false, false, true);
     }

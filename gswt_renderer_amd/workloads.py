@@ -37,10 +37,10 @@ WORKLOADS = {
                 user=dict(surface_type=host.SURFACE_HEIGHTMAP, height_map_scale=(1.0, 1.0, 0.25), tile_sort_type=host.SORT_GRAPH,
                           merge_type=host.MERGE_EDGE, lod_blending=True, lod_transition_width_ratio=0.05, merge_topk=100,
                           merge_dot_threshold=0.2, lod_max_dist=64.0 * 4.0)),
-    # c3 with 2.5 x larger splats (same counts, same cameras): ~6 x the footprint area, so that the pair count is what
+    # c3 with 4 x larger splats (same counts, same cameras): ~16 x the footprint area, so that the pair count is what
     # SURVEY 8(d) assumed for this configuration (P ~ 10 - 15 M); shows how the compositor scales with overdraw
-    "c3d": dict(desc="c3 with 2.5x larger Gaussians (dense overdraw): 33x33 map, ~10M instanced, 1920x1080",
-                half=(16, 16), lod0=9800, n_lod=3, width=1920, height=1080, base_scale=0.05,
+    "c3d": dict(desc="c3 with 4x larger Gaussians (dense overdraw): 33x33 map, ~10M instanced, 1920x1080",
+                half=(16, 16), lod0=9800, n_lod=3, width=1920, height=1080, base_scale=0.08,
                 user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
                           lod_blending=True, lod_transition_width_ratio=0.05, merge_topk=100, merge_dot_threshold=0.2,
                           lod_max_dist=64.0 * 4.0)),

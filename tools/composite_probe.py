@@ -21,7 +21,7 @@ r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lo
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
 ref = None
-for seg, flags in ((512, 0), (512, 1), (512, 2), (512, 4), (512, 2 + 32), (512, 2 + 64), (512, 2 + 96), (512, 32), (512, 64), (512, 96)):
+for seg, flags in ((512, 0), (256, 0), (1024, 0), (512, 1), (512, 2), (512, 4), (512, 2 + 32), (512, 2 + 64), (512, 2 + 96)):
     r.set_option(L.GSWT_OPT_SEGMENT, seg)
     r.set_option(L.GSWT_OPT_DEBUG_FLAGS, flags)
     ts = []
