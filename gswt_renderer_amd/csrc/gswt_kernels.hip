@@ -842,10 +842,23 @@ constexpr uint32_t kSortWideMax = 8u << 20;     // pair capacities up to this us
 // 256 x nblk/32 addresses).  k_radix_scatter derives its global offsets from those directly -- digit d's
 // base = sum of gtot[< d] + gsup[d][< blk >> 5] + ghist[d][same group, < blk] -- so no scan kernel runs.
 constexpr uint32_t kSupShift = 5;
+constexpr uint32_t kSupDirect = 32;             // up to this many groups the scatter kernel reads every group row instead of digit totals
+
+// Lanes of the wave that hold the same digit as this one (match-any on `nbits` bits), restricted to valid lanes.
+__device__ __forceinline__ unsigned long long match_digit(uint32_t dgt, bool valid, uint32_t nbits)
+{
+    unsigned long long peers = __ballot(valid);
+    for (uint32_t b = 0; b < nbits; b++) {
+        const bool bit = (dgt >> b) & 1u;
+        const unsigned long long m = __ballot(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
 
 template <int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
-                                                    uint32_t n_cap, uint32_t shift, uint32_t mask, uint32_t* __restrict__ ghist,
+                                                    uint32_t n_cap, uint32_t shift, uint32_t mask, uint32_t nbits, uint32_t* __restrict__ ghist,
                                                     uint32_t* __restrict__ gsup, uint32_t* __restrict__ gtot, uint32_t nblk,
                                                     uint32_t nsup)
 {
@@ -862,6 +875,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
         uint32_t key[kSortItems];
 #pragma unroll
         for (int k = 0; k < kSortItems; k++) key[k] = keys[min(base + (uint32_t)k * 64u + lane, n - 1u)];
+        // (one add per distinct digit of a round through match-any, as k_radix_scatter counts, was measured here: 12.1 us against
+        // 11.2 -- eight ballots per round cost this short kernel more than the same-address serialisation of the LDS adds)
 #pragma unroll
         for (int k = 0; k < kSortItems; k++)
             if (base + (uint32_t)k * 64u + lane < n) atomicAdd(&s_h[(key[k] >> shift) & mask], 1u);
@@ -873,11 +888,16 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
     ghist[blockIdx.x * 256u + threadIdx.x] = cnt;
     if (cnt) {
         atomicAdd(&gsup[(blockIdx.x >> kSupShift) * 256u + threadIdx.x], cnt);
-        atomicAdd(&gtot[threadIdx.x], cnt);
+        // digit totals: with few groups k_radix_scatter sums the group rows itself -- every workgroup adding to the same 256 words
+        // (650 adds per word at c3) is the most contended traffic of the sort
+        if (nsup > kSupDirect) atomicAdd(&gtot[threadIdx.x], cnt);
     }
-    (void)nblk; (void)nsup;
+    (void)nblk; (void)nbits;
 }
 
+// The block's 4096 items are first ranked INTO LDS (sorted by digit inside the block), then copied out: consecutive threads
+// write consecutive addresses of a digit's run instead of every lane storing two separate words to its own rank position
+// (a wave's store instruction used to touch as many regions as it held distinct digits).
 template <int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -890,11 +910,15 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     const uint32_t n = clamped_count(n_ptr, n_cap);
     if (blockIdx.x * kSortBlock >= n) return;
     __shared__ uint32_t s_h[kSortWaves][256];
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_g[256];                       // digit -> (global base of this block's run) - (its start inside the block)
+    __shared__ uint32_t s_w[4], s_w2[4];
+    __shared__ uint32_t s_gs[2][256];                   // direct group sums: [0] earlier groups, [1] all groups (waves 4..7 -> waves 0..3)
+    __shared__ uint2 s_kv[kSortBlock];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (int k = 0; k < kSortWaves * 256 / kSortThreads; k++) (&s_h[0][0])[k * kSortThreads + threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * kSortBlock + w * (64 * kSortItems);
+    const uint32_t blk0 = blockIdx.x * kSortBlock;
+    const uint32_t base = blk0 + w * (64 * kSortItems);
     uint32_t key[kSortItems], val[kSortItems];
     // every load of the workgroup is issued before anything is consumed: clamped indices instead of lane masks
     // (masked loads were waited for one by one: 16 + ~30 dependent round trips per wave, the whole 31 us of this kernel)
@@ -911,60 +935,110 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     const uint32_t sb = blockIdx.x >> kSupShift;
     uint32_t pre = 0, g_tot = 0;
     if (dig) {                                                                   // wave-uniform (waves 0..3)
-        g_tot = gtot[d];
         uint32_t t[32];
 #pragma unroll
         for (uint32_t u = 0; u < 32u; u++) {                                     // <= 31 earlier workgroups of this group
             const uint32_t j = (sb << kSupShift) + u;
             t[u] = ghist[min(j, nblk - 1u) * 256u + d];
         }
-        for (uint32_t j0 = 0; j0 < sb; j0 += 16u) {                              // earlier groups, 16 loads in flight
-            uint32_t g[16];
+        if (nsup <= kSupDirect && kSortThreads >= 512) {
+            // the group rows are summed by the upper half of the workgroup (below), which has no digit column of its own
+        } else if (nsup <= kSupDirect) {                                         // every group row at once: digit total + earlier groups
+            uint32_t g[kSupDirect];
 #pragma unroll
-            for (uint32_t u = 0; u < 16u; u++) g[u] = gsup[min(j0 + u, nsup - 1u) * 256u + d];
+            for (uint32_t u = 0; u < kSupDirect; u++) g[u] = gsup[min(u, nsup - 1u) * 256u + d];
 #pragma unroll
-            for (uint32_t u = 0; u < 16u; u++) if (j0 + u < sb) pre += g[u];
+            for (uint32_t u = 0; u < kSupDirect; u++) { if (u < nsup) g_tot += g[u]; if (u < sb) pre += g[u]; }
+        } else {
+            g_tot = gtot[d];
+            for (uint32_t j0 = 0; j0 < sb; j0 += 16u) {                          // earlier groups, 16 loads in flight
+                uint32_t g[16];
+#pragma unroll
+                for (uint32_t u = 0; u < 16u; u++) g[u] = gsup[min(j0 + u, nsup - 1u) * 256u + d];
+#pragma unroll
+                for (uint32_t u = 0; u < 16u; u++) if (j0 + u < sb) pre += g[u];
+            }
         }
 #pragma unroll
         for (uint32_t u = 0; u < 32u; u++) if ((sb << kSupShift) + u < blockIdx.x) pre += t[u];
-    }
+    } else if (nsup <= kSupDirect && kSortThreads >= 512 && threadIdx.x < 512u) {
+        uint32_t g[kSupDirect], ge = 0, ga = 0;
 #pragma unroll
-    for (int k = 0; k < kSortItems; k++)
-        if (base + (uint32_t)k * 64u + lane < n) atomicAdd(&s_h[w][(key[k] >> shift) & mask], 1u);
+        for (uint32_t u = 0; u < kSupDirect; u++) g[u] = gsup[min(u, nsup - 1u) * 256u + d];
+#pragma unroll
+        for (uint32_t u = 0; u < kSupDirect; u++) { if (u < nsup) ga += g[u]; if (u < sb) ge += g[u]; }
+        s_gs[0][d] = ge; s_gs[1][d] = ga;                                        // read by thread d after the next barrier
+    }
+    // per-wave digit counts: one LDS add per distinct digit of a 64-item round (see k_radix_hist); the peer masks are kept for
+    // the ranking below
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    constexpr bool kCachePeers = kSortItems <= 8;       // 16 rounds of masks would cost the 256-thread build a wave per SIMD
+    unsigned long long pm[kCachePeers ? kSortItems : 1];
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const bool valid = base + (uint32_t)k * 64u + lane < n;
+        const uint32_t dgt = (key[k] >> shift) & mask;
+        const unsigned long long peers = match_digit(dgt, valid, nbits);
+        if (kCachePeers) pm[k] = peers;
+        if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+    }
     {
-        // exclusive scan of the digit totals over the first 256 threads (the other waves only take part in the barriers)
+        // exclusive scans over the first 256 threads (the other waves only take part in the barriers): of the digit totals
+        // (global bases) and of this block's digit counts (positions inside the block)
+        const bool direct = nsup <= kSupDirect && kSortThreads >= 512;
+        if (direct) {                                                            // uniform
+            __syncthreads();
+            if (dig) { pre += s_gs[0][d]; g_tot = s_gs[1][d]; }
+        }
         uint32_t inc = wave_incl_scan(g_tot, lane);
         if (dig && lane == 63u) s_w[w] = inc;
         __syncthreads();                                                         // also: the LDS counts are complete
+        uint32_t cnt[kSortWaves], blk_cnt = 0;
         if (dig) {
-            uint32_t wb = 0;
-            for (uint32_t i = 0; i < w; i++) wb += s_w[i];
-            uint32_t b = wb + inc - g_tot + pre;
-            for (int k = 0; k < kSortWaves; k++) { uint32_t c = s_h[k][d]; s_h[k][d] = b; b += c; }      // per-wave bases
+#pragma unroll
+            for (int k = 0; k < kSortWaves; k++) { cnt[k] = s_h[k][d]; blk_cnt += cnt[k]; }
+        }
+        const uint32_t inc2 = wave_incl_scan(blk_cnt, lane);
+        if (dig && lane == 63u) s_w2[w] = inc2;
+        __syncthreads();
+        if (dig) {
+            uint32_t wb = 0, wb2 = 0;
+            for (uint32_t i = 0; i < w; i++) { wb += s_w[i]; wb2 += s_w2[i]; }
+            const uint32_t gbase = wb + inc - g_tot + pre;
+            uint32_t lb = wb2 + inc2 - blk_cnt;                                  // start of digit d inside the block
+            s_g[d] = gbase - lb;
+#pragma unroll
+            for (int k = 0; k < kSortWaves; k++) { s_h[k][d] = lb; lb += cnt[k]; }      // per-wave positions inside the block
         }
     }
     __syncthreads();
-    volatile uint32_t* h = s_h[w];
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    // Ranking, 64 items per round: match-any on the digit bits gives every lane its peers; the lowest peer takes the run's
+    // position with ONE returning LDS add and hands it to the others through a lane shuffle.  (Round 1 read the counter,
+    // fenced the wave, wrote it back and fenced again: two dependent LDS round trips per round that no other round could
+    // overlap; the adds of consecutive rounds are independent instructions.)
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
         uint32_t i = base + k * 64 + lane;
         bool valid = i < n;
         uint32_t dgt = valid ? ((key[k] >> shift) & mask) : 0u;
-        unsigned long long peers = __ballot(valid);
-        for (uint32_t b = 0; b < nbits; b++) {
-            bool bit = (dgt >> b) & 1u;
-            unsigned long long m = __ballot(valid && bit);
-            peers &= bit ? m : ~m;
-        }
-        if (valid) {
-            uint32_t rank = __popcll(peers & lt);
-            uint32_t pos = h[dgt];
-            __builtin_amdgcn_wave_barrier();
-            if (rank == 0) h[dgt] = pos + __popcll(peers);
-            __builtin_amdgcn_wave_barrier();
-            keys_out[pos + rank] = key[k];
-            vals_out[pos + rank] = val[k];
+        const unsigned long long peers = kCachePeers ? pm[kCachePeers ? k : 0] : match_digit(dgt, valid, nbits);
+        const uint32_t rank = __popcll(peers & lt);
+        uint32_t pos = 0;
+        if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+        const int leader = valid ? (int)__ffsll((long long)peers) - 1 : (int)lane;
+        pos = (uint32_t)__shfl((int)pos, leader, 64);
+        if (valid) s_kv[pos + rank] = make_uint2(key[k], val[k]);
+    }
+    __syncthreads();
+    const uint32_t n_blk = min((uint32_t)kSortBlock, n - blk0);
+#pragma unroll
+    for (int k = 0; k < kSortItems; k++) {
+        const uint32_t i = (uint32_t)k * kSortThreads + threadIdx.x;
+        if (i < n_blk) {
+            const uint2 kv = s_kv[i];
+            const uint32_t gp = s_g[(kv.x >> shift) & mask] + i;
+            keys_out[gp] = kv.x;
+            vals_out[gp] = kv.y;
         }
     }
 }
@@ -1275,7 +1349,8 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
 #ifdef GSWT_STATS
 __device__ unsigned long long g_stats[8];
 #define GSWT_STAT_STEP(C) { unsigned long long cm_ = __ballot(C); if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[0], 1ull); \
-    atomicAdd(&g_stats[1], (unsigned long long)__popcll(cm_)); if (cm_ == 0ull) atomicAdd(&g_stats[2], 1ull); } }
+    atomicAdd(&g_stats[1], (unsigned long long)__popcll(cm_)); if (cm_ == 0ull) atomicAdd(&g_stats[2], 1ull); \
+    unsigned z_ = 0; for (int q_ = 0; q_ < 4; q_++) if (((cm_ >> (16 * q_)) & 0xFFFFull) == 0ull) z_++; atomicAdd(&g_stats[6], (unsigned long long)z_); } }
 #define GSWT_STAT_BATCH(NMAX, C0, C1, C2, C3) { if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)(NMAX)); \
     atomicAdd(&g_stats[5], (unsigned long long)((C0) + (C1) + (C2) + (C3))); } }
 #else
@@ -1737,7 +1812,7 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
 #define GSWT_SORT_PASS(T)                                                                                                        \
-        hipLaunchKernelGGL(k_radix_hist<T>, dim3(nblk), dim3(T), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, ghist, gsup, gtot, nblk, nsup); \
+        hipLaunchKernelGGL(k_radix_hist<T>, dim3(nblk), dim3(T), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup); \
         hipLaunchKernelGGL(k_radix_scatter<T>, dim3(nblk), dim3(T), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
                            ghist, gsup, gtot, nblk, nsup)
         if (threads == 512) { GSWT_SORT_PASS(512); }
