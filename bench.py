@@ -144,6 +144,8 @@ class Worker:
         self._wake = threading.Event()
         self._req = None
         self._res = None
+        self._fifo = []
+        self._done = {}
         self._stop = False
         self._prev_vp = None
         self.build_ms, self.sort_ms = [], []
@@ -154,6 +156,25 @@ class Worker:
         with self._lock:
             self._req = (pos, vp)
         self._wake.set()
+
+    # -- lock-step mode (N > 1): every rank must swap the SAME SortData in at the SAME frame, or the gathered bands come from
+    # different draw lists (and tile maps: spawning consumes the worker's RNG in the order of its build events).  The ranks
+    # therefore hand the worker every `every`-th camera IN ORDER and apply its result a fixed number of frames later, waiting
+    # for it if need be -- deterministic on every rank, unlike "newest camera wins".
+    def submit_ordered(self, tag, pos, vp):
+        with self._lock:
+            self._fifo.append((tag, pos, vp))
+        self._wake.set()
+
+    def take(self, tag, timeout=30.0):
+        t_end = time.perf_counter() + timeout
+        while True:
+            with self._lock:
+                if tag in self._done:
+                    return self._done.pop(tag)
+            if time.perf_counter() > t_end:
+                raise RuntimeError(f"worker result {tag} did not arrive")
+            time.sleep(2e-5)
 
     def poll(self):
         with self._lock:
@@ -188,6 +209,14 @@ class Worker:
             self._wake.clear()
             if self._stop:
                 return
+            while True:
+                with self._lock:
+                    job = self._fifo.pop(0) if self._fifo else None
+                if job is None:
+                    break
+                res = self.step(job[1], job[2])
+                with self._lock:
+                    self._done[job[0]] = res
             with self._lock:
                 req, self._req = self._req, None
             if req is None:
@@ -294,10 +323,15 @@ def main():
     # slot, so keeping fewer frames in flight also keeps fewer buffer sets in rotation.
     r.render_wait(r.render_async(cu0, su0, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, shard=shard))
     per_slot_bytes = 60.0 * float(r.timings()["n_instanced"])           # rects + records per list entry, roughly
+    # three frames in flight on a static camera (a fourth costs 6 %: four buffer sets in rotation), four on the fly path (the
+    # fourth covers the bubble a SortData swap-in leaves in the frame stream: +5 %)
+    slots_static = min(slots, 3)
     if args.in_flight > 0:
-        slots = max(1, min(slots, args.in_flight))
+        slots = slots_static = max(1, min(slots, args.in_flight))
     elif per_slot_bytes > 2e9:
-        slots = min(slots, 2)
+        slots = slots_static = min(slots, 2)
+    elif args.mode == "static":
+        slots = slots_static
     gathered = torch.empty((world * rows, band_w, 4), dtype=torch.float32, device=dev) if use_dist else None
     frame = torch.empty((H, W, 4), dtype=torch.float32, device=dev) if use_dist else None
 
@@ -329,7 +363,7 @@ def main():
     else:
         cams = [(tuple(cam0["pos"]), cu0, vp0)]
 
-    state = {"su": su0, "swaps": 0, "swap_ms": []}
+    state = {"su": su0, "swaps": 0, "swap_ms": [], "slots": slots}
     stats = {"comp_ms": [], "pairs": [], "stage": [], "submit_ms": []}
     inflight = []
 
@@ -344,6 +378,7 @@ def main():
     def submit(i, cu, timed):
         # the frame runs on its slot's own stream (the frames in flight overlap on the GPU); the all-gather of frame i is
         # queued on the ctx stream behind a fence, AFTER frame i+1 has been submitted
+        slots = state["slots"]
         o = outs[i % slots]
         bgp = dpp = 0
         t0 = time.perf_counter()
@@ -379,10 +414,19 @@ def main():
             stats["stage"].append(t)
 
     def run(n, worker, first=0):
+        slots = state["slots"]
         for k in range(n):
             i = first + k
             pos, cu, vp = cams[i % len(cams)]
-            if worker is not None:
+            if worker is not None and lockstep:
+                # N > 1: every 4th camera goes to the worker in order; its SortData is swapped in four frames later on every rank
+                if i % 4 == 0:
+                    worker.submit_ordered(i, pos, vp)
+                if i % 4 == 0 and i >= 4 + first_tag[0]:
+                    res = worker.take(i - 4)
+                    if res is not None:
+                        swap_in(res)
+            elif worker is not None:
                 worker.submit(pos, vp)             # state.rs:323-334: camera to the worker, newest wins
                 res = worker.poll()
                 if res is not None:
@@ -393,6 +437,9 @@ def main():
         while inflight:
             collect()
         stream.synchronize()
+
+    lockstep = world > 1            # (also with GSWT_BENCH_FAKE_WORLD)
+    first_tag = [0]
 
     def timed_run(n, worker, warm):
         run(warm, worker)
@@ -489,9 +536,10 @@ def main():
             wang.build_tiles(pos_s); res = (wang.sort_tiles_raw(pos_s, vp_s), wang.scene_uniforms())
         swap_in(res)
         cams_save, cams = cams, [(pos_s, cu_s, vp_s)]
+        state["slots"] = slots_static
         dts = timed_run(args.static_steps, None, 30)
         static = {"value": args.static_steps / dts, "unit": "frames/s", "steps": args.static_steps, "n_pairs": int(np.mean(stats["pairs"])),
-                  "k_composite_ms": float(np.mean(stats["comp_ms"])) if stats["comp_ms"] else None,
+                  "k_composite_ms": float(np.mean(stats["comp_ms"])) if stats["comp_ms"] else None, "frames_in_flight": slots_static,
                   "note": "one camera (the workload's own), resident draw list, no worker, no swap-ins: what round 1 reported as value"}
         cams = cams_save
     if dist:

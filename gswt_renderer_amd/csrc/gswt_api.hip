@@ -99,14 +99,17 @@ struct HostBuf {
 
 }  // namespace
 
-// Three frame slots: c3 4 220 (two) -> 4 600 frames/s (three); four slots are SLOWER (4 190, also with three in flight: the
-// frames then rotate over four sets of per-frame buffers and the working set outgrows the Infinity Cache).
-constexpr int kFrameSlots = 3;
+// Frame slots.  Round 1: c3 4 220 (two in flight) -> 4 600 frames/s (three); a fourth was SLOWER on a static camera (the frames then
+// rotate over four sets of per-frame buffers and the working set outgrows the Infinity Cache).  Round 2: with sort events in the
+// frame stream a fourth frame in flight covers the bubble a swap-in leaves (fly path 3 570 -> 3 770 frames/s) while it still costs
+// a static camera 6 % (4 476 -> 4 214), so the library offers four and the caller decides how many it keeps in flight:
+// gswt_render_async takes the lowest free slot, unused slots cost nothing.
+constexpr int kFrameSlots = 4;
 
 // The per-sort-event state (GSWTRenderer's swap-in of a SortData, state.rs:361-376): draw descriptors, chunk tables, merged
 // lists, band-cull bounds.  Double-buffered: gswt_set_draws* fills the set that is NOT current while the frames in flight
 // keep reading the one they were submitted with, so a sort event does not drain the frame pipeline.
-constexpr int kDrawSets = 4;     // frames in flight + 1: the set being refilled is never one a frame in flight still reads
+constexpr int kDrawSets = kFrameSlots + 1;     // frames in flight + 1: the set being refilled is never one a frame in flight still reads
 template <typename T>
 struct Ref { T* p = nullptr; };
 

@@ -240,7 +240,7 @@ GSWT_API int gswt_render(gswt_ctx *ctx, const gswt_camera_uniforms *camera,
  * display refresh; with the device library the next frame can be queued while the previous one is still
  * executing).  All pointers are DEVICE pointers.  gswt_render_async enqueues the frame and returns a
  * ticket; gswt_render_wait(ticket) blocks the host until it finished, re-runs it if the pair buffers had
- * to grow, and makes gswt_last_timings refer to it.  At most gswt_frame_slots() (= 3) frames may be in
+ * to grow, and makes gswt_last_timings refer to it.  At most gswt_frame_slots() (= 4) frames may be in
  * flight (enqueuing one more waits for the oldest).  Each frame in flight runs on its own internal stream
  * with its own per-frame buffers, so the frames OVERLAP on the GPU; frames in flight together must write
  * different output buffers.  Ordering against the ctx stream (gswt_set_stream):
