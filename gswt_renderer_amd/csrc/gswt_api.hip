@@ -26,7 +26,8 @@
 #include <vector>
 
 namespace gswt {
-void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t);
+void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t,
+                 uint32_t*, uint2*);
 void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
@@ -37,7 +38,7 @@ void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uin
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, uint32_t, const uint32_t*, const uint32_t*,
-                    const uint32_t*, const uint4*, const float*, const uint32_t*, const uint32_t*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
+                    const uint32_t*, const uint4*, const float*, const uint32_t*, const uint32_t*, uint32_t*, const uint2*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
                     unsigned long long*, Varyings*, float4*, uint32_t);
 void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
@@ -199,6 +200,8 @@ struct FrameSlot {
     // per-frame HBM buffers
     DevBuf<uint2> rects;
     DevBuf<Rec> recs;
+    DevBuf<uint2> live_tab;                // this frame's launch table of k_project: the chunks of the draws that survive k_cull
+    DevBuf<uint32_t> live_cnt;             // entries per XCD list of live_tab (8 words; zero between frames)
     DevBuf<uint32_t> cell_culled;          // column-band shards: per map cell, 1 = no splat of that tile instance can reach the band
     DevBuf<uint32_t> block_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
     DevBuf<uint2> ranges;
@@ -210,7 +213,7 @@ struct FrameSlot {
     DevBuf<float> depths;                  // per-slot depth: frames with a proxy depth buffer or GSWT_ORDER_DEPTH only
     void release_buffers()
     {
-        rects.release(); recs.release(); cell_culled.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
+        rects.release(); recs.release(); cell_culled.release(); live_tab.release(); live_cnt.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
         keys_b.release(); vals_a.release(); vals_b.release(); ghist.release(); ranges.release(); item_base.release();
         depth_ws.release(); partials.release(); item_tab.release(); col_f.release(); depths.release();
     }
@@ -970,6 +973,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         HIP_TRY(c, sl.rects.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.block_sums.ensure((size_t)D.n_chunks + 1));
+        HIP_TRY(c, sl.live_tab.ensure((size_t)D.n_launch + 8));
+        if (!sl.live_cnt.p) { HIP_TRY(c, sl.live_cnt.ensure(8)); HIP_TRY(c, hipMemset(sl.live_cnt.p, 0, sl.live_cnt.cap * 4)); }
         HIP_TRY(c, sl.draw_culled.ensure((size_t)D.n_draws + 1));
         if (su->draw_mode != 0u) HIP_TRY(c, sl.col_f.ensure(n_slots_all + 1));
         if (a.d_bgd || cfg->order_mode == GSWT_ORDER_DEPTH) HIP_TRY(c, sl.depths.ensure(n_slots_all + 1));
@@ -1074,9 +1079,9 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     const uint32_t n_cells = f.band_cull ? (2u * su->map_half_wh[0] + 1u) * (2u * su->map_half_wh[1] + 1u) : 0u;
     HIP_TRY(c, sl.cell_culled.ensure((size_t)n_cells + 1));
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)(16 + n_super2 + radix_words),
-                reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u);
+                reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
-                   c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
+                   c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p, sl.col_f.p, cap);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
     // ---- emit

@@ -253,14 +253,20 @@ __device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], c
 __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __restrict__ draws, uint32_t n_draws,
                                               uint32_t* __restrict__ draw_culled, uint32_t* __restrict__ cell_culled, uint32_t n_cells,
                                               uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
-                                              uint32_t* __restrict__ zero_b, uint32_t n_zero_b)
+                                              uint32_t* __restrict__ zero_b, uint32_t n_zero_b,
+                                              uint32_t* __restrict__ zero_c, uint32_t n_zero_c,
+                                              uint32_t* __restrict__ live_cnt, uint2* __restrict__ live_tab)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    for (uint32_t j = i; j < n_zero_a; j += gridDim.x * 256u) zero_a[j] = 0u;
-    for (uint32_t j = i; j < n_zero_b; j += gridDim.x * 256u) zero_b[j] = 0u;
+    // eight lanes per draw: all of them evaluate the (cheap) cull, lane 0 of the eight keeps the flag and allocates the draw's range
+    // of the live-chunk table, and the eight fill it together (a merged group has up to a few hundred chunks)
+    const uint32_t gtid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = gtid >> 3, sub = gtid & 7u;
+    for (uint32_t j = gtid; j < n_zero_a; j += gridDim.x * 256u) zero_a[j] = 0u;
+    for (uint32_t j = gtid; j < n_zero_b; j += gridDim.x * 256u) zero_b[j] = 0u;
+    for (uint32_t j = gtid; j < n_zero_c; j += gridDim.x * 256u) zero_c[j] = 0u;       // per-chunk pair counts: culled chunks never run
     if (f.band_cull) {
         uint32_t map_wh_y = 2u * f.map_half_wh[1] + 1u;                      // plain surface only (band_cull is off otherwise)
-        for (uint32_t j = i; j < n_cells; j += gridDim.x * 256u) {
+        for (uint32_t j = gtid; j < n_cells; j += gridDim.x * 256u) {
             // the merged-member offset of gswt.wgsl:52-63, same expression as k_project
             const float ox = (float)((int32_t)(j / map_wh_y - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
             const float oy = (float)((int32_t)(j % map_wh_y - f.map_half_wh[1]) + f.center_coord[1]) * f.tile_width;
@@ -268,8 +274,8 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
             cell_culled[j] = band_misses(f, lo, hi) ? 1u : 0u;
         }
     }
-    if (i >= n_draws) return;
-    const DrawDev& d = draws[i];
+    const bool have = i < n_draws;
+    const DrawDev& d = draws[have ? i : 0u];
     uint32_t culled = 0;
     if (d.cull_enable) {
         float mx = 3.402823466e+38f, my = 3.402823466e+38f, mz = -3.402823466e+38f;
@@ -295,7 +301,17 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
         const float hi[3] = {f.loc_hi[0] + d.off[0], f.loc_hi[1] + d.off[1], f.loc_hi[2] + d.off[2]};
         if (band_misses(f, lo, hi)) culled = 1;
     }
-    draw_culled[i] = culled;
+    if (have && sub == 0u) draw_culled[i] = culled;
+    // Launch table of k_project for THIS frame: only the chunks of surviving draws, in the per-XCD layout of chunk_tab_xcd
+    // (position k * 8 + x runs on XCD x = draw % 8).  The workgroups of culled chunks used to learn that they are culled from
+    // three dependent loads each (chunk table -> draw record -> cull flag): 21 k of c3's 39 k chunks, 290 k of c5's 366 k.
+    // The order inside an XCD's list is the order of the atomic adds: irrelevant, a chunk's output slots are fixed.
+    const bool live = have && !culled && d.count != 0u;
+    const uint32_t nch = live ? (d.count + (uint32_t)kChunk - 1u) / (uint32_t)kChunk : 0u, x = i & 7u;
+    uint32_t pos = 0;
+    if (live && sub == 0u) pos = atomicAdd(&live_cnt[x], nch);
+    pos = (uint32_t)__shfl((int)pos, (int)((threadIdx.x & 63u) & ~7u), 64);           // from lane 0 of this draw's eight
+    for (uint32_t k = sub; k < nch; k += 8u) live_tab[(size_t)(pos + k) * 8u + x] = make_uint2(i, k * (uint32_t)kChunk);
 }
 
 // ------------------------------------------------------------------------------------
@@ -319,7 +335,8 @@ __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
-    const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, const uint32_t* __restrict__ cell_culled, uint2* __restrict__ rects,
+    const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, const uint32_t* __restrict__ cell_culled,
+    const uint32_t* __restrict__ live_cnt, const uint2* __restrict__ live_tab, uint2* __restrict__ rects,
     Rec* __restrict__ recs, float* __restrict__ depths, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
     Varyings* __restrict__ dbg, float4* __restrict__ col_f)
 {
@@ -327,16 +344,20 @@ __global__ __launch_bounds__(256) void k_project(
     // chunk_tab is in LAUNCH order, which is not slot order: workgroup b runs on XCD b % 8, and the table is laid out so
     // that all chunks of a draw land on one XCD (draw % 8) -- a draw's gathers stay inside one tile type's 313 KB of the
     // record table, so an XCD's 4 MB L2 then holds the few tile types it is working on instead of all 48 (6.6 MB).
-    const uint2 ct = chunk_tab[blockIdx.x];
-    if (ct.y == 0xFFFFFFFFu) return;        // padding of a short per-XCD list
+    // The normal frame launches over k_cull's table of live chunks (same layout, culled draws left out; workgroups past an XCD's
+    // live count exit after one cached scalar load); the debug-varyings build visits every chunk through the static table.
+    uint2 ct;
+    if (DEBUG) {
+        ct = chunk_tab[blockIdx.x];
+        if (ct.y == 0xFFFFFFFFu) return;    // padding of a short per-XCD list
+    } else {
+        if ((blockIdx.x >> 3) >= live_cnt[blockIdx.x & 7u]) return;
+        ct = live_tab[blockIdx.x];
+    }
     const DrawDev& d = draws[ct.x];
     const uint32_t tid = threadIdx.x;
     const uint32_t cid = (d.slot_base + ct.y) >> 8;      // chunk id in slot space
-    const bool s_culled = draw_culled[ct.x] != 0u;
-    if (s_culled && !DEBUG) {               // nothing to project: the chunk contributes no pairs
-        if (tid == 0) block_sums[cid] = 0u;
-        return;
-    }
+    const bool s_culled = DEBUG ? draw_culled[ct.x] != 0u : false;
 
     const uint32_t r = ct.y + tid;
     const uint32_t slot = d.slot_base + r;
@@ -634,8 +655,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 // (c5: 1 430 per workgroup).  Single workgroup.  (Folding it into k_emit -- every workgroup sums the super-group counts
 // in front of it, workgroup 0 leaves the totals -- was measured: k_emit +6 us for the 4.6 us saved, 4015 -> 3881 frames/s.)
 __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ super_sums, uint32_t n_super,
-                                                unsigned long long* __restrict__ counters, uint32_t* __restrict__ super_excl, uint32_t pair_cap)
+                                                unsigned long long* __restrict__ counters, uint32_t* __restrict__ super_excl, uint32_t pair_cap,
+                                                uint32_t* __restrict__ live_cnt)
 {
+    // k_project is done with this frame's live-chunk counts: cleared here for the slot's next frame (k_cull both clears
+    // buffers and adds to these counters, so it cannot clear them itself)
+    if (live_cnt && threadIdx.x < 8u) live_cnt[threadIdx.x] = 0u;
     __shared__ unsigned long long s_v[4];
     __shared__ uint32_t s_w[4];
     unsigned long long v = 0;
@@ -1734,16 +1759,17 @@ void launch_chunk_tabs(hipStream_t s, const DrawDev* draws, const uint32_t* xcd_
 }
 
 void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, uint32_t* cell_culled, uint32_t n_cells,
-                 uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b)
+                 uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b, uint32_t* zero_c, uint32_t n_zero_c,
+                 uint32_t* live_cnt, uint2* live_tab)
 {
-    uint32_t grid = (n_draws + 255) / 256;
+    uint32_t grid = (n_draws * 8u + 255u) / 256u;          // eight lanes per draw
     if (grid < 32) grid = 32;
-    hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b);
+    hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, live_cnt, live_tab);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
-                    const float* hmap, const uint32_t* draw_culled, const uint32_t* cell_culled, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
+                    const float* hmap, const uint32_t* draw_culled, const uint32_t* cell_culled, uint32_t* live_cnt, const uint2* live_tab, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
                     uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap)
 {
     if (n_chunks == 0) return;
@@ -1751,13 +1777,13 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
 #define GSWT_LAUNCH_PROJECT(D, F)                                                                                              \
     hipLaunchKernelGGL((k_project<D, F>), dim3(n_launch), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,        \
-                       merged_map, tex, hmap, draw_culled, cell_culled, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f)
+                       merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f)
     if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
     else if (debug) { GSWT_LAUNCH_PROJECT(true, false); }
     else if (full) { GSWT_LAUNCH_PROJECT(false, true); }
     else { GSWT_LAUNCH_PROJECT(false, false); }
 #undef GSWT_LAUNCH_PROJECT
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, live_cnt);
 }
 
 // exclusive scan of `n` u32 in `data` -> `out` (may alias), total -> *total_out.
@@ -1905,7 +1931,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 // k_totals alone on caller-provided sums (unit test of the 64-bit pair count)
 void launch_totals(hipStream_t s, uint32_t* super_sums, uint32_t n_super, unsigned long long* counters, uint32_t pair_cap)
 {
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, (uint32_t*)nullptr);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded, int band_px)
