@@ -443,6 +443,9 @@ void gswt_destroy(gswt_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     sync_all(c);
+    for (gswt_ctx* m : std::vector<gswt_ctx*>(c->group))       // leave a peer-copy group before the memory goes away
+        if (m && m != c) m->group.clear();
+    c->group.clear();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->ev_push) hipEventDestroy(c->ev_push);
     c->gather_buf.release();
@@ -1407,7 +1410,12 @@ try {
     hipSetDevice(c->device);
     HIP_TRY(c, collect_pending(c));
     if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; c->comm_world = 0; }
+    // a peer-copy group is dissolved as a whole: no member keeps a pointer to a context that may be destroyed next
+    const std::vector<gswt_ctx*> members = c->group;
+    for (gswt_ctx* m : members)
+        if (m && m != c) { hipSetDevice(m->device); collect_pending(m); m->group.clear(); }
     c->group.clear();
+    hipSetDevice(c->device);
     return GSWT_OK;
 } GSWT_CATCH("gswt_comm_destroy")
 
