@@ -302,13 +302,27 @@ def main():
     # set-up) falls back to torch.distributed.all_gather_into_tensor + gswt_unshard_mode.
     abi_comm = False
     if use_dist and dist is not None and os.environ.get("GSWT_BENCH_TORCH_GATHER") != "1":
-        try:
-            box = [GSWTRenderer.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            r.comm_init(box[0], rank, world)
-            abi_comm = True
-        except Exception as e:      # noqa: BLE001 - reported in the JSON line
-            print(f"[bench] communicator behind the ABI unavailable ({e}); using torch.distributed for the gather", file=sys.stderr)
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = GSWTRenderer.comm_unique_id()
+            except Exception as e:      # noqa: BLE001 - every rank learns it through the broadcast below and falls back together
+                print(f"[bench] RCCL id unavailable ({e}); using torch.distributed for the gather", file=sys.stderr)
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is not None:
+            ok = torch.ones(1, dtype=torch.int32, device=dev)
+            try:
+                r.comm_init(box[0], rank, world)
+            except Exception as e:      # noqa: BLE001
+                ok.zero_()
+                print(f"[bench] rank {rank}: gswt_comm_init failed ({e})", file=sys.stderr)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)           # all ranks use the ABI's gather, or none does
+            abi_comm = bool(ok.item())
+            if not abi_comm:
+                try:
+                    r.comm_destroy()
+                except Exception:       # noqa: BLE001
+                    pass
     if fake_world > 1 and world == 1:
         world, use_dist = fake_world, True
     shard = (rank, world, "cols") if world > 1 else (0, 1)
