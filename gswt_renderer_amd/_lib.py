@@ -91,6 +91,48 @@ class Timings(C.Structure):
                 ("_pad", C.c_uint32), ("ms_composite_kernel", C.c_float), ("_pad2", C.c_float)]
 
 
+class SortedTile(C.Structure):
+    _fields_ = [("lod", C.c_uint32), ("tile", C.c_uint32), ("view_id", C.c_uint32), ("tile_offset", C.c_float * 3),
+                ("map_index", C.c_uint32), ("map_coord", C.c_uint32 * 2), ("tile_center", C.c_float * 3),
+                ("transition", C.c_int32), ("spawning_factor", C.c_float), ("has_corners", C.c_uint32),
+                ("corners", C.c_float * 12), ("key_len", C.c_uint32), ("merged", C.c_uint32),
+                ("merged_offset", C.c_uint32), ("merged_count", C.c_uint32), ("single_lod_id", C.c_int32),
+                ("cache_hit", C.c_uint32), ("merged_group", C.c_uint32)]
+
+
+class SortDataC(C.Structure):
+    _fields_ = [("scene_id", C.c_uint32), ("n_tiles", C.c_uint32), ("tiles", C.POINTER(SortedTile)),
+                ("n_merged", C.c_size_t), ("merged_gs_index", C.c_void_p), ("merged_map_id", C.c_void_p),
+                ("merged_lod_id", C.c_void_p), ("n_groups", C.c_uint32), ("n_members", C.c_uint32),
+                ("groups", C.c_void_p), ("members", C.c_void_p)]
+
+
+class Cell(C.Structure):
+    """gswt_cell: one map cell as update_tile_map leaves it (structure.rs:495-509)."""
+    _fields_ = [("tile", C.c_uint32), ("has_corner", C.c_uint32), ("tile_offset", C.c_float * 3), ("tile_center", C.c_float * 3),
+                ("to_local", C.c_float * 9), ("corner_pos", C.c_float * 12), ("corner_up", C.c_float * 12),
+                ("edge_pos", C.c_float * 12), ("edge_normal", C.c_float * 12)]
+
+
+class CellState(C.Structure):
+    _fields_ = [("lod", C.c_uint32), ("transition", C.c_int32), ("spawning_factor", C.c_float), ("merge", C.c_uint32),
+                ("merged_to", C.c_uint32)]
+
+
+class WorkerConfig(C.Structure):
+    _fields_ = [("map_w", C.c_uint32), ("map_h", C.c_uint32), ("half_w", C.c_uint32), ("half_h", C.c_uint32),
+                ("n_lod", C.c_uint32), ("n_tile", C.c_uint32), ("n_view", C.c_uint32), ("tile_width", C.c_float),
+                ("surface_type", C.c_uint32), ("tile_sort_type", C.c_uint32), ("merge_type", C.c_uint32),
+                ("height_map_scale", C.c_float * 3), ("sphere_radius", C.c_float), ("lod_blending", C.c_uint32),
+                ("lod_bbox_check", C.c_uint32), ("lod_transition_width_ratio", C.c_float), ("lod_dist_tolerance", C.c_float),
+                ("merge_tile_dist", C.c_int32 * 2), ("merge_dot_threshold", C.c_float), ("merge_topk", C.c_uint32),
+                ("hm_w", C.c_uint32), ("hm_h", C.c_uint32), ("height_map", C.c_void_p), ("lod_transition_dist", C.c_void_p),
+                ("tile_center", C.c_void_p), ("tile_aabb", C.c_void_p), ("splat_count", C.c_void_p), ("presort_dirs", C.c_void_p),
+                ("neighbors", C.c_void_p)]
+
+
+assert C.sizeof(Cell) == 260 and C.sizeof(CellState) == 20
+
 assert C.sizeof(CameraUniforms) == 176 and C.sizeof(SceneUniforms) == 160 and C.sizeof(TileUniforms) == 80
 
 # every symbol include/gswt_hip.h declares: name -> (restype, argtypes)
@@ -136,6 +178,15 @@ SYMBOLS = {
     "gswt_render_gather": (C.c_int, [_P, C.c_int, _P]),
     "gswt_group_init": (C.c_int, [_P, C.c_int]),
     "gswt_group_render_gather": (C.c_int, [_P, _P, _P, C.c_int]),
+    "gswt_worker_create": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "gswt_worker_destroy": (None, [_P]),
+    "gswt_worker_last_error": (C.c_char_p, [_P]),
+    "gswt_worker_set_cells": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "gswt_worker_update_lod": (C.c_int, [_P, _P]),
+    "gswt_worker_sort_tiles": (C.c_int, [_P, _P, _P]),
+    "gswt_worker_read_cell_state": (C.c_int, [_P, _P, C.c_size_t]),
+    "gswt_worker_read_sort": (C.c_int, [_P, _P]),
+    "gswt_set_draws_from_worker": (C.c_int, [_P, _P]),
     "gswt_synchronize": (C.c_int, [_P]),
     "gswt_last_timings": (C.c_int, [_P, _P]),
     "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),

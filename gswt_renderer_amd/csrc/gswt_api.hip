@@ -411,6 +411,10 @@ static void collect_set(gswt_ctx* c, int set)
         }
 }
 
+namespace gswt {
+int ctx_device(const gswt_ctx* c) { return c->device; }     // gswt_worker.hip: the worker lives on its ctx's device
+}
+
 extern "C" {
 
 int gswt_create(int device_id, gswt_ctx** out)

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "gswt_math.h"
+#include "gswt_surface.h"
 
 using namespace gswt_host;
 
@@ -526,6 +527,9 @@ struct gswt_wang {
     bool device_merge = false;
     std::vector<const int32_t*> rd_ptrs;
     std::vector<uint32_t> rd_counts, rd_offsets;
+    std::vector<float> wk_center, wk_aabb, wk_dirs;          // flat tables of gswt_wang_worker_config
+    std::vector<uint32_t> wk_counts;
+    std::vector<int32_t> wk_nb;
 
     TileBaseData& tb(size_t l, size_t t, size_t v) { return base[(l * n_tile + t) * n_view + v]; }
     const TileBaseData& tb(size_t l, size_t t, size_t v) const { return base[(l * n_tile + t) * n_view + v]; }
@@ -543,6 +547,18 @@ struct gswt_wang {
 };
 
 namespace {
+
+SurfaceParams surface_params(const gswt_wang& w)
+{
+    SurfaceParams p;
+    p.map_w = w.map_w; p.map_h = w.map_h; p.half_w = (int)w.user.tile_map_half_wh[0]; p.half_h = (int)w.user.tile_map_half_wh[1];
+    p.center_x = w.center_x; p.center_y = w.center_y;
+    p.tile_width = w.user.tile_width; p.surface_type = (int)w.user.surface_type;
+    for (int k = 0; k < 3; k++) p.hm_scale[k] = w.user.height_map_scale[k];
+    p.sphere_radius = w.user.sphere_radius;
+    p.height_map = w.height_map.empty() ? nullptr : w.height_map.data(); p.hm_w = w.hm_w; p.hm_h = w.hm_h;
+    return p;
+}
 
 // ---- WangTile::preprocess, wangtile.rs:71-255 ---------------------------------------------
 int preprocess(gswt_wang& w)
@@ -689,12 +705,6 @@ void compute_map_neighbors(const gswt_wang& w, int x, int y, Neighbor out[4])
 }
 
 // ---- height map helpers, wangtile.rs:1220-1349 ---------------------------------------------
-float hm_texel(const std::vector<float>& hm, int width, int height, long x, long y)
-{
-    long xi = ((x % width) + width) % width, yi = ((y % height) + height) % height;
-    return hm[(size_t)yi * width + xi];
-}
-
 void cubic_weight(float t, float wgt[4])
 {
     wgt[0] = ((-0.5f * t + 1.0f) * t - 0.5f) * t;
@@ -718,7 +728,7 @@ std::vector<float> map_resize(const std::vector<float>& src, int fw, int fh, int
             float result = 0.0f;
             for (int jj = 0; jj < 4; jj++)
                 for (int ii = 0; ii < 4; ii++) {
-                    float val = hm_texel(src, fw, fh, x0 + ii - 1, y0 + jj - 1);
+                    float val = hm_texel(src.data(), fw, fh, x0 + ii - 1, y0 + jj - 1);
                     result += val * wx[ii] * wy[jj];
                 }
             out[(size_t)j * tw + i] = result;
@@ -726,128 +736,9 @@ std::vector<float> map_resize(const std::vector<float>& src, int fw, int fh, int
     return out;
 }
 
-void map_fetch_bilinear_aux(const gswt_wang& w, float u, float v, float dt, float res[5])
-{
-    const int width = w.hm_w, height = w.hm_h;
-    float x = u * (float)width - 0.5f, y = v * (float)height - 0.5f;
-    float dx = dt * (float)width, dy = dt * (float)height;
-    long x0 = (long)std::floor(x), y0 = (long)std::floor(y);
-    float tx = x - (float)x0, ty = y - (float)y0;
-    float i00 = hm_texel(w.height_map, width, height, x0, y0), i10 = hm_texel(w.height_map, width, height, x0 + 1, y0);
-    float i01 = hm_texel(w.height_map, width, height, x0, y0 + 1), i11 = hm_texel(w.height_map, width, height, x0 + 1, y0 + 1);
-    auto bil = [&](float ax, float ay) {
-        float i0 = i00 * (1.0f - ax) + i10 * ax;
-        float i1 = i01 * (1.0f - ax) + i11 * ax;
-        return i0 * (1.0f - ay) + i1 * ay;
-    };
-    res[0] = bil(tx, ty);
-    res[1] = bil(tx + dx, ty);
-    res[2] = bil(tx - dx, ty);
-    res[3] = bil(tx, ty + dy);
-    res[4] = bil(tx, ty - dy);
-}
-
-// Canonical sin / cos: Rust's f32::sin / cos are platform libm calls, so their last bits are
-// unpinnable; the host uses the one sequence the device kernels use (k = rint(x 2/pi), three-term Cody-Waite with
-// fmaf, Cephes minimax polynomials), so tile centres / corners agree with the GPU's sphere mapping.
-void csincosf(float x, float& sn, float& cs)
-{
-    const float kf = std::rint(x * 0.636619772367581343f);
-    float r = std::fmaf(kf, -1.5703125f, x);
-    r = std::fmaf(kf, -4.837512969970703125e-4f, r);
-    r = std::fmaf(kf, -7.54978995489188216e-8f, r);
-    const float z = r * r;
-    float ps = std::fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
-    ps = std::fmaf(ps, z, -1.6666654611e-1f);
-    const float s = std::fmaf(ps * z, r, r);
-    float pc = std::fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
-    pc = std::fmaf(pc, z, 4.166664568298827e-2f);
-    const float c = std::fmaf(pc * z, z, std::fmaf(-0.5f, z, 1.0f));
-    const int q = (int)kf & 3;
-    float so = (q & 1) ? c : s, co = (q & 1) ? s : c;
-    if (q == 2 || q == 3) so = -so;
-    if (q == 1 || q == 2) co = -co;
-    sn = so; cs = co;
-}
-
-// get_uv + uv_to_pos closures of surface_mapping, wangtile.rs:1410-1461
-V3 sphere_point(float block_w, float bidx, float bidy, float bx, float by)
-{
-    const float PI = 3.14159265358979323846f;
-    float u, v;
-    if (bidy == 0.0f) {
-        if (by < bx) {
-            if (bx - by == block_w) u = 0.0f;
-            else u = (by / (block_w - (bx - by)) + bidx) / 5.0f;
-            v = ((block_w - (bx - by)) / block_w) / 3.0f;
-        } else {
-            u = (bx / block_w + bidx) / 5.0f + ((by - bx) / block_w) * 0.1f;
-            v = ((by - bx) / block_w) / 3.0f + (1.0f / 3.0f);
-        }
-    } else {
-        if (by < bx) {
-            u = (bx / block_w + bidx) / 5.0f + ((block_w - (bx - by)) / block_w) * 0.1f;
-            v = ((block_w - (bx - by)) / block_w) / 3.0f + (1.0f / 3.0f);
-        } else {
-            if (by - bx == block_w) u = 0.0f;
-            else u = (bx / (block_w - (by - bx)) + bidx) / 5.0f + 0.1f;
-            v = ((by - bx) / block_w) / 3.0f + (2.0f / 3.0f);
-        }
-    }
-    u = u + 0.5f * std::floor(v);
-    u = u * (2.0f * PI);
-    v = (v - 0.5f) * PI;
-    float su, cu, sv, cv;
-    csincosf(u, su, cu);
-    csincosf(v, sv, cv);
-    return V3{cv * cu, cv * su, sv};
-}
-
-// ---- WangTile::surface_mapping, wangtile.rs:1352-1494 --------------------------------------
 void surface_mapping(const gswt_wang& w, int mcx, int mcy, V3 pos, bool to_world, V3& new_pos, M3& transform)
 {
-    new_pos = pos;
-    transform = M3{};
-    const float DELTA = 0.001f;
-    const float tw = w.user.tile_width;
-    if (w.user.surface_type == SURFACE_SPHERE) {
-        const float xmax = (float)w.map_w * tw, ymax = (float)w.map_h * tw;
-        const float block_w = xmax / 5.0f;
-        int c0x, c0y;
-        w.map_to_coord(0, 0, c0x, c0y);
-        new_pos = new_pos - w.coord_to_pos(c0x, c0y);
-        const float bidx = (float)(5 * mcx / w.map_w), bidy = (float)(2 * mcy / w.map_h);
-        const float bx = new_pos.x - bidx * block_w, by = new_pos.y - bidy * block_w;
-        const V3 lz = sphere_point(block_w, bidx, bidy, bx, by);
-        const float r = w.user.sphere_radius;
-        new_pos = lz * r;
-        const float dt = DELTA * ymax;
-        const V3 pr = sphere_point(block_w, bidx, bidy, bx + dt, by) * r;
-        const V3 pl = sphere_point(block_w, bidx, bidy, bx - dt, by) * r;
-        const V3 pu = sphere_point(block_w, bidx, bidy, bx, by + dt) * r;
-        const V3 pd = sphere_point(block_w, bidx, bidy, bx, by - dt) * r;
-        const V3 lx = (pr - pl) / (2.0f * dt), ly = (pu - pd) / (2.0f * dt);
-        M3 l2w = from_cols(lx, ly, lz);
-        new_pos = new_pos + l2w * V3{0.0f, 0.0f, pos.z};
-        transform = to_world ? l2w : invert(l2w);
-        return;
-    }
-    if (w.user.surface_type != SURFACE_HEIGHTMAP) return;
-    float xr = ((float)w.map_w * tw) * w.user.height_map_scale[0];
-    float yr = ((float)w.map_h * tw) * w.user.height_map_scale[1];
-    float u = (pos.x + (float)w.user.tile_map_half_wh[0] * tw) / xr;
-    float v = (pos.y + (float)w.user.tile_map_half_wh[1] * tw) / yr;
-    float hv[5];
-    map_fetch_bilinear_aux(w, u, v, DELTA, hv);
-    const float hz = w.user.height_map_scale[2];
-    new_pos.z = hv[0] * hz;
-    float h_r = hv[1] * hz, h_l = hv[2] * hz, h_u = hv[3] * hz, h_d = hv[4] * hz;
-    V3 lx{1.0f, 0.0f, (h_r - h_l) / ((2.0f * DELTA) * xr)};
-    V3 ly{0.0f, 1.0f, (h_u - h_d) / ((2.0f * DELTA) * yr)};
-    V3 lz = normalize(cross(lx, ly));
-    M3 l2w = from_cols(lx, ly, lz);
-    new_pos = new_pos + l2w * V3{0.0f, 0.0f, pos.z};
-    transform = to_world ? l2w : invert(l2w);
+    surface_mapping(surface_params(w), mcx, mcy, pos, to_world, new_pos, transform);
 }
 
 // ---- compute_corner_edge, wangtile.rs:1609-1669 -------------------------------------------
@@ -1698,6 +1589,87 @@ try {
     *ptrs = w->rd_ptrs.data(); *counts = w->rd_counts.data(); *merge_offset = w->rd_offsets.data();
     return GSWT_OK;
 } GSWT_CATCH("gswt_wang_raw_depth_tables")
+
+int gswt_wang_worker_config(gswt_wang* w, gswt_worker_config* out)
+try {
+    if (!w || !out) return fail(GSWT_ERR_BAD_ARG, "gswt_wang_worker_config: null argument");
+    if (w->map_w == 0) return fail(GSWT_ERR_STATE, "gswt_wang_worker_config before configure");
+    memset(out, 0, sizeof(*out));
+    const gswt_user_data& u = w->user;
+    out->map_w = (uint32_t)w->map_w; out->map_h = (uint32_t)w->map_h;
+    out->half_w = u.tile_map_half_wh[0]; out->half_h = u.tile_map_half_wh[1];
+    out->n_lod = (uint32_t)w->n_lod; out->n_tile = (uint32_t)w->n_tile; out->n_view = (uint32_t)w->presort_dirs.size();
+    out->tile_width = u.tile_width;
+    out->surface_type = u.surface_type; out->tile_sort_type = u.tile_sort_type; out->merge_type = u.merge_type;
+    for (int k = 0; k < 3; k++) out->height_map_scale[k] = u.height_map_scale[k];
+    out->sphere_radius = u.sphere_radius;
+    out->lod_blending = u.lod_blending; out->lod_bbox_check = u.lod_bbox_check;
+    out->lod_transition_width_ratio = u.lod_transition_width_ratio; out->lod_dist_tolerance = u.lod_dist_tolerance;
+    out->merge_tile_dist[0] = u.merge_tile_dist[0]; out->merge_tile_dist[1] = u.merge_tile_dist[1];
+    out->merge_dot_threshold = u.merge_dot_threshold; out->merge_topk = u.merge_topk;
+    out->hm_w = (uint32_t)w->hm_w; out->hm_h = (uint32_t)w->hm_h;
+    out->height_map = w->height_map.empty() ? nullptr : w->height_map.data();
+    out->lod_transition_dist = w->lod_transition_dist.data();
+    w->wk_center.clear(); w->wk_aabb.clear(); w->wk_dirs.clear(); w->wk_counts.clear(); w->wk_nb.clear();
+    for (size_t t = 0; t < w->n_tile; t++) {
+        const V3 c = w->tile_center[t], lo = w->aabb_lo[t], hi = w->aabb_hi[t];
+        w->wk_center.insert(w->wk_center.end(), {c.x, c.y, c.z});
+        w->wk_aabb.insert(w->wk_aabb.end(), {lo.x, lo.y, lo.z, hi.x, hi.y, hi.z});
+    }
+    for (size_t l = 0; l < w->n_lod; l++)
+        for (size_t t = 0; t < w->n_tile; t++) w->wk_counts.push_back((uint32_t)w->tb(l, t, 0).raw_depth.size());
+    for (const V3& d : w->presort_dirs) w->wk_dirs.insert(w->wk_dirs.end(), {d.x, d.y, d.z});
+    for (int x = 0; x < w->map_w; x++)
+        for (int y = 0; y < w->map_h; y++)
+            for (int s = 0; s < 4; s++) {
+                const Neighbor& n = w->nb(x, y, s);
+                w->wk_nb.push_back(n.some ? (int32_t)((w->map_to_index(n.x, n.y) << 2) | (size_t)n.slot) : -1);
+            }
+    out->tile_center = w->wk_center.data(); out->tile_aabb = w->wk_aabb.data(); out->splat_count = w->wk_counts.data();
+    out->presort_dirs = w->wk_dirs.data(); out->neighbors = w->wk_nb.data();
+    return GSWT_OK;
+} GSWT_CATCH("gswt_wang_worker_config")
+
+int gswt_wang_export_cells(const gswt_wang* w, gswt_cell* out, size_t cap, int32_t center_coord[2])
+try {
+    if (!w || !out) return fail(GSWT_ERR_BAD_ARG, "gswt_wang_export_cells: null argument");
+    const size_t n = (size_t)w->map_w * w->map_h;
+    if (cap < n) return fail(GSWT_ERR_CAPACITY, "need %zu cells", n);
+    for (size_t i = 0; i < n; i++) {
+        const TileInstance* t = w->tile_map[i].get();
+        if (!t) return fail(GSWT_ERR_STATE, "tile map not built");
+        gswt_cell& c = out[i];
+        memset(&c, 0, sizeof(c));
+        c.tile = (uint32_t)t->tile; c.has_corner = t->has_corner ? 1u : 0u;
+        c.tile_offset[0] = t->tile_offset.x; c.tile_offset[1] = t->tile_offset.y; c.tile_offset[2] = t->tile_offset.z;
+        c.tile_center[0] = t->tile_center.x; c.tile_center[1] = t->tile_center.y; c.tile_center[2] = t->tile_center.z;
+        memcpy(c.to_local, t->to_local.m, sizeof(c.to_local));
+        if (t->has_corner)
+            for (int k = 0; k < 4; k++) {
+                const V3 up = t->corner[k].to_world.col(2);
+                c.corner_pos[3 * k] = t->corner[k].pos.x; c.corner_pos[3 * k + 1] = t->corner[k].pos.y; c.corner_pos[3 * k + 2] = t->corner[k].pos.z;
+                c.corner_up[3 * k] = up.x; c.corner_up[3 * k + 1] = up.y; c.corner_up[3 * k + 2] = up.z;
+                c.edge_pos[3 * k] = t->edge[k].pos.x; c.edge_pos[3 * k + 1] = t->edge[k].pos.y; c.edge_pos[3 * k + 2] = t->edge[k].pos.z;
+                c.edge_normal[3 * k] = t->edge[k].normal.x; c.edge_normal[3 * k + 1] = t->edge[k].normal.y; c.edge_normal[3 * k + 2] = t->edge[k].normal.z;
+            }
+    }
+    if (center_coord) { center_coord[0] = w->center_x; center_coord[1] = w->center_y; }
+    return GSWT_OK;
+} GSWT_CATCH("gswt_wang_export_cells")
+
+int gswt_wang_export_cell_state(const gswt_wang* w, gswt_cell_state* out, size_t cap)
+try {
+    if (!w || !out) return fail(GSWT_ERR_BAD_ARG, "gswt_wang_export_cell_state: null argument");
+    const size_t n = (size_t)w->map_w * w->map_h;
+    if (cap < n) return fail(GSWT_ERR_CAPACITY, "need %zu cells", n);
+    for (size_t i = 0; i < n; i++) {
+        const TileInstance* t = w->tile_map[i].get();
+        if (!t) return fail(GSWT_ERR_STATE, "tile map not built");
+        out[i].lod = (uint32_t)t->lod; out[i].transition = t->transition; out[i].spawning_factor = t->spawning;
+        out[i].merge = (uint32_t)t->merge; out[i].merged_to = t->merge == MS_TO ? (uint32_t)t->merged_to : 0u;
+    }
+    return GSWT_OK;
+} GSWT_CATCH("gswt_wang_export_cell_state")
 
 int gswt_wang_get_tile_ids(const gswt_wang* w, uint32_t* ids, size_t cap)
 try {

@@ -1,6 +1,11 @@
 // gswt_math.h -- f32 vector / matrix helpers with cgmath 0.18's operand order.
 // One rounding per operator (build with -ffp-contract=off); column-major matrices.
 #pragma once
+// GSWT_HD: empty for g++ (libgswt_host); gswt_worker.hip defines it as __host__ __device__ so the device-side worker stages
+// run the very same operator sequences.
+#ifndef GSWT_HD
+#define GSWT_HD
+#endif
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -10,26 +15,26 @@ namespace gswt_host {
 struct V3 {
     float x = 0, y = 0, z = 0;
 };
-inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
-inline bool is_zero(V3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
-inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-inline float magnitude(V3 a) { return std::sqrt(dot(a, a)); }
-inline float distance2(V3 a, V3 b) { V3 d = b - a; return dot(d, d); }     // MetricSpace: (other - self).magnitude2()
-inline float distance(V3 a, V3 b) { return magnitude(b - a); }
-inline V3 normalize(V3 a) { return a * (1.0f / magnitude(a)); }            // InnerSpace::normalize
-inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+GSWT_HD inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+GSWT_HD inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+GSWT_HD inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+GSWT_HD inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+GSWT_HD inline bool is_zero(V3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+GSWT_HD inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+GSWT_HD inline float magnitude(V3 a) { return std::sqrt(dot(a, a)); }
+GSWT_HD inline float distance2(V3 a, V3 b) { V3 d = b - a; return dot(d, d); }     // MetricSpace: (other - self).magnitude2()
+GSWT_HD inline float distance(V3 a, V3 b) { return magnitude(b - a); }
+GSWT_HD inline V3 normalize(V3 a) { return a * (1.0f / magnitude(a)); }            // InnerSpace::normalize
+GSWT_HD inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
 struct M3 {
     float m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // [3*c + r]
-    V3 col(int c) const { return {m[3 * c], m[3 * c + 1], m[3 * c + 2]}; }
-    float at(int c, int r) const { return m[3 * c + r]; }
+    GSWT_HD V3 col(int c) const { return {m[3 * c], m[3 * c + 1], m[3 * c + 2]}; }
+    GSWT_HD float at(int c, int r) const { return m[3 * c + r]; }
 };
-inline M3 from_cols(V3 a, V3 b, V3 c) { M3 r; r.m[0] = a.x; r.m[1] = a.y; r.m[2] = a.z; r.m[3] = b.x; r.m[4] = b.y; r.m[5] = b.z; r.m[6] = c.x; r.m[7] = c.y; r.m[8] = c.z; return r; }
-inline V3 operator*(const M3& m, V3 v) { return (m.col(0) * v.x + m.col(1) * v.y) + m.col(2) * v.z; }
-inline M3 invert(const M3& m)    // cgmath Matrix3::invert (determinant nonzero assumed by the reference's unwrap)
+GSWT_HD inline M3 from_cols(V3 a, V3 b, V3 c) { M3 r; r.m[0] = a.x; r.m[1] = a.y; r.m[2] = a.z; r.m[3] = b.x; r.m[4] = b.y; r.m[5] = b.z; r.m[6] = c.x; r.m[7] = c.y; r.m[8] = c.z; return r; }
+GSWT_HD inline V3 operator*(const M3& m, V3 v) { return (m.col(0) * v.x + m.col(1) * v.y) + m.col(2) * v.z; }
+GSWT_HD inline M3 invert(const M3& m)    // cgmath Matrix3::invert (determinant nonzero assumed by the reference's unwrap)
 {
     V3 c0 = m.col(0), c1 = m.col(1), c2 = m.col(2);
     float det = (c0.x * (c1.y * c2.z - c2.y * c1.z) - c1.x * (c0.y * c2.z - c2.y * c0.z)) + c2.x * (c0.y * c1.z - c1.y * c0.z);
@@ -44,7 +49,7 @@ inline M3 invert(const M3& m)    // cgmath Matrix3::invert (determinant nonzero 
 struct Quat {
     float s = 0, x = 0, y = 0, z = 0;
 };
-inline Quat quat_from_mat3(const M3& m)     // cgmath From<Matrix3> for Quaternion
+GSWT_HD inline Quat quat_from_mat3(const M3& m)     // cgmath From<Matrix3> for Quaternion
 {
     float trace = (m.at(0, 0) + m.at(1, 1)) + m.at(2, 2);
     const float half = 0.5f;
@@ -80,7 +85,7 @@ inline Quat quat_from_mat3(const M3& m)     // cgmath From<Matrix3> for Quaterni
     }
     return q;
 }
-inline M3 mat3_from_quat(Quat q)            // cgmath From<Quaternion> for Matrix3
+GSWT_HD inline M3 mat3_from_quat(Quat q)            // cgmath From<Quaternion> for Matrix3
 {
     float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
     float xx2 = x2 * q.x, xy2 = x2 * q.y, xz2 = x2 * q.z;
@@ -94,7 +99,7 @@ inline M3 mat3_from_quat(Quat q)            // cgmath From<Quaternion> for Matri
 }
 
 // Matrix4 * Matrix4 and Matrix4 * (x, y, z, w), flat column-major [4*c + r]
-inline void mat4_mul(const float* a, const float* b, float* out)
+GSWT_HD inline void mat4_mul(const float* a, const float* b, float* out)
 {
     for (int c = 0; c < 4; c++)
         for (int r = 0; r < 4; r++) {
@@ -103,7 +108,7 @@ inline void mat4_mul(const float* a, const float* b, float* out)
             out[4 * c + r] = acc;
         }
 }
-inline void mat4_vec(const float* m, const float v[4], float out[4])
+GSWT_HD inline void mat4_vec(const float* m, const float v[4], float out[4])
 {
     for (int r = 0; r < 4; r++) {
         float acc = m[r] * v[0];
@@ -112,7 +117,7 @@ inline void mat4_vec(const float* m, const float v[4], float out[4])
     }
 }
 // cgmath::perspective; cot(fovy/2) evaluated in double and rounded once
-inline void perspective(float fovy_deg, float aspect, float near_, float far_, float* m)
+GSWT_HD inline void perspective(float fovy_deg, float aspect, float near_, float far_, float* m)
 {
     float fovy = fovy_deg * (float)(3.14159265358979323846 / 180.0);
     float f = (float)(1.0 / std::tan((double)fovy / 2.0));
@@ -124,7 +129,7 @@ inline void perspective(float fovy_deg, float aspect, float near_, float far_, f
     m[14] = (2.0f * far_ * near_) / (near_ - far_);
 }
 // Matrix4::look_at_rh -> look_to_rh(eye, center - eye, up)
-inline void look_at_rh(V3 eye, V3 center, V3 up, float* m)
+GSWT_HD inline void look_at_rh(V3 eye, V3 center, V3 up, float* m)
 {
     V3 f = normalize(center - eye);
     V3 s = normalize(cross(f, up));
@@ -136,14 +141,14 @@ inline void look_at_rh(V3 eye, V3 center, V3 up, float* m)
 }
 
 // Rust `as i32` / `as u8` on f32: saturating, NaN -> 0
-inline int32_t rust_as_i32(float v)
+GSWT_HD inline int32_t rust_as_i32(float v)
 {
     if (v != v) return 0;
     if (v >= 2147483648.0f) return INT32_MAX;
     if (v <= -2147483648.0f) return INT32_MIN;
     return (int32_t)v;
 }
-inline uint8_t rust_as_u8(float v)
+GSWT_HD inline uint8_t rust_as_u8(float v)
 {
     if (v != v) return 0;
     if (v <= 0.0f) return 0;

@@ -83,20 +83,8 @@ class SceneData(C.Structure):
                 ("lod_instance_count", C.c_uint64 * 16)]
 
 
-class SortedTile(C.Structure):
-    _fields_ = [("lod", C.c_uint32), ("tile", C.c_uint32), ("view_id", C.c_uint32), ("tile_offset", C.c_float * 3),
-                ("map_index", C.c_uint32), ("map_coord", C.c_uint32 * 2), ("tile_center", C.c_float * 3),
-                ("transition", C.c_int32), ("spawning_factor", C.c_float), ("has_corners", C.c_uint32),
-                ("corners", C.c_float * 12), ("key_len", C.c_uint32), ("merged", C.c_uint32),
-                ("merged_offset", C.c_uint32), ("merged_count", C.c_uint32), ("single_lod_id", C.c_int32),
-                ("cache_hit", C.c_uint32), ("merged_group", C.c_uint32)]
-
-
-class SortDataC(C.Structure):
-    _fields_ = [("scene_id", C.c_uint32), ("n_tiles", C.c_uint32), ("tiles", C.POINTER(SortedTile)),
-                ("n_merged", C.c_size_t), ("merged_gs_index", C.c_void_p), ("merged_map_id", C.c_void_p),
-                ("merged_lod_id", C.c_void_p), ("n_groups", C.c_uint32), ("n_members", C.c_uint32),
-                ("groups", C.c_void_p), ("members", C.c_void_p)]
+SortedTile = L.SortedTile        # SortData records live in gswt_hip.h: the device-side worker stages produce them too
+SortDataC = L.SortDataC
 
 
 class Preload(C.Structure):
@@ -134,6 +122,9 @@ HOST_SYMBOLS = {
     "gswt_wang_sort_tiles": (C.c_int, [_P, _P, _P, _P]),
     "gswt_wang_set_device_merge": (C.c_int, [_P, C.c_int]),
     "gswt_wang_raw_depth_tables": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "gswt_wang_worker_config": (C.c_int, [_P, _P]),
+    "gswt_wang_export_cells": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "gswt_wang_export_cell_state": (C.c_int, [_P, _P, C.c_size_t]),
     "gswt_wang_get_tile_ids": (C.c_int, [_P, _P, C.c_size_t]),
     "gswt_wang_set_tile_ids": (C.c_int, [_P, _P, C.c_size_t]),
     "gswt_renderer_build_draws": (C.c_int, [_P, _P]),
@@ -416,6 +407,27 @@ class WangTile:
             return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(sd.n_merged,)).copy()
         return SortData(tiles, arr(sd.merged_gs_index), arr(sd.merged_map_id), arr(sd.merged_lod_id),
                         [draws[i] for i in range(sd.n_tiles)], groups, members)
+
+    # -- hand-over to the device-side worker stages (gswt_worker_* of libgswt_hip) -------------
+    def worker_config(self) -> L.WorkerConfig:
+        cfg = L.WorkerConfig()
+        _check(self._lib.gswt_wang_worker_config(self._h, C.byref(cfg)))
+        return cfg
+
+    def export_cells(self):
+        """-> (gswt_cell C array, n, center_coord int32[2]) of the map build_tiles left."""
+        n = self.conf.tile_map_wh[0] * self.conf.tile_map_wh[1]
+        cells = (L.Cell * n)()
+        cc = (C.c_int32 * 2)()
+        _check(self._lib.gswt_wang_export_cells(self._h, cells, n, cc))
+        return cells, n, cc
+
+    def export_cell_state(self) -> np.ndarray:
+        """Per cell (lod, transition, spawning bits, merge, merged_to) as a [n, 5] uint32 array (floats as bit patterns)."""
+        n = self.conf.tile_map_wh[0] * self.conf.tile_map_wh[1]
+        st = (L.CellState * n)()
+        _check(self._lib.gswt_wang_export_cell_state(self._h, st, n))
+        return np.frombuffer(bytes(st), dtype=np.uint32).reshape(n, 5).copy()
 
     def sort_tiles_raw(self, cam_pos, view_proj):
         """sort_tiles + gswt_renderer_build_draws without per-tile Python objects (the worker thread of a frame loop calls

@@ -339,6 +339,112 @@ GSWT_API int gswt_render_gather(gswt_ctx *ctx, int ticket, float *frame_out_dev)
 GSWT_API int gswt_group_init(gswt_ctx *const *ctxs, int n);          /* rank r = ctxs[r]; undone by gswt_comm_destroy on each */
 GSWT_API int gswt_group_render_gather(gswt_ctx *const *ctxs, const int *tickets, float *const *frames_out_dev, int n);
 
+
+/* ---- SortData: what one sort event hands from the worker to the renderer --------------- */
+/* One element of SortData.tile_instance_vec + render_data_vec (structure.rs:488-509,670-694). */
+typedef struct {
+    uint32_t lod, tile, view_id;      /* tid.0, tid.1, view_id                                   */
+    float tile_offset[3];
+    uint32_t map_index;
+    uint32_t map_coord[2];
+    float tile_center[3];
+    int32_t transition;               /* 0 None, 1 Spawning, 2 Changing(false), 3 Changing(true)   */
+    float spawning_factor;
+    uint32_t has_corners;
+    float corners[12];                /* corner_data[ci].0                                        */
+    uint32_t key_len;                 /* render_data_key.tid.len()                                */
+    uint32_t merged;                  /* Some(render_data_value)                                  */
+    uint32_t merged_offset;           /* into the concatenated merged arrays of gswt_sort_data    */
+    uint32_t merged_count;
+    int32_t single_lod_id;
+    uint32_t cache_hit;               /* value came from the LRU cache (wangtile.rs:575-593)      */
+    uint32_t merged_group;            /* index into gswt_sort_data.groups when merged               */
+} gswt_sorted_tile;
+
+typedef struct {
+    uint32_t scene_id;
+    uint32_t n_tiles;
+    const gswt_sorted_tile *tiles;    /* back-to-front */
+    size_t n_merged;
+    const uint32_t *merged_gs_index, *merged_map_id, *merged_lod_id;   /* NULL in device-merge mode */
+    /* group descriptions for gswt_set_draws_merge_groups (always filled) */
+    uint32_t n_groups, n_members;
+    const gswt_merge_group *groups;
+    const gswt_merge_member *members;
+} gswt_sort_data;
+
+
+/* ---- Device-side worker stages: update_lod, selective merging, the four tile orders and the presort-view
+ * choice of WangTile (wangtile.rs:476-690,720-1218,1496-1607) as HIP kernels.  The tile MAP itself (update_tile_map,
+ * :1671-1781: map shift, tile ids from the RNG, centres / corners / edges through surface_mapping) stays in libgswt_host and
+ * is handed over once per build event as gswt_cell[]; every per-sort-event stage then runs on the device and leaves a
+ * gswt_sort_data (device-merge form: group descriptions, no CPU lists) that is byte-identical to gswt_wang_sort_tiles'. */
+
+/* One map cell, TileInstance as update_tile_map leaves it (structure.rs:495-509); index = x * map_h + y. */
+typedef struct {
+    uint32_t tile;             /* tid.1 */
+    uint32_t has_corner;
+    float tile_offset[3];
+    float tile_center[3];
+    float to_local[9];         /* column-major Matrix3 */
+    float corner_pos[12];      /* corner_data[ci].0 */
+    float corner_up[12];       /* corner_data[ci].1 column 2 (surface normal at the corner) */
+    float edge_pos[12];        /* edge_data[ei].0 */
+    float edge_normal[12];     /* edge_data[ei].1 */
+} gswt_cell;                   /* 260 bytes */
+
+/* Per-cell results of update_lod and of selective merging (the TileInstance fields those stages write). */
+typedef struct {
+    uint32_t lod;
+    int32_t transition;        /* 0 None, 1 Spawning, 2 Changing(false), 3 Changing(true) */
+    float spawning_factor;
+    uint32_t merge;            /* 0 None, 1 MergedFrom (group head), 2 MergedTo */
+    uint32_t merged_to;        /* map index of the head when merge == 2 */
+} gswt_cell_state;
+
+/* UserData fields the stages read plus the tables preprocess / configure leave behind.  Filled by
+ * gswt_wang_worker_config (pointers borrowed from the gswt_wang); gswt_worker_create copies everything to the device. */
+typedef struct {
+    uint32_t map_w, map_h, half_w, half_h;
+    uint32_t n_lod, n_tile, n_view;
+    float tile_width;
+    uint32_t surface_type, tile_sort_type, merge_type;
+    float height_map_scale[3];
+    float sphere_radius;
+    uint32_t lod_blending, lod_bbox_check;
+    float lod_transition_width_ratio, lod_dist_tolerance;
+    int32_t merge_tile_dist[2];
+    float merge_dot_threshold;
+    uint32_t merge_topk;
+    uint32_t hm_w, hm_h;
+    const float *height_map;          /* hm_w * hm_h, or NULL */
+    const float *lod_transition_dist; /* n_lod */
+    const float *tile_center;         /* n_tile * 3 */
+    const float *tile_aabb;           /* n_tile * 6: lo.xyz, hi.xyz */
+    const uint32_t *splat_count;      /* n_lod * n_tile: raw_depth lengths */
+    const float *presort_dirs;        /* n_view * 3 */
+    const int32_t *neighbors;         /* map_w * map_h * 4 slots (W, N, E, S): neighbour map index << 2 | its slot for us, or -1 */
+} gswt_worker_config;
+
+typedef struct gswt_worker gswt_worker;
+/* Lives on ctx's device with a stream of its own (the reference's worker is a thread of its own, state.rs:478-561). */
+GSWT_API int gswt_worker_create(gswt_ctx *ctx, const gswt_worker_config *cfg, gswt_worker **out);
+GSWT_API void gswt_worker_destroy(gswt_worker *w);
+GSWT_API const char *gswt_worker_last_error(const gswt_worker *w);
+/* After every build event on the host (update_tile_map): the whole map and its centre coordinate. */
+GSWT_API int gswt_worker_set_cells(gswt_worker *w, const gswt_cell *cells, size_t n_cells, const int32_t center_coord[2]);
+/* update_lod (wangtile.rs:1496-1607): LOD, transition status and spawning factor of every cell. */
+GSWT_API int gswt_worker_update_lod(gswt_worker *w, const float cam_pos[3]);
+/* sort_tiles (wangtile.rs:476-690): merge, order, views, records.  Enqueued on the worker's stream. */
+GSWT_API int gswt_worker_sort_tiles(gswt_worker *w, const float cam_pos[3], const float view_proj16[16]);
+/* Results to host memory (blocking on the worker's stream).  read_sort: pointers into worker-owned pinned memory, valid
+ * until the next gswt_worker_sort_tiles. */
+GSWT_API int gswt_worker_read_cell_state(gswt_worker *w, gswt_cell_state *out, size_t capacity);
+GSWT_API int gswt_worker_read_sort(gswt_worker *w, gswt_sort_data *out);
+/* Swap-in (state.rs:521-540 + renderer.rs:466-591 host half): TileUniforms / list selection per record on the device, then
+ * gswt_set_draws_merge_groups' planning from the compact record array.  ctx must be the worker's ctx. */
+GSWT_API int gswt_set_draws_from_worker(gswt_ctx *ctx, gswt_worker *w);
+
 GSWT_API int gswt_synchronize(gswt_ctx *ctx);
 GSWT_API int gswt_last_timings(const gswt_ctx *ctx, gswt_timings *out);
 

@@ -109,37 +109,8 @@ typedef struct {
     uint64_t lod_instance_count[16];
 } gswt_scene_data;
 
-/* One element of SortData.tile_instance_vec + render_data_vec (structure.rs:488-509,670-694). */
-typedef struct {
-    uint32_t lod, tile, view_id;      /* tid.0, tid.1, view_id                                   */
-    float tile_offset[3];
-    uint32_t map_index;
-    uint32_t map_coord[2];
-    float tile_center[3];
-    int32_t transition;               /* 0 None, 1 Spawning, 2 Changing(false), 3 Changing(true)   */
-    float spawning_factor;
-    uint32_t has_corners;
-    float corners[12];                /* corner_data[ci].0                                        */
-    uint32_t key_len;                 /* render_data_key.tid.len()                                */
-    uint32_t merged;                  /* Some(render_data_value)                                  */
-    uint32_t merged_offset;           /* into the concatenated merged arrays of gswt_sort_data    */
-    uint32_t merged_count;
-    int32_t single_lod_id;
-    uint32_t cache_hit;               /* value came from the LRU cache (wangtile.rs:575-593)      */
-    uint32_t merged_group;            /* index into gswt_sort_data.groups when merged               */
-} gswt_sorted_tile;
-
-typedef struct {
-    uint32_t scene_id;
-    uint32_t n_tiles;
-    const gswt_sorted_tile *tiles;    /* back-to-front */
-    size_t n_merged;
-    const uint32_t *merged_gs_index, *merged_map_id, *merged_lod_id;   /* NULL in device-merge mode */
-    /* group descriptions for gswt_set_draws_merge_groups (always filled) */
-    uint32_t n_groups, n_members;
-    const gswt_merge_group *groups;
-    const gswt_merge_member *members;
-} gswt_sort_data;
+/* gswt_sorted_tile / gswt_sort_data (SortData, structure.rs:488-509,670-694) are declared in gswt_hip.h: the device-side
+ * worker stages of libgswt_hip produce the same records. */
 
 /* PreloadData (structure.rs:731-736) */
 typedef struct {
@@ -176,6 +147,13 @@ GSWT_API int gswt_wang_set_device_merge(gswt_wang *w, int enable);
 /* Raw-depth tables for gswt_upload_raw_depth: ptrs[(lod*n_tile+tile)*n_view+view], counts / merge_offset [lod*n_tile+tile]. */
 GSWT_API int gswt_wang_raw_depth_tables(gswt_wang *w, const int32_t *const **ptrs, const uint32_t **counts,
                                         const uint32_t **merge_offset);
+
+/* Hand-over to the device-side worker stages (gswt_worker_* in gswt_hip.h).  worker_config: UserData fields + tables,
+ * pointers valid until the next gswt_wang_configure / destroy.  export_cells: the tile map after build_tiles;
+ * export_cell_state: what update_lod and the last sort_tiles' merging left in every cell (for parity tests). */
+GSWT_API int gswt_wang_worker_config(gswt_wang *w, gswt_worker_config *out);
+GSWT_API int gswt_wang_export_cells(const gswt_wang *w, gswt_cell *out, size_t capacity, int32_t center_coord[2]);
+GSWT_API int gswt_wang_export_cell_state(const gswt_wang *w, gswt_cell_state *out, size_t capacity);
 
 /* Inspect / override the tile-id map (tile ids come from an unpinned RNG in the reference; parity
  * fixtures pass them explicitly).  ids: tile_map_wh[0] * tile_map_wh[1], index = x * h + y. */

@@ -98,8 +98,8 @@ impl WangTile {
     }
 
     /// `WangTile::sort_tiles` (`wangtile.rs:476`).  The returned arrays are borrowed until the next mutating call.
-    pub fn sort_tiles(&mut self, cam_pos: [f32; 3], view_proj: &[f32; 16]) -> Result<host::GswtSortData> {
-        let mut s: host::GswtSortData = unsafe { std::mem::zeroed() };
+    pub fn sort_tiles(&mut self, cam_pos: [f32; 3], view_proj: &[f32; 16]) -> Result<hip::GswtSortData> {
+        let mut s: hip::GswtSortData = unsafe { std::mem::zeroed() };
         host_check(unsafe { host::gswt_wang_sort_tiles(self.raw, cam_pos.as_ptr(), view_proj.as_ptr(), &mut s) })?;
         Ok(s)
     }
@@ -164,7 +164,7 @@ impl GSWTRenderer {
     }
 
     /// Swap-in of a new `SortData` (`state.rs:361-376`): once per sort event, not per frame.
-    pub fn set_sort_data(&mut self, sort: &host::GswtSortData) -> Result<()> {
+    pub fn set_sort_data(&mut self, sort: &hip::GswtSortData) -> Result<()> {
         let mut draws: Vec<hip::GswtDraw> = vec![unsafe { std::mem::zeroed() }; sort.n_tiles as usize];
         host_check(unsafe { host::gswt_renderer_build_draws(sort, draws.as_mut_ptr()) })?;
         self.check(unsafe {
