@@ -386,113 +386,161 @@ __global__ __launch_bounds__(256) void k_w_order_reverse(const WDev w, const uin
 }
 
 // ---- Object (breadth-first, :1062-1126) and Graph (:1128-1218) orders: one workgroup, the traversals on thread 0 ----------
-// u16 tables carved from `tab` (LDS when they fit, global scratch otherwise; generic addressing serves both).
+// Tables carved from one block: LDS when they fit (kLds: the pointers then stay in the LDS address space), global scratch
+// otherwise.  An edge is ONE 64-bit record (src | dst << 16 | next-out << 32 | next-in << 48) and a node's list heads one
+// 32-bit word, so a traversal step costs one record read plus one flag read instead of four dependent u16 reads.
+constexpr int kSeqThreads = 1024;
 struct GraphTabs {
-    uint16_t *node_of_cell, *weight, *row_of_index, *index_of_row, *ohead, *ihead, *deg, *esrc, *edst, *onext, *inext, *pair_eid, *stack, *finish, *removed;
-    uint8_t *disc, *fin;
+    unsigned long long* erec;      // 2 x cells
+    uint32_t* nrec;                // cells: ohead | ihead << 16
+    uint16_t *node_of_cell, *weight, *row_of_index, *index_of_row, *deg, *pair_eid, *stack, *finish, *removed, *pos;
+    uint16_t* flags;               // per node: bit 0 discovered, bit 1 finished (one read for both)
 };
 __host__ __device__ inline size_t graph_tab_bytes(int cells)
 {
-    // node tables 7 x cells, edge tables 4 x 2 cells, pair ids 4 cells, stack 3 cells, finish + removed 2 cells (u16), flags 2 cells (u8)
-    return (size_t)cells * 2u * (7 + 8 + 4 + 3 + 2) + (size_t)cells * 2u + 64;
+    // erec 16 B, nrec 4 B, five node tables 10 B, pair ids 8 B, stack 6 B, finish + removed + pos 6 B, flags 2 B per cell
+    return (size_t)cells * (16 + 4 + 10 + 8 + 6 + 6 + 2) + 64;
 }
-__device__ inline GraphTabs graph_tabs(uint16_t* tab, int cells)
+template <typename P>
+__device__ __forceinline__ GraphTabs graph_tabs(P* tab, int cells)
 {
     GraphTabs T;
-    uint16_t* p = tab;
-    T.node_of_cell = p; p += cells; T.weight = p; p += cells; T.row_of_index = p; p += cells; T.index_of_row = p; p += cells;
-    T.ohead = p; p += cells; T.ihead = p; p += cells; T.deg = p; p += cells;
-    T.esrc = p; p += 2 * cells; T.edst = p; p += 2 * cells; T.onext = p; p += 2 * cells; T.inext = p; p += 2 * cells;
-    T.pair_eid = p; p += 4 * cells; T.stack = p; p += 3 * cells; T.finish = p; p += cells; T.removed = p; p += cells;
-    T.disc = reinterpret_cast<uint8_t*>(p); T.fin = T.disc + cells;
+    T.erec = reinterpret_cast<unsigned long long*>(tab);
+    T.nrec = reinterpret_cast<uint32_t*>(T.erec + 2 * cells);
+    uint16_t* p = reinterpret_cast<uint16_t*>(T.nrec + cells);
+    T.node_of_cell = p; p += cells; T.weight = p; p += cells; T.row_of_index = p; p += cells; T.index_of_row = p; p += cells; T.deg = p; p += cells;
+    T.pair_eid = p; p += 4 * cells; T.stack = p; p += 3 * cells; T.finish = p; p += cells; T.removed = p; p += cells; T.pos = p; p += cells;
+    T.flags = p;
     return T;
 }
+__device__ __forceinline__ uint32_t e_src(unsigned long long r) { return (uint32_t)r & 0xFFFFu; }
+__device__ __forceinline__ uint32_t e_dst(unsigned long long r) { return (uint32_t)(r >> 16) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t e_onext(unsigned long long r) { return (uint32_t)(r >> 32) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t e_inext(unsigned long long r) { return (uint32_t)(r >> 48); }
 
 // petgraph::algo::toposort over the live part of the graph (rows are node identities, indices are petgraph's NodeIndex values,
-// which swap_remove renumbers).  Returns the number of finished nodes in T.finish (topological order), or -1 - row of a node on
-// a cycle.
-__device__ int toposort_rows(const GraphTabs& T, int n_index)
+// which swap_remove renumbers), in its two halves.  Pass 1: depth-first finish order from the roots n-1..0, reversed ->
+// T.finish, returns its length.  Pass 2 (petgraph's cycle check: a reverse-graph traversal per node in that order that must
+// not reach a second node) returns the row petgraph reports, or -1.  Pass 2 can only find something if some live edge points
+// backwards in T.finish, which the workgroup tests in parallel first: on an acyclic graph the second traversal is skipped.
+__device__ __forceinline__ int toposort_pass1(const GraphTabs& T, int n_index)       // T.flags of every live row cleared by the caller
 {
-    for (int i = 0; i < n_index; i++) { const int r = T.row_of_index[i]; T.disc[r] = 0; T.fin[r] = 0; }
     int nfin = 0, sp = 0;
     for (int i = n_index - 1; i >= 0; i--) {
         const int root = T.row_of_index[i];
-        if (T.disc[root]) continue;
+        if (T.flags[root] & 1u) continue;
         T.stack[sp++] = (uint16_t)root;
+        int top = root;
+        bool top_known = true;                       // the element just pushed is the top: no need to read it back
         while (sp > 0) {
-            const int nx = T.stack[sp - 1];
-            if (!T.disc[nx]) {
-                T.disc[nx] = 1;
-                for (int e = T.ohead[nx]; e != kNone16; e = T.onext[e]) {
-                    if (T.esrc[e] == kNone16) continue;             // removed with a cycle node
-                    const int succ = T.edst[e];
-                    if (succ == nx) return -1 - nx;
-                    if (!T.disc[succ]) T.stack[sp++] = (uint16_t)succ;
+            const int nx = top_known ? top : (int)T.stack[sp - 1];
+            const uint32_t f = T.flags[nx];
+            if (!(f & 1u)) {
+                T.flags[nx] = (uint16_t)(f | 1u);
+                uint32_t e = T.nrec[nx] & 0xFFFFu;
+                top = nx; top_known = true;
+                if (e != kNone16) {
+                    unsigned long long rec = T.erec[e];
+                    for (;;) {
+                        // the successor's flag and the next record are fetched together (both addresses come from `rec`), so a
+                        // list step costs one LDS round trip instead of two; dead records (src = none) fetch harmless addresses
+                        const uint32_t next_e = e_onext(rec);
+                        const bool live = e_src(rec) != kNone16;
+                        const int succ = (int)e_dst(rec);             // (never nx itself: an edge joins two different nodes)
+                        const uint32_t fl = T.flags[live ? succ : nx];
+                        const unsigned long long rec_n = T.erec[next_e != kNone16 ? next_e : e];
+                        if (live && !(fl & 1u)) { T.stack[sp++] = (uint16_t)succ; top = succ; }
+                        if (next_e == kNone16) break;
+                        e = next_e; rec = rec_n;
+                    }
                 }
             } else {
                 sp--;
-                if (!T.fin[nx]) { T.fin[nx] = 1; T.finish[nfin++] = (uint16_t)nx; }
+                if (!(f & 2u)) { T.flags[nx] = (uint16_t)(f | 2u); T.finish[nfin++] = (uint16_t)nx; }
+                top_known = false;
             }
         }
     }
     for (int a = 0, b = nfin - 1; a < b; a++, b--) { const uint16_t t = T.finish[a]; T.finish[a] = T.finish[b]; T.finish[b] = t; }
-    for (int i = 0; i < n_index; i++) T.disc[T.row_of_index[i]] = 0;
+    return nfin;
+}
+__device__ __forceinline__ int toposort_pass2(const GraphTabs& T, int n_index, int nfin)
+{
+    for (int i = 0; i < n_index; i++) T.flags[T.row_of_index[i]] = 0;
     for (int k = 0; k < nfin; k++) {
-        sp = 0;
+        int sp = 0;
         T.stack[sp++] = T.finish[k];
         bool cycle = false;
         while (sp > 0) {
             const int node = T.stack[--sp];
-            if (T.disc[node]) continue;
-            T.disc[node] = 1;
-            for (int e = T.ihead[node]; e != kNone16; e = T.inext[e]) {
-                if (T.esrc[e] == kNone16) continue;
-                const int pred = T.esrc[e];
-                if (!T.disc[pred]) T.stack[sp++] = (uint16_t)pred;
+            if (T.flags[node]) continue;
+            T.flags[node] = 1;
+            for (uint32_t e = T.nrec[node] >> 16; e != kNone16;) {
+                const unsigned long long r = T.erec[e];
+                e = e_inext(r);
+                if (e_src(r) == kNone16) continue;
+                const int pred = (int)e_src(r);
+                if (!T.flags[pred]) T.stack[sp++] = (uint16_t)pred;
             }
-            if (cycle) return -1 - node;
+            if (cycle) return node;
             cycle = true;
         }
     }
-    return nfin;
+    return -1;
 }
 
-__global__ __launch_bounds__(256) void k_w_order_seq(const WDev w, const V3 cam, const int8_t* __restrict__ gdir, uint16_t* __restrict__ gtab, int use_lds,
-                                                     uint32_t* __restrict__ order)
+// exclusive prefix of a 0/1 flag over the workgroup's threads (ballot + popcount per wave, wave totals through LDS); returns the
+// prefix and adds the total to `carry` (read it before the next call: two barriers inside)
+__device__ __forceinline__ uint32_t flag_scan(bool flag, uint32_t* s_wave, uint32_t& carry)
 {
-    extern __shared__ uint16_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    const uint32_t in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t k = 0; k < kSeqThreads / 64; k++) { const uint32_t c = s_wave[k]; total += c; if (k < wv) before += c; }
+    __syncthreads();
+    const uint32_t r = carry + before + in_wave;
+    carry += total;
+    return r;
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(kSeqThreads) void k_w_order_seq(const WDev w, const V3 cam, const int8_t* __restrict__ gdir, unsigned long long* __restrict__ gtab,
+                                                             uint32_t* __restrict__ order)
+{
+    extern __shared__ unsigned long long lds64[];
     const int cells = w.cells, tid = threadIdx.x;
-    uint16_t* tab = use_lds ? lds : gtab;
-    const GraphTabs T = graph_tabs(tab, cells);
-    __shared__ uint32_t s_scan[256];
-    __shared__ uint32_t s_carry;
+    const GraphTabs T = kLds ? graph_tabs(lds64, cells) : graph_tabs(gtab, cells);
+    __shared__ uint32_t s_wave[kSeqThreads / 64];
     if (w.sort_type == SORT_OBJECT) {
         // start: the not-MergedTo cell nearest to the camera, first minimum in index order
-        __shared__ float s_d[256];
-        __shared__ int s_i[256];
+        __shared__ float s_d[kSeqThreads];
+        __shared__ int s_i[kSeqThreads];
         float bd = -1.0f; int bi = 0;
-        for (int idx = tid; idx < cells; idx += 256) {
+        for (int idx = tid; idx < cells; idx += kSeqThreads) {
             if (w.st[idx].merge == MS_TO) continue;
             const float d = distance2(cam, v3(w.cell[idx].tile_center));
             if (bd < 0.0f || d < bd) { bd = d; bi = idx; }
         }
         s_d[tid] = bd; s_i[tid] = bi;
-        for (int idx = tid; idx < cells; idx += 256) T.disc[idx] = 0;
+        for (int idx = tid; idx < cells; idx += kSeqThreads) T.flags[idx] = 0;
         __syncthreads();
         if (tid != 0) return;
         bd = -1.0f; bi = 0;
-        for (int k = 0; k < 256; k++)              // a thread's candidates are idx = k mod 256 ascending: compare (d, idx) to keep the first minimum
+        for (int k = 0; k < kSeqThreads; k++)     // a thread's own candidates ascend in index: (d, index) order keeps the first minimum overall
             if (s_d[k] >= 0.0f && (bd < 0.0f || s_d[k] < bd || (s_d[k] == bd && s_i[k] < bi))) { bd = s_d[k]; bi = s_i[k]; }
-        uint16_t* queue = T.stack;                 // 3 x cells entries: enough for one entry per cell
+        uint16_t* queue = T.stack;                 // 3 x cells entries: one per cell is enough
         int qh = 0, qt = 0, n = 0;
         queue[qt++] = (uint16_t)bi;
-        T.disc[bi] = 1;
+        T.flags[bi] = 1;
         while (qh < qt) {
             const int c = queue[qh++];
             T.finish[n++] = (uint16_t)c;
             for (int s = 0; s < 4; s++) {
                 const int nb = nbr(w, c, s);
-                if (nb >= 0 && !T.disc[nb >> 2]) { queue[qt++] = (uint16_t)(nb >> 2); T.disc[nb >> 2] = 1; }
+                if (nb >= 0 && !T.flags[nb >> 2]) { queue[qt++] = (uint16_t)(nb >> 2); T.flags[nb >> 2] = 1; }
             }
         }
         for (int k = 0; k < n; k++) order[k] = T.finish[n - 1 - k];
@@ -501,67 +549,55 @@ __global__ __launch_bounds__(256) void k_w_order_seq(const WDev w, const V3 cam,
     }
     // ---- Graph ------------------------------------------------------------------------------------------------------------
     // nodes: not-MergedTo cells in index order (add_node in the scan of :1136-1147)
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < cells; base += 256) {
+    uint32_t carry = 0;
+    for (int base = 0; base < cells; base += kSeqThreads) {
         const int idx = base + tid;
-        const uint32_t flag = idx < cells && w.st[idx].merge != MS_TO ? 1u : 0u;
-        s_scan[tid] = flag;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) { const uint32_t v = tid >= o ? s_scan[tid - o] : 0u; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
-        const uint32_t r = s_carry + s_scan[tid] - flag;
+        const bool flag = idx < cells && w.st[idx].merge != MS_TO;
+        const uint32_t r = flag_scan(flag, s_wave, carry);
         if (idx < cells) {
             T.node_of_cell[idx] = flag ? (uint16_t)r : kNone16;
-            if (flag) { T.weight[r] = (uint16_t)idx; T.row_of_index[r] = (uint16_t)r; T.index_of_row[r] = (uint16_t)r; T.ohead[r] = kNone16; T.ihead[r] = kNone16; T.deg[r] = 0; }
+            if (flag) { T.weight[r] = (uint16_t)idx; T.row_of_index[r] = (uint16_t)r; T.index_of_row[r] = (uint16_t)r; T.nrec[r] = 0xFFFFFFFFu; T.deg[r] = 0; }
         }
-        __syncthreads();
-        if (tid == 255) s_carry += s_scan[255];
-        __syncthreads();
     }
-    const int n_nodes = (int)s_carry;
+    const int n_nodes = (int)carry;
     __syncthreads();
     // edges: one per owned pair of different nodes with a nonzero orientation, numbered in scan order (cell, side)
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
+    carry = 0;
     auto node_of = [&](int c) -> int { return w.st[c].merge == MS_TO ? T.node_of_cell[w.st[c].merged_to] : T.node_of_cell[c]; };
-    for (int base = 0; base < cells * 4; base += 256) {
+    for (int base = 0; base < cells * 4; base += kSeqThreads) {
         const int t = base + tid;
-        uint32_t flag = 0;
+        bool flag = false;
         int a = 0, b = 0;
         if (t < cells * 4) {
             const int c = t >> 2, s = t & 3;
-            const int nb = nbr(w, c, s);
-            const int dir = gdir[t];
-            if (nb >= 0 && (nb >> 2) > c && dir != 0) {
+            const int dir = gdir[t];                  // nonzero only on the owner's side of a pair (k_w_edges)
+            if (dir != 0) {
+                const int nb = nbr(w, c, s);
                 const int tn = node_of(c), nn = node_of(nb >> 2);
-                if (tn != nn) { flag = 1; a = dir > 0 ? tn : nn; b = dir > 0 ? nn : tn; }
+                if (tn != nn) { flag = true; a = dir > 0 ? tn : nn; b = dir > 0 ? nn : tn; }
             }
         }
-        s_scan[tid] = flag;
-        __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) { const uint32_t v = tid >= o ? s_scan[tid - o] : 0u; __syncthreads(); s_scan[tid] += v; __syncthreads(); }
-        const uint32_t e = s_carry + s_scan[tid] - flag;
+        const uint32_t e = flag_scan(flag, s_wave, carry);
         if (t < cells * 4) {
             T.pair_eid[t] = flag ? (uint16_t)e : kNone16;
-            if (flag) { T.esrc[e] = (uint16_t)a; T.edst[e] = (uint16_t)b; }
+            if (flag) T.erec[e] = (unsigned long long)(uint32_t)a | ((unsigned long long)(uint32_t)b << 16) | (0xFFFFFFFFull << 32);
         }
-        __syncthreads();
-        if (tid == 255) s_carry += s_scan[255];
-        __syncthreads();
     }
-    // adjacency lists, newest edge first (petgraph links a new edge at the head of both lists): per node, its incident edges are
-    // the pairs of its cells' sides; link them in ascending id so that the last one linked is the head
-    for (int r = tid; r < n_nodes; r += 256) {
+    __syncthreads();
+    // adjacency lists, newest edge first (petgraph links a new edge at the head of both lists): a node's incident edges are the
+    // pairs of its cells' sides; linking them in ascending id leaves the newest at the head
+    for (int r = tid; r < n_nodes; r += kSeqThreads) {
         const int head = T.weight[r];
         const bool grp = w.st[head].merge == MS_FROM;
         const int len = grp ? (int)w.head_len[head] : 1;
         const uint32_t* mem = w.pool + (grp ? w.head_off[head] : 0u);
-        int last = -1;
-        int deg = 0;
+        uint32_t oh = kNone16, ih = kNone16;
+        int last = -1, deg = 0;
         for (;;) {                                    // selection in ascending edge id: degrees are small (4 per member cell)
             int best = 0x7FFFFFFF;
             for (int m = 0; m < len; m++) {
                 const int c = grp ? (int)mem[m] : head;
+#pragma unroll
                 for (int s = 0; s < 4; s++) {
                     const int nb = nbr(w, c, s);
                     if (nb < 0) continue;
@@ -571,41 +607,70 @@ __global__ __launch_bounds__(256) void k_w_order_seq(const WDev w, const V3 cam,
                 }
             }
             if (best == 0x7FFFFFFF) break;
-            // an edge between two cells of this node does not exist (tn == nn above); one between this node and another is seen from
-            // exactly one side here, except multi-edges to the same neighbour node, which have distinct ids
-            if (T.esrc[best] == r) { T.onext[best] = T.ohead[r]; T.ohead[r] = (uint16_t)best; }
-            else { T.inext[best] = T.ihead[r]; T.ihead[r] = (uint16_t)best; }
+            // an edge inside this node does not exist (tn == nn above); an edge to another node is seen from exactly one cell side
+            // here, and multi-edges to the same neighbour node have ids of their own
+            // the record's two link fields are written by the two end nodes' threads: 16-bit stores, so neither clobbers the other
+            uint16_t* half = reinterpret_cast<uint16_t*>(&T.erec[best]);
+            if (half[0] == (uint16_t)r) { half[2] = (uint16_t)oh; oh = (uint32_t)best; }       // this node is the source: out-list
+            else { half[3] = (uint16_t)ih; ih = (uint32_t)best; }
             deg++;
             last = best;
         }
+        T.nrec[r] = oh | (ih << 16);
         T.deg[r] = (uint16_t)deg;
     }
     __syncthreads();
-    if (tid != 0) return;
-    int n_index = n_nodes, n_removed = 0, n_out = 0;
-    for (;;) {
-        const int res = toposort_rows(T, n_index);
-        if (res >= 0) {
-            for (int k = 0; k < res; k++) {
-                const int r = T.finish[k];
-                if (T.deg[r] != 0) order[n_out++] = T.weight[r];
-            }
-            break;
+    const int n_edges = (int)carry;
+    __shared__ int s_nfin, s_cyc;
+    int n_index = n_nodes, n_removed = 0;
+#ifdef GSWT_W_SKIP_DFS                                        // timing ablation (tools only): everything but the traversals
+    if (tid == 0) w.counts[C_N_ORDER] = 0;
+    return;
+#endif
+    for (;;) {                                              // uniform over the workgroup
+        for (int k = tid; k < n_nodes; k += kSeqThreads) T.flags[k] = 0;
+        __syncthreads();
+        if (tid == 0) s_nfin = toposort_pass1(T, n_index);
+        __syncthreads();
+        const int nfin = s_nfin;
+        for (int k = tid; k < nfin; k += kSeqThreads) T.pos[T.finish[k]] = (uint16_t)k;
+        __syncthreads();
+        int back = 0;
+        for (int e = tid; e < n_edges; e += kSeqThreads) {
+            const unsigned long long rec = T.erec[e];
+            if (e_src(rec) != kNone16 && T.pos[e_src(rec)] >= T.pos[e_dst(rec)]) back = 1;
         }
+        const int cyclic = __syncthreads_or(back);
+        if (tid == 0) s_cyc = cyclic ? toposort_pass2(T, n_index, nfin) : -1;
+        __syncthreads();
+        const int r = s_cyc;
+        if (r < 0) break;
         // a node on a cycle is taken out (Graph::remove_node: its edges go, the last node takes its index) and listed behind the rest
-        const int r = -1 - res;
-        T.removed[n_removed++] = T.weight[r];
-        for (int pass = 0; pass < 2; pass++)
-            for (int e = pass ? T.ihead[r] : T.ohead[r]; e != kNone16; e = pass ? T.inext[e] : T.onext[e]) {
-                if (T.esrc[e] == kNone16) continue;
-                const int other = pass ? T.esrc[e] : T.edst[e];
-                T.deg[other]--;
-                T.deg[r]--;
-                T.esrc[e] = kNone16;
-            }
-        const int idx = T.index_of_row[r], last = n_index - 1;
-        if (idx != last) { const int lr = T.row_of_index[last]; T.row_of_index[idx] = (uint16_t)lr; T.index_of_row[lr] = (uint16_t)idx; }
+        if (tid == 0) {
+            T.removed[n_removed] = T.weight[r];
+            for (int pass = 0; pass < 2; pass++)
+                for (uint32_t e = pass ? T.nrec[r] >> 16 : T.nrec[r] & 0xFFFFu; e != kNone16;) {
+                    const unsigned long long rec = T.erec[e];
+                    const uint32_t cur = e;
+                    e = pass ? e_inext(rec) : e_onext(rec);
+                    if (e_src(rec) == kNone16) continue;
+                    const int other = pass ? (int)e_src(rec) : (int)e_dst(rec);
+                    T.deg[other]--;
+                    T.deg[r]--;
+                    T.erec[cur] = rec | 0xFFFFull;
+                }
+            const int idx = T.index_of_row[r], last = n_index - 1;
+            if (idx != last) { const int lr = T.row_of_index[last]; T.row_of_index[idx] = (uint16_t)lr; T.index_of_row[lr] = (uint16_t)idx; }
+        }
+        n_removed++;
         n_index--;
+        __syncthreads();
+    }
+    if (tid != 0) return;
+    int n_out = 0;
+    for (int k = 0; k < s_nfin; k++) {
+        const int r = T.finish[k];
+        if (T.deg[r] != 0) order[n_out++] = T.weight[r];
     }
     for (int k = 0; k < n_removed; k++) order[n_out++] = T.removed[k];
     for (int a = 0, b = n_out - 1; a < b; a++, b--) { const uint32_t t = order[a]; order[a] = order[b]; order[b] = t; }
@@ -815,7 +880,7 @@ struct gswt_worker {
     Dev<gswt_cell> cell;
     Dev<gswt_cell_state> st;
     Dev<int8_t> gdir;
-    Dev<uint16_t> gtab;
+    Dev<unsigned long long> gtab;
     Dev<unsigned long long> n64;
     Dev<gswt_sorted_tile> tiles;
     Dev<gswt_merge_group> groups;
@@ -918,7 +983,7 @@ int gswt_worker_create(gswt_ctx* ctx, const gswt_worker_config* cfg, gswt_worker
     A(w->cell.alloc(cells)); A(w->st.alloc(cells)); A(w->head_off.alloc(cells)); A(w->head_len.alloc(cells)); A(w->pool.alloc(cells + 8));
     A(w->counts.alloc(C_COUNT)); A(w->order.alloc(cells)); A(w->keys_a.alloc(n_cand)); A(w->vals_a.alloc(n_cand)); A(w->keys_b.alloc(n_cand));
     A(w->vals_b.alloc(n_cand)); A(w->radix_ws.alloc(w->radix_words)); A(w->pre_group.alloc(cells)); A(w->pre_member.alloc(cells)); A(w->pre_len.alloc(cells));
-    A(w->ent_len.alloc(cells)); A(w->gdir.alloc(n_cand)); A(w->gtab.alloc(graph_tab_bytes((int)cells) / 2 + 8)); A(w->n64.alloc(8));
+    A(w->ent_len.alloc(cells)); A(w->gdir.alloc(n_cand)); A(w->gtab.alloc(graph_tab_bytes((int)cells) / 8 + 8)); A(w->n64.alloc(8));
     A(w->tiles.alloc(cells)); A(w->groups.alloc(cells)); A(w->members.alloc(cells)); A(w->draws.alloc(cells));
     A(w->h_tiles.alloc(cells)); A(w->h_groups.alloc(cells)); A(w->h_members.alloc(cells)); A(w->h_draws.alloc(cells)); A(w->h_counts.alloc(C_COUNT));
     if (e != hipSuccess) { gswt_worker_destroy(w); return GSWT_ERR_HIP; }
@@ -932,12 +997,12 @@ int gswt_worker_create(gswt_ctx* ctx, const gswt_worker_config* cfg, gswt_worker
     w->lds_merge = (3 * cells + 3 * (cells / 2 + 1)) * sizeof(uint16_t);
     if (cfg->merge_type == MERGE_EDGE && w->lds_merge > 156u * 1024u) { gswt_worker_destroy(w); return GSWT_ERR_CAPACITY; }
     w->lds_graph = graph_tab_bytes((int)cells);
-    w->graph_in_lds = w->lds_graph <= 150u * 1024u;
+    w->graph_in_lds = w->lds_graph <= 140u * 1024u;     // beside the kernel's 8 KB of static LDS
     if (w->lds_merge > 48u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_merge) != hipSuccess) {
         gswt_worker_destroy(w); return GSWT_ERR_HIP;
     }
     if (w->graph_in_lds && w->lds_graph > 48u * 1024u &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_order_seq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_graph) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_order_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_graph) != hipSuccess) {
         gswt_worker_destroy(w); return GSWT_ERR_HIP;
     }
 #undef WTRY
@@ -1027,7 +1092,8 @@ int gswt_worker_sort_tiles(gswt_worker* w, const float cam_pos[3], const float v
         const int where = gswt::launch_sort(s, w->keys_a.p, w->vals_a.p, w->keys_b.p, w->vals_b.p, cells, w->n64.p + 4, 32, w->radix_ws.p);
         hipLaunchKernelGGL(k_w_order_reverse, dim3((cells + 255) / 256), dim3(256), 0, s, d, where ? w->vals_b.p : w->vals_a.p, w->order.p);
     } else {
-        hipLaunchKernelGGL(k_w_order_seq, dim3(1), dim3(256), w->graph_in_lds ? w->lds_graph : 0, s, d, cam, w->gdir.p, w->gtab.p, w->graph_in_lds, w->order.p);
+        if (w->graph_in_lds) hipLaunchKernelGGL(k_w_order_seq<true>, dim3(1), dim3(kSeqThreads), w->lds_graph, s, d, cam, w->gdir.p, w->gtab.p, w->order.p);
+        else hipLaunchKernelGGL(k_w_order_seq<false>, dim3(1), dim3(kSeqThreads), 0, s, d, cam, w->gdir.p, w->gtab.p, w->order.p);
     }
     hipLaunchKernelGGL(k_w_scan, dim3(1), dim3(1024), 0, s, d, w->order.p, w->pre_group.p, w->pre_member.p, w->pre_len.p, w->ent_len.p);
     hipLaunchKernelGGL(k_w_records, dim3((cells + 255) / 256), dim3(256), 0, s, d, cam, w->order.p, w->pre_group.p, w->pre_member.p, w->pre_len.p, w->ent_len.p,
