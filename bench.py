@@ -137,9 +137,11 @@ class Worker:
     far enough (check_update / build_tiles), re-sorts when the view-projection changed by >= 0.01 (sum of |d VP|), and hands
     the newest SortData (+ the scene uniforms that belong to it) back.  libgswt_host calls release the GIL."""
 
-    def __init__(self, wang):
+    def __init__(self, wang, dev=None):
         import threading
         self.wang = wang
+        self.dev = dev          # DeviceWorker: update_lod / merging / order / views / records on the GPU (--device-worker)
+        self._dev_built = False
         self._lock = threading.Lock()
         self._wake = threading.Event()
         self._req = None
@@ -189,9 +191,12 @@ class Worker:
     def step(self, pos, vp):
         """One worker iteration, synchronously (initial frame)."""
         rebuilt = False
-        if self.wang.check_update(pos):
+        if self.wang.check_update(pos) or (self.dev is not None and not self._dev_built):
+            self._dev_built = True                    # the device worker's first map comes with its first step
             t0 = time.perf_counter()
             self.wang.build_tiles(pos)
+            if self.dev is not None:
+                self.dev.build_tiles(pos)             # map upload + update_lod on the device
             self.build_ms.append(1e3 * (time.perf_counter() - t0))
             rebuilt = True
         moved = self._prev_vp is None or float(np.abs(vp - self._prev_vp).sum()) >= 0.01       # state.rs:527-548
@@ -199,7 +204,12 @@ class Worker:
             return None
         self._prev_vp = vp.copy()
         t0 = time.perf_counter()
-        raw = self.wang.sort_tiles_raw(pos, vp)
+        if self.dev is not None:
+            self.dev.sort_tiles(pos, vp)
+            self.dev.fetch()                          # waits for the worker's stream, publishes the event for the render thread
+            raw = None
+        else:
+            raw = self.wang.sort_tiles_raw(pos, vp)
         self.sort_ms.append(1e3 * (time.perf_counter() - t0))
         return raw, self.wang.scene_uniforms()
 
@@ -252,6 +262,7 @@ def main():
     ap.add_argument("--static-at", type=int, default=-1, help="static mode: use fly-path camera number K instead of the workload's own")
     ap.add_argument("--freeze-sort", action="store_true", help="fly path cameras without the worker: the first SortData stays (\"Lock (Sort)\" of the "
                     "reference GUI, gui.rs:599-605); separates the per-view workload from the cost of the sort events")
+    ap.add_argument("--device-worker", action="store_true", help="fly path: run the per-sort-event worker stages on the GPU (gswt_worker_*) instead of libgswt_host")
     ap.add_argument("--static-steps", type=int, default=100, help="flypath mode: frames of the static-camera comparison run (0: skip)")
     args = ap.parse_args()
 
@@ -382,9 +393,13 @@ def main():
     inflight = []
 
     def swap_in(res):
-        (draws, nd, groups, ng, members, nm), su = res
+        raw, su = res
         t0 = time.perf_counter()
-        r.set_draws_merge_groups_raw(draws, nd, groups, ng, members, nm)         # SortData swap-in, state.rs:361-376
+        if raw is None:
+            dev_worker.swap_in(fetch=False)                                      # the event the device-side worker published last
+        else:
+            draws, nd, groups, ng, members, nm = raw
+            r.set_draws_merge_groups_raw(draws, nd, groups, ng, members, nm)     # SortData swap-in, state.rs:361-376
         state["swap_ms"].append(1e3 * (time.perf_counter() - t0))
         state["su"] = su
         state["swaps"] += 1
@@ -481,8 +496,12 @@ def main():
     worker = None
     if args.mode == "static" and args.static_at >= 0:
         swap_in(res_k)
+    dev_worker = None
     if args.mode == "flypath":
-        worker = Worker(wang)
+        if args.device_worker:
+            from gswt_renderer_amd.worker import DeviceWorker
+            dev_worker = DeviceWorker(r, wang)
+        worker = Worker(wang, dev_worker)
         res = worker.step(cams[0][0], cams[0][2])            # the first SortData, synchronously (State::new + first frames)
         if res is not None:
             swap_in(res)
@@ -500,6 +519,10 @@ def main():
                      "sort_tiles_ms_mean": float(np.mean(worker.sort_ms)) if worker.sort_ms else None, "sort_tiles_events": len(worker.sort_ms),
                      "threads": 1, "note": "libgswt_host (C++ WangTile) on one host thread beside the render thread, as state.rs:478-561; "
                      "sort_tiles in device-merge mode (group descriptions only; the merged lists are built on the GPU at swap-in)"}
+        if dev_worker is not None:
+            worker_ms["note"] = ("--device-worker: update_tile_map on the host thread, then update_lod, selective merging, tile order, views and "
+                                 "records as HIP kernels on the worker's own stream (gswt_worker_*); build = host map + upload + update_lod, "
+                                 "sort = device sort event + record read-back")
 
     # the last fly-path camera again, one frame at a time: k_composite without another frame's kernels sharing the chip, and the
     # image the CPU baseline is compared with.  `roofline` itself comes from the timed region, where the frames overlap.

@@ -184,6 +184,7 @@ SYMBOLS = {
     "gswt_worker_set_cells": (C.c_int, [_P, _P, C.c_size_t, _P]),
     "gswt_worker_update_lod": (C.c_int, [_P, _P]),
     "gswt_worker_sort_tiles": (C.c_int, [_P, _P, _P]),
+    "gswt_worker_fetch": (C.c_int, [_P]),
     "gswt_worker_read_cell_state": (C.c_int, [_P, _P, C.c_size_t]),
     "gswt_worker_read_sort": (C.c_int, [_P, _P]),
     "gswt_set_draws_from_worker": (C.c_int, [_P, _P]),

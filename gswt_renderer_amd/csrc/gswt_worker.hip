@@ -16,6 +16,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -886,10 +887,18 @@ struct gswt_worker {
     Dev<gswt_merge_group> groups;
     Dev<gswt_merge_member> members;
     Dev<gswt_draw> draws;
-    Pinned<gswt_sorted_tile> h_tiles;
-    Pinned<gswt_merge_group> h_groups;
-    Pinned<gswt_merge_member> h_members;
-    Pinned<gswt_draw> h_draws;
+    // Results in host memory, three sets: one published (what gswt_set_draws_from_worker takes), one possibly in use by the render
+    // thread, one being written by gswt_worker_fetch -- the worker thread never waits for the render thread and vice versa.
+    struct HostSet {
+        Pinned<gswt_sorted_tile> tiles;
+        Pinned<gswt_merge_group> groups;
+        Pinned<gswt_merge_member> members;
+        Pinned<gswt_draw> draws;
+        uint32_t counts[C_COUNT] = {};
+    } hs[3];
+    std::mutex mu;
+    int published = -1, in_use = -1;
+    bool sort_pending = false;
     Pinned<uint32_t> h_counts;
     size_t radix_words = 0;
 };
@@ -985,7 +994,8 @@ int gswt_worker_create(gswt_ctx* ctx, const gswt_worker_config* cfg, gswt_worker
     A(w->vals_b.alloc(n_cand)); A(w->radix_ws.alloc(w->radix_words)); A(w->pre_group.alloc(cells)); A(w->pre_member.alloc(cells)); A(w->pre_len.alloc(cells));
     A(w->ent_len.alloc(cells)); A(w->gdir.alloc(n_cand)); A(w->gtab.alloc(graph_tab_bytes((int)cells) / 8 + 8)); A(w->n64.alloc(8));
     A(w->tiles.alloc(cells)); A(w->groups.alloc(cells)); A(w->members.alloc(cells)); A(w->draws.alloc(cells));
-    A(w->h_tiles.alloc(cells)); A(w->h_groups.alloc(cells)); A(w->h_members.alloc(cells)); A(w->h_draws.alloc(cells)); A(w->h_counts.alloc(C_COUNT));
+    for (auto& h : w->hs) { A(h.tiles.alloc(cells)); A(h.groups.alloc(cells)); A(h.members.alloc(cells)); A(h.draws.alloc(cells)); }
+    A(w->h_counts.alloc(C_COUNT));
     if (e != hipSuccess) { gswt_worker_destroy(w); return GSWT_ERR_HIP; }
     A(hipMemset(w->st.p, 0, cells * sizeof(gswt_cell_state))); A(hipMemset(w->head_len.p, 0, cells * 4)); A(hipMemset(w->counts.p, 0, C_COUNT * 4));
     A(hipMemset(w->n64.p, 0, 8 * sizeof(unsigned long long)));
@@ -1020,7 +1030,8 @@ void gswt_worker_destroy(gswt_worker* w)
     w->keys_a.release(); w->vals_a.release(); w->keys_b.release(); w->vals_b.release(); w->radix_ws.release(); w->pre_group.release();
     w->pre_member.release(); w->pre_len.release(); w->ent_len.release(); w->nb.release(); w->cell.release(); w->st.release(); w->gdir.release();
     w->gtab.release(); w->n64.release(); w->tiles.release(); w->groups.release(); w->members.release(); w->draws.release();
-    w->h_tiles.release(); w->h_groups.release(); w->h_members.release(); w->h_draws.release(); w->h_counts.release();
+    for (auto& h : w->hs) { h.tiles.release(); h.groups.release(); h.members.release(); h.draws.release(); }
+    w->h_counts.release();
     delete w;
 }
 
@@ -1042,7 +1053,7 @@ int gswt_worker_set_cells(gswt_worker* w, const gswt_cell* cells, size_t n_cells
         WHIP(hipMemset(w->head_len.p, 0, n_cells * 4));
         WHIP(hipMemset(w->counts.p, 0, C_COUNT * 4));
     }
-    w->have_cells = true; w->have_lod = false; w->have_sort = false;
+    w->have_cells = true; w->have_lod = false; w->have_sort = false; w->sort_pending = false;
     return GSWT_OK;
 }
 
@@ -1099,7 +1110,7 @@ int gswt_worker_sort_tiles(gswt_worker* w, const float cam_pos[3], const float v
     hipLaunchKernelGGL(k_w_records, dim3((cells + 255) / 256), dim3(256), 0, s, d, cam, w->order.p, w->pre_group.p, w->pre_member.p, w->pre_len.p, w->ent_len.p,
                        w->tiles.p, w->groups.p, w->members.p, w->draws.p);
     WHIP(hipGetLastError());
-    w->have_sort = true;
+    w->have_sort = true; w->sort_pending = true;
     return GSWT_OK;
 }
 
@@ -1114,45 +1125,75 @@ int gswt_worker_read_cell_state(gswt_worker* w, gswt_cell_state* out, size_t cap
     return GSWT_OK;
 }
 
+int gswt_worker_fetch(gswt_worker* w)
+{
+    if (!w) return GSWT_ERR_BAD_ARG;
+    if (!w->have_sort) return wfail(w, GSWT_ERR_STATE, "gswt_worker_fetch before gswt_worker_sort_tiles");
+    WHIP(hipSetDevice(w->device));
+    const int rc = read_counts(w);
+    if (rc != GSWT_OK) return rc;
+    int b = 0;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        while (b == w->published || b == w->in_use) b++;
+    }
+    gswt_worker::HostSet& h = w->hs[b];
+    memcpy(h.counts, w->h_counts.p, sizeof(h.counts));
+    const uint32_t* c = h.counts;
+    hipStream_t s = w->stream;
+    if (c[C_N_ORDER]) {
+        WHIP(hipMemcpyAsync(h.tiles.p, w->tiles.p, c[C_N_ORDER] * sizeof(gswt_sorted_tile), hipMemcpyDeviceToHost, s));
+        WHIP(hipMemcpyAsync(h.draws.p, w->draws.p, c[C_N_ORDER] * sizeof(gswt_draw), hipMemcpyDeviceToHost, s));
+    }
+    if (c[C_N_GROUPS]) WHIP(hipMemcpyAsync(h.groups.p, w->groups.p, c[C_N_GROUPS] * sizeof(gswt_merge_group), hipMemcpyDeviceToHost, s));
+    if (c[C_N_MEMBERS]) WHIP(hipMemcpyAsync(h.members.p, w->members.p, c[C_N_MEMBERS] * sizeof(gswt_merge_member), hipMemcpyDeviceToHost, s));
+    WHIP(hipStreamSynchronize(s));
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->published = b;
+    }
+    w->sort_pending = false;
+    return GSWT_OK;
+}
+
 int gswt_worker_read_sort(gswt_worker* w, gswt_sort_data* out)
 {
     if (!w) return GSWT_ERR_BAD_ARG;
     if (!out) return wfail(w, GSWT_ERR_BAD_ARG, "gswt_worker_read_sort: null argument");
     if (!w->have_sort) return wfail(w, GSWT_ERR_STATE, "gswt_worker_read_sort before gswt_worker_sort_tiles");
-    WHIP(hipSetDevice(w->device));
-    const int rc = read_counts(w);
-    if (rc != GSWT_OK) return rc;
-    const uint32_t* c = w->h_counts.p;
-    hipStream_t s = w->stream;
-    if (c[C_N_ORDER]) WHIP(hipMemcpyAsync(w->h_tiles.p, w->tiles.p, c[C_N_ORDER] * sizeof(gswt_sorted_tile), hipMemcpyDeviceToHost, s));
-    if (c[C_N_GROUPS]) WHIP(hipMemcpyAsync(w->h_groups.p, w->groups.p, c[C_N_GROUPS] * sizeof(gswt_merge_group), hipMemcpyDeviceToHost, s));
-    if (c[C_N_MEMBERS]) WHIP(hipMemcpyAsync(w->h_members.p, w->members.p, c[C_N_MEMBERS] * sizeof(gswt_merge_member), hipMemcpyDeviceToHost, s));
-    WHIP(hipStreamSynchronize(s));
+    if (w->sort_pending) {
+        const int rc = gswt_worker_fetch(w);
+        if (rc != GSWT_OK) return rc;
+    }
+    const gswt_worker::HostSet& h = w->hs[w->published];
+    const uint32_t* c = h.counts;
     memset(out, 0, sizeof(*out));
-    out->n_tiles = c[C_N_ORDER]; out->tiles = w->h_tiles.p;
+    out->n_tiles = c[C_N_ORDER]; out->tiles = h.tiles.p;
     out->n_merged = (size_t)c[C_MERGED_LO] | ((size_t)c[C_MERGED_HI] << 32);
     out->n_groups = c[C_N_GROUPS]; out->n_members = c[C_N_MEMBERS];
-    out->groups = w->h_groups.p; out->members = w->h_members.p;
+    out->groups = h.groups.p; out->members = h.members.p;
     return GSWT_OK;
 }
 
 int gswt_set_draws_from_worker(gswt_ctx* ctx, gswt_worker* w)
 {
     if (!ctx || !w) return GSWT_ERR_BAD_ARG;
-    if (w->ctx != ctx) return wfail(w, GSWT_ERR_BAD_ARG, "gswt_set_draws_from_worker: the worker belongs to another ctx");
-    if (!w->have_sort) return wfail(w, GSWT_ERR_STATE, "gswt_set_draws_from_worker before gswt_worker_sort_tiles");
-    WHIP(hipSetDevice(w->device));
-    const int rc = read_counts(w);
-    if (rc != GSWT_OK) return rc;
-    const uint32_t* c = w->h_counts.p;
-    hipStream_t s = w->stream;
-    if (c[C_N_ORDER]) WHIP(hipMemcpyAsync(w->h_draws.p, w->draws.p, c[C_N_ORDER] * sizeof(gswt_draw), hipMemcpyDeviceToHost, s));
-    if (c[C_N_GROUPS]) WHIP(hipMemcpyAsync(w->h_groups.p, w->groups.p, c[C_N_GROUPS] * sizeof(gswt_merge_group), hipMemcpyDeviceToHost, s));
-    if (c[C_N_MEMBERS]) WHIP(hipMemcpyAsync(w->h_members.p, w->members.p, c[C_N_MEMBERS] * sizeof(gswt_merge_member), hipMemcpyDeviceToHost, s));
-    WHIP(hipStreamSynchronize(s));
-    const int r = gswt_set_draws_merge_groups(ctx, w->h_draws.p, (int)c[C_N_ORDER], w->h_groups.p, (int)c[C_N_GROUPS], w->h_members.p, (int)c[C_N_MEMBERS]);
-    if (r != GSWT_OK) return wfail(w, r, gswt_last_error(ctx));
-    return GSWT_OK;
+    if (w->ctx != ctx) return GSWT_ERR_BAD_ARG;
+    int b;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        b = w->published;
+        if (b < 0) return GSWT_ERR_STATE;              // nothing fetched yet (gswt_worker_fetch publishes a sort event)
+        w->in_use = b;
+    }
+    const gswt_worker::HostSet& h = w->hs[b];
+    const uint32_t* c = h.counts;
+    const int r = gswt_set_draws_merge_groups(ctx, h.draws.p, (int)c[C_N_ORDER], h.groups.p, (int)c[C_N_GROUPS], h.members.p, (int)c[C_N_MEMBERS]);
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->in_use = -1;
+    }
+    return r;                                          // failure text: gswt_last_error(ctx)
 }
 
 }  // extern "C"

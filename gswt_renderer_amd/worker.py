@@ -70,6 +70,13 @@ class DeviceWorker:
         members = C.string_at(sd.members, sd.n_members * C.sizeof(L.MergeMember)) if sd.n_members else b""
         return tiles, groups, members, int(sd.n_tiles), int(sd.n_groups), int(sd.n_members), int(sd.n_merged)
 
-    def swap_in(self):
-        """gswt_set_draws_from_worker: the renderer's next frames use this sort event."""
-        self._check(self._lib.gswt_set_draws_from_worker(self._r._h, self._h))
+    def fetch(self):
+        """Worker thread: wait for the sort event and publish its records, groups and draws in host memory."""
+        self._check(self._lib.gswt_worker_fetch(self._h))
+
+    def swap_in(self, fetch: bool = True):
+        """gswt_set_draws_from_worker (render thread): the renderer's next frames use the sort event published last.
+        fetch=True is the single-threaded form (fetch, then swap in)."""
+        if fetch:
+            self.fetch()
+        self._r._check(self._lib.gswt_set_draws_from_worker(self._r._h, self._h))

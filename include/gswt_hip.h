@@ -437,12 +437,17 @@ GSWT_API int gswt_worker_set_cells(gswt_worker *w, const gswt_cell *cells, size_
 GSWT_API int gswt_worker_update_lod(gswt_worker *w, const float cam_pos[3]);
 /* sort_tiles (wangtile.rs:476-690): merge, order, views, records.  Enqueued on the worker's stream. */
 GSWT_API int gswt_worker_sort_tiles(gswt_worker *w, const float cam_pos[3], const float view_proj16[16]);
-/* Results to host memory (blocking on the worker's stream).  read_sort: pointers into worker-owned pinned memory, valid
- * until the next gswt_worker_sort_tiles. */
+/* Threads: every gswt_worker_* call belongs to ONE thread (the reference's worker thread); gswt_set_draws_from_worker belongs to
+ * the ctx's thread.  The two meet in three host-side result sets: gswt_worker_fetch waits for the worker's stream, copies the
+ * records, group descriptions and draws of the last sort event into a free set and publishes it; gswt_set_draws_from_worker
+ * takes the set published last (GSWT_ERR_STATE if there is none yet).  Neither waits for the other. */
+GSWT_API int gswt_worker_fetch(gswt_worker *w);
+/* Test hooks (worker thread, blocking).  read_sort fetches if needed; its pointers stay valid for two further fetches. */
 GSWT_API int gswt_worker_read_cell_state(gswt_worker *w, gswt_cell_state *out, size_t capacity);
 GSWT_API int gswt_worker_read_sort(gswt_worker *w, gswt_sort_data *out);
-/* Swap-in (state.rs:521-540 + renderer.rs:466-591 host half): TileUniforms / list selection per record on the device, then
- * gswt_set_draws_merge_groups' planning from the compact record array.  ctx must be the worker's ctx. */
+/* Swap-in (state.rs:521-540 + renderer.rs:466-591 host half): the draws were built on the device (TileUniforms, list
+ * selection, cull inputs per record); this runs gswt_set_draws_merge_groups' planning on the published set.  ctx must be the
+ * worker's ctx; a failure's text is in gswt_last_error(ctx). */
 GSWT_API int gswt_set_draws_from_worker(gswt_ctx *ctx, gswt_worker *w);
 
 GSWT_API int gswt_synchronize(gswt_ctx *ctx);
