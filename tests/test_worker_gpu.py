@@ -133,6 +133,22 @@ def test_graph_cycles_are_removed_like_petgraph():
         dw.close()
 
 
+def test_large_map_graph_tables_in_global_memory():
+    """57x57 cells: the graph tables (50 B per cell) no longer fit the LDS budget and k_w_order_seq runs from global scratch;
+    same bytes as the host, flat and on a steep height map (cycles)."""
+    from gswt_renderer_amd import host
+    from gswt_renderer_amd.worker import DeviceWorker
+    for surface, extra in [(host.SURFACE_NONE, {}), (host.SURFACE_HEIGHTMAP, dict(height_map_scale=(1.0, 1.0, 2.0), height_map_wh=(16, 16)))]:
+        pipe, _ = _pipe((28, 28), dict(surface_type=surface, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE, merge_topk=60,
+                                       merge_dot_threshold=0.5, lod_max_dist=40.0, **extra), lod0=60)
+        dw = DeviceWorker(pipe.renderer, pipe.wang)
+        for k, (pos, tgt) in enumerate([((3.0, -2.0, 6.0), (20.0, 30.0, 0.0)), ((-30.0, 12.0, 9.0), (0.0, 0.0, 0.0))]):
+            cu, vp = _cam(pos, tgt)
+            ref = _compare(pipe, dw, pos, vp, rebuild=True, tag=f"57x57 surface {surface} cam {k}")
+            assert ref["n"][0] > 3000
+        dw.close()
+
+
 def test_random_sweep_matches_host():
     """Random maps, parameters and cameras (Graph order + Edge merge, the reference's defaults, and the other modes)."""
     from gswt_renderer_amd import host
