@@ -427,7 +427,8 @@ typedef struct {
 } gswt_worker_config;
 
 typedef struct gswt_worker gswt_worker;
-/* Lives on ctx's device with a stream of its own (the reference's worker is a thread of its own, state.rs:478-561). */
+/* Lives on ctx's device with a stream of its own (the reference's worker is a thread of its own, state.rs:478-561).
+ * GSWT_ERR_CAPACITY: maps beyond 32 767 cells (u16 ids), or beyond ~17 700 cells with Edge merging (its LDS tables). */
 GSWT_API int gswt_worker_create(gswt_ctx *ctx, const gswt_worker_config *cfg, gswt_worker **out);
 GSWT_API void gswt_worker_destroy(gswt_worker *w);
 GSWT_API const char *gswt_worker_last_error(const gswt_worker *w);
