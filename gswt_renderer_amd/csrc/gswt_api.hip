@@ -27,7 +27,7 @@
 
 namespace gswt {
 void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t,
-                 uint32_t*, uint2*);
+                 uint32_t*, uint4*);
 void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
@@ -38,7 +38,7 @@ void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uin
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, uint32_t, const uint32_t*, const uint32_t*,
-                    const uint32_t*, const uint4*, const float*, const uint32_t*, const uint32_t*, uint32_t*, const uint2*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
+                    const uint32_t*, const uint4*, const float*, const uint32_t*, const uint32_t*, uint32_t*, const uint4*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
                     unsigned long long*, Varyings*, float4*, uint32_t);
 void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
@@ -200,7 +200,7 @@ struct FrameSlot {
     // per-frame HBM buffers
     DevBuf<uint2> rects;
     DevBuf<Rec> recs;
-    DevBuf<uint2> live_tab;                // this frame's launch table of k_project: the chunks of the draws that survive k_cull
+    DevBuf<uint4> live_tab;                // this frame's launch table of k_project: the chunks of the draws that survive k_cull
     DevBuf<uint32_t> live_cnt;             // entries per XCD list of live_tab (8 words; zero between frames)
     DevBuf<uint32_t> cell_culled;          // column-band shards: per map cell, 1 = no splat of that tile instance can reach the band
     DevBuf<uint32_t> block_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;

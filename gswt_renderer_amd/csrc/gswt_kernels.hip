@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
                                               uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
                                               uint32_t* __restrict__ zero_b, uint32_t n_zero_b,
                                               uint32_t* __restrict__ zero_c, uint32_t n_zero_c,
-                                              uint32_t* __restrict__ live_cnt, uint2* __restrict__ live_tab)
+                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab)
 {
     // eight lanes per draw: all of them evaluate the (cheap) cull, lane 0 of the eight keeps the flag and allocates the draw's range
     // of the live-chunk table, and the eight fill it together (a merged group has up to a few hundred chunks)
@@ -311,7 +311,10 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
     uint32_t pos = 0;
     if (live && sub == 0u) pos = atomicAdd(&live_cnt[x], nch);
     pos = (uint32_t)__shfl((int)pos, (int)((threadIdx.x & 63u) & ~7u), 64);           // from lane 0 of this draw's eight
-    for (uint32_t k = sub; k < nch; k += 8u) live_tab[(size_t)(pos + k) * 8u + x] = make_uint2(i, k * (uint32_t)kChunk);
+    // an entry carries what the chunk's first load needs -- the list position of its lane 0 and the list's length and arena -- so that
+    // k_project's list-word load does not wait for the draw record (one dependent round trip less in front of the gathers)
+    for (uint32_t k = sub; k < nch; k += 8u)
+        live_tab[(size_t)(pos + k) * 8u + x] = make_uint4(i, k * (uint32_t)kChunk, d.list_base + d.count - 1u - k * (uint32_t)kChunk, d.count | (d.merged ? 0x80000000u : 0u));
 }
 
 // ------------------------------------------------------------------------------------
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256) void k_project(
     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
     const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, const uint32_t* __restrict__ cell_culled,
-    const uint32_t* __restrict__ live_cnt, const uint2* __restrict__ live_tab, uint2* __restrict__ rects,
+    const uint32_t* __restrict__ live_cnt, const uint4* __restrict__ live_tab, uint2* __restrict__ rects,
     Rec* __restrict__ recs, float* __restrict__ depths, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
     Varyings* __restrict__ dbg, float4* __restrict__ col_f)
 {
@@ -347,12 +350,15 @@ __global__ __launch_bounds__(256) void k_project(
     // The normal frame launches over k_cull's table of live chunks (same layout, culled draws left out; workgroups past an XCD's
     // live count exit after one cached scalar load); the debug-varyings build visits every chunk through the static table.
     uint2 ct;
+    uint32_t list_top = 0, list_cnt = 0;      // non-DEBUG: list index of this chunk's lane 0, list length | merged << 31 (from k_cull)
     if (DEBUG) {
         ct = chunk_tab[blockIdx.x];
         if (ct.y == 0xFFFFFFFFu) return;    // padding of a short per-XCD list
     } else {
         if ((blockIdx.x >> 3) >= live_cnt[blockIdx.x & 7u]) return;
-        ct = live_tab[blockIdx.x];
+        const uint4 lt = live_tab[blockIdx.x];
+        ct = make_uint2(lt.x, lt.y);
+        list_top = lt.z; list_cnt = lt.w;
     }
     const DrawDev& d = draws[ct.x];
     const uint32_t tid = threadIdx.x;
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(256) void k_project(
 
     const uint32_t r = ct.y + tid;
     const uint32_t slot = d.slot_base + r;
-    const bool in_list = r < d.count;
+    const bool in_list = DEBUG ? r < d.count : r < (list_cnt & 0x7FFFFFFFu);
     uint32_t count = 0;
     bool visible = false;
     uint2 my_rect = make_uint2(1u, 0u);     // empty: tx0 = 1 > tx1 = 0
@@ -370,11 +376,13 @@ __global__ __launch_bounds__(256) void k_project(
                  vout.minor[0] = vout.minor[1] = 0.f; vout.rgba[0] = vout.rgba[1] = vout.rgba[2] = vout.rgba[3] = 0.f; }
 
     if (in_list && !s_culled) {
-        const uint32_t j = d.count - 1u - r;
-        const uint32_t* list = d.merged ? merged_list : static_list;
-        const uint32_t entry = list[d.list_base + j];
-        // the map id of a merged draw rides along with the list word (one round trip, not a third dependent one)
-        const uint32_t map_id_m = d.single_draw == 1u ? merged_map[d.list_base + j] : 0u;
+        // list word (and, for a merged draw, the map id beside it: one round trip, not a third dependent one).  The normal frame
+        // addresses it from the launch-table entry alone, so the load is in flight while the draw record is still being fetched.
+        const bool mrg = DEBUG ? d.merged != 0u : (list_cnt >> 31) != 0u;
+        const uint32_t li = DEBUG ? d.list_base + (d.count - 1u - r) : list_top - tid;
+        const uint32_t* list = mrg ? merged_list : static_list;
+        const uint32_t entry = list[li];
+        const uint32_t map_id_m = mrg ? merged_map[li] : 0u;
         const uint32_t gs_index = entry & kIdxMask;
         const uint32_t lod_id = entry >> kLodShift;
         do {
@@ -1760,7 +1768,7 @@ void launch_chunk_tabs(hipStream_t s, const DrawDev* draws, const uint32_t* xcd_
 
 void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, uint32_t* cell_culled, uint32_t n_cells,
                  uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b, uint32_t* zero_c, uint32_t n_zero_c,
-                 uint32_t* live_cnt, uint2* live_tab)
+                 uint32_t* live_cnt, uint4* live_tab)
 {
     uint32_t grid = (n_draws * 8u + 255u) / 256u;          // eight lanes per draw
     if (grid < 32) grid = 32;
@@ -1769,7 +1777,7 @@ void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
-                    const float* hmap, const uint32_t* draw_culled, const uint32_t* cell_culled, uint32_t* live_cnt, const uint2* live_tab, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
+                    const float* hmap, const uint32_t* draw_culled, const uint32_t* cell_culled, uint32_t* live_cnt, const uint4* live_tab, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
                     uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap)
 {
     if (n_chunks == 0) return;
