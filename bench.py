@@ -262,6 +262,7 @@ def main():
     ap.add_argument("--static-at", type=int, default=-1, help="static mode: use fly-path camera number K instead of the workload's own")
     ap.add_argument("--freeze-sort", action="store_true", help="fly path cameras without the worker: the first SortData stays (\"Lock (Sort)\" of the "
                     "reference GUI, gui.rs:599-605); separates the per-view workload from the cost of the sort events")
+    ap.add_argument("--no-defer-swap", action="store_true", help="fly path: every swap-in is current at once (the next frame waits for its merged-list build on the device)")
     ap.add_argument("--device-worker", action="store_true", help="fly path: run the per-sort-event worker stages on the GPU (gswt_worker_*) instead of libgswt_host")
     ap.add_argument("--static-steps", type=int, default=100, help="flypath mode: frames of the static-camera comparison run (0: skip)")
     args = ap.parse_args()
@@ -497,6 +498,12 @@ def main():
     if args.mode == "static" and args.static_at >= 0:
         swap_in(res_k)
     dev_worker = None
+    defer_swap = args.mode == "flypath" and world == 1 and not args.no_defer_swap
+    if defer_swap:
+        # a swap-in takes effect with the first frame submitted after its device-side list build has finished; frames submitted
+        # meanwhile keep the previous SortData (the reference's swap-in also lands one frame after the worker's message).  Not with
+        # N > 1: there every rank must switch at the same frame, and "finished" is a per-GPU event.
+        r.set_option(L.GSWT_OPT_DEFER_SWAP, 1)
     if args.mode == "flypath":
         if args.device_worker:
             from gswt_renderer_amd.worker import DeviceWorker
@@ -632,7 +639,8 @@ def main():
             "frames_in_flight": slots,
             "sort_events": {"swapped_in": swaps, "swap_in_ms_mean": float(np.mean(swap_ms)) if swap_ms else None,
                             "merged_groups_sorted": mg_built, "merged_groups_copied_from_previous_event": mg_reused,
-                            "note": "SortData swap-ins inside the timed region (gswt_set_draws_merge_groups: draw-list upload into the spare draw set + merged lists built on the device)"},
+                            "takes_effect": "first frame submitted after the event's device-side list build has finished (GSWT_OPT_DEFER_SWAP)" if defer_swap else "next frame (which waits for the build on the device)",
+                            "note": "SortData swap-ins inside the timed region (gswt_set_draws_merge_groups: draw-list upload into the spare draw set + merged lists built on the device, on a stream of their own)"},
             "worker_ms": worker_ms,
             "host_submit_ms_mean": float(np.mean(st["submit_ms"])) if st["submit_ms"] else None,
             "stage_ms": stage_ms,

@@ -28,6 +28,7 @@ GSWT_OPT_DEBUG_FLAGS = 4
 GSWT_OPT_TIMING = 5
 GSWT_OPT_PAIR_CAP = 6
 GSWT_OPT_NO_MERGE_REUSE = 7
+GSWT_OPT_DEFER_SWAP = 8
 GSWT_SHARD_ROWS = 0
 GSWT_SHARD_COLUMNS = 1
 

@@ -245,6 +245,11 @@ struct gswt_ctx {
     // draws
     DrawSet sets[kDrawSets];
     int cur_set = 0;                       // the set frames submitted from now on read
+    int latest_set = 0;                    // the set filled last (== cur_set unless a deferred swap-in is pending)
+    int pending_set = -1;                  // GSWT_OPT_DEFER_SWAP: filled, still being built on set_stream, not yet read by frames
+    hipStream_t set_stream = nullptr;      // uploads and device-side builds of a sort event: beside the frames, not in front of them
+    int opt_defer_swap = 0;
+    int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
     // on-device merged lists
     DevBuf<int32_t> raw_depth;
     std::vector<uint32_t> raw_off;          // [(lod*n_tile + tile)*n_view + view] -> offset in raw_depth
@@ -295,6 +300,7 @@ int fail(gswt_ctx* c, int code, const char* fmt, ...)
 hipError_t sync_all(gswt_ctx* c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
+    if (c->set_stream) { hipError_t e2 = hipStreamSynchronize(c->set_stream); if (e == hipSuccess) e = e2; }
     for (auto& sl : c->slots)
         if (sl.stream) { hipError_t e2 = hipStreamSynchronize(sl.stream); if (e == hipSuccess) e = e2; }
     return e;
@@ -429,6 +435,7 @@ try {
     if (!c) return GSWT_ERR_CAPACITY;
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&c->set_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
     for (auto& sl : c->slots) {
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         if (hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
@@ -464,6 +471,7 @@ void gswt_destroy(gswt_ctx* c)
         if (sl.stream) hipStreamDestroy(sl.stream);
     }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->set_stream) hipStreamDestroy(c->set_stream);
     delete c;
 }
 
@@ -490,6 +498,7 @@ try {
     case GSWT_OPT_DEBUG_FLAGS: c->opt_dbg_flags = value; return GSWT_OK;
     case GSWT_OPT_TIMING: c->opt_timing = value; return GSWT_OK;
     case GSWT_OPT_NO_MERGE_REUSE: c->opt_no_merge_reuse = value; return GSWT_OK;
+    case GSWT_OPT_DEFER_SWAP: c->opt_defer_swap = value; return GSWT_OK;
     case GSWT_OPT_PAIR_CAP:
         if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "pair capacity must be >= 0");
         c->opt_fixed_pair_cap = value > 0; if (value > 0) c->pair_cap = (uint32_t)value;
@@ -589,6 +598,30 @@ try {
 // merged_gs_index == nullptr && device_merge).
 // `device_merge`: called by gswt_set_draws_merge_groups, which has already planned the target set's upload block (it holds the
 // merge tables too) and issues the one copy + the chunk-table kernel itself once its own tables are in place.
+// Which draw set the next sort event fills, and when frames start reading it.  Sets rotate; the one after the set filled last is
+// free once the frames still reading it have been collected.  By default a new set is current at once (the next frame waits for its
+// build on the device).  With GSWT_OPT_DEFER_SWAP it becomes current with the first frame submitted AFTER its build has finished
+// on set_stream: frames submitted meanwhile keep the previous list and nothing waits -- the reference's swap-in likewise takes
+// effect with the frame after the worker's message (state.rs:361-376).  At most one set is pending: the next event makes it current.
+static void activate_pending(gswt_ctx* c, bool force)
+{
+    if (c->pending_set < 0) return;
+    DrawSet& P = c->sets[c->pending_set];
+    if (force || !P.ev_up || hipEventQuery(P.ev_up) == hipSuccess) { c->cur_set = c->pending_set; c->pending_set = -1; }
+}
+static int next_target(gswt_ctx* c)
+{
+    activate_pending(c, true);
+    return c->draws_ready ? (c->latest_set + 1) % kDrawSets : c->cur_set;
+}
+static void publish_set(gswt_ctx* c, int target)
+{
+    const bool first = !c->draws_ready || target == c->cur_set;
+    c->latest_set = target;
+    if (c->opt_defer_swap && !first) c->pending_set = target;
+    else { c->cur_set = target; c->pending_set = -1; }
+}
+
 static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, const uint32_t* merged_gs_index,
                           const uint32_t* merged_map_id, const uint32_t* merged_lod_id, size_t n_merged, bool device_merge)
 {
@@ -602,7 +635,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     // (only a frame still running on the set being refilled -- two sort events old -- is waited for), so a sort event
     // does not drain the frame pipeline.  The upload is asynchronous on the ctx stream from the set's pinned staging; every
     // frame submitted afterwards starts behind an event recorded on that stream (enqueue_frame).
-    const int target = c->draws_ready ? (c->cur_set + 1) % kDrawSets : c->cur_set;
+    const int target = device_merge ? c->merge_target : next_target(c);
     collect_set(c, target);
     DrawSet& D = c->sets[target];
     // the set's pinned staging is free again once its previous upload has been consumed
@@ -674,7 +707,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     for (int x = 0; x < 8; x++) D.per_xcd[x] = per_xcd[x];
     D.longest = longest;
     if (!device_merge) {
-        hipStream_t s = c->stream;
+        hipStream_t s = c->set_stream;
         HIP_TRY(c, hipMemcpyAsync(D.d_blob.p, D.h_blob.p, D.blob_bytes, hipMemcpyHostToDevice, s));      // the one upload of the event
         launch_chunk_tabs(s, D.draws.p, D.xcd_first.p, (uint32_t)n_draws, D.chunk_tab.p, D.chunk_tab_xcd.p, D.per_xcd, D.longest);
         HIP_TRY(c, hipGetLastError());
@@ -707,8 +740,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     D.n_chunks = (uint32_t)n_chunks;
     D.g_valid = false;
     D.n_entries = entries;
-    c->cur_set = target;
-    c->draws_ready = true;       // the per-frame buffers are sized by enqueue_frame, per slot
+    if (!device_merge) { publish_set(c, target); c->draws_ready = true; }      // (gswt_set_draws_merge_groups publishes behind its builds)
     return GSWT_OK;
 }
 
@@ -754,10 +786,11 @@ try {
     // previous draw set with the members' map ids rewritten -- the reference's LRU hit (wangtile.rs:575-593) -- and only
     // the other groups go through the segmented sort.  Everything is staged in the target set's pinned memory.
     hipSetDevice(c->device);
-    const int target = c->draws_ready ? (c->cur_set + 1) % kDrawSets : c->cur_set;
+    const int target = next_target(c);
+    c->merge_target = target;
     collect_set(c, target);
     DrawSet& D = c->sets[target];
-    const DrawSet* prev = (c->draws_ready && target != c->cur_set && c->sets[c->cur_set].g_valid && !c->opt_no_merge_reuse) ? &c->sets[c->cur_set] : nullptr;
+    const DrawSet* prev = (c->draws_ready && target != c->latest_set && c->sets[c->latest_set].g_valid && !c->opt_no_merge_reuse) ? &c->sets[c->latest_set] : nullptr;
     if (D.ev_up_pending) { HIP_TRY(c, hipEventSynchronize(D.ev_up)); D.ev_up_pending = false; }
     {   // upper bound of the merged entries (sizes the block tables of the upload block)
         size_t total_upper = 0;
@@ -858,8 +891,7 @@ try {
     D.g_members.assign(members, members + n_members);
     D.g_valid = true;
     c->stat_groups_built += n_build; c->stat_groups_reused += n_jobs;
-    c->draws_ready = false;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->set_stream;
     // block tables: every copy job / segment cut into runs of <= 1024 entries (what one workgroup handles)
     uint2* const h_cblocks = D.hp<uint2>(D.off_cblocks);
     uint2* const h_blocks = D.hp<uint2>(D.off_blocks);
@@ -894,6 +926,7 @@ try {
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(D.ev_up, s));
     D.ev_up_pending = true;
+    publish_set(c, target);
     c->draws_ready = true;
     return GSWT_OK;
 } GSWT_CATCH("gswt_set_draws_merge_groups")
@@ -1081,6 +1114,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // the output buffer, the device-side merged-list build and the draw bounds of its draw set), on the slot's own stream
     HIP_TRY(c, hipEventRecord(sl.ev_in, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(s, sl.ev_in, 0));
+    if (D.ev_up) HIP_TRY(c, hipStreamWaitEvent(s, D.ev_up, 0));        // and behind its draw set's upload / merged-list build (set_stream)
     if (sc > 1 && out_px > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
     const uint32_t n_cells = f.band_cull ? (2u * su->map_half_wh[0] + 1u) * (2u * su->map_half_wh[1] + 1u) : 0u;
@@ -1197,6 +1231,7 @@ try {
     for (int k = 0; k < kFrameSlots; k++) if (!c->slots[k].pending) { si0 = k; break; }
     FrameSlot& sl = c->slots[si0];
     if (sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render: every frame slot holds an uncollected gswt_render_async ticket");
+    activate_pending(c, false);
     sl.set = c->cur_set;
     fill_args(sl.args, cam, su, cfg, width, height, d_bg, d_bgd, d_out);
     rc = enqueue_frame(c, sl);
@@ -1232,6 +1267,7 @@ try {
         if (rc != GSWT_OK) return rc;
     }
     sl.seq = ++c->frame_seq;
+    activate_pending(c, false);
     sl.set = c->cur_set;
     fill_args(sl.args, cam, su, cfg, width, height, reinterpret_cast<const float4*>(bg_rgba_dev), bg_depth_dev,
               reinterpret_cast<float4*>(out_rgba_dev));

@@ -174,7 +174,10 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
        GSWT_OPT_TIMING = 5 /* hipEvent timing: 0 none, 1 frame + k_composite, 2 every stage (default) */,
        GSWT_OPT_PAIR_CAP = 6 /* test hook: pin the pair-buffer capacity to `value` pairs until a frame overflows it (0: automatic) */,
        GSWT_OPT_NO_MERGE_REUSE = 7 /* gswt_set_draws_merge_groups re-sorts every merged group at every sort event instead of copying
-                                      the groups that did not change since the previous one (results are identical) */ };
+                                      the groups that did not change since the previous one (results are identical) */,
+       GSWT_OPT_DEFER_SWAP = 8 /* 1: a gswt_set_draws* call takes effect with the first frame submitted AFTER its uploads and device-side
+                                  list builds have finished (frames submitted meanwhile keep the previous draw list and nothing waits);
+                                  0 (default): with the next frame, which then waits for them on the device */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

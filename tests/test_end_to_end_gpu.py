@@ -379,3 +379,42 @@ def test_merged_group_reuse_across_sort_events(renderer):
     for (img_a, l_a, m_a), (img_b, l_b, m_b) in zip(results[False][0], results[True][0]):
         assert np.array_equal(l_a, l_b) and np.array_equal(m_a, m_b)
         assert np.array_equal(img_a, img_b)
+
+
+def test_deferred_swap_in_takes_effect_once_built(renderer):
+    """GSWT_OPT_DEFER_SWAP: a sort event is read by the first frame submitted after its device-side build has finished; until then
+    frames keep the previous draw list, and the next event makes a still-pending one current.  After gswt_synchronize (which
+    also waits for the build stream) every event must have landed, in order, with the images of the immediate mode."""
+    from gswt_renderer_amd import _lib as L
+    cfg = dict(tile_map_half_wh=(4, 4), surface_type=0, lod_max_dist=22.0, tile_sort_type=3, merge_type=2, merge_topk=40)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=900)
+    W, Hh = 320, 200
+    path = [((4.2 + 0.35 * k, 1.0 + 0.5 * k, 1.5), (5.0 + 0.3 * k, 4.0 + 0.55 * k, 1.0)) for k in range(7)]
+    cams = [host.camera_uniforms(pos, tgt, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh) for pos, tgt in path]
+    cu_fix = cams[3][0]                                  # one camera for every image: only the draw list changes
+    ref = []
+    renderer.set_option(L.GSWT_OPT_DEFER_SWAP, 0)
+    pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer, device_merge=True)
+    for (pos, _), (cu, vp) in zip(path, cams):
+        pipe.update(pos, vp, force_sort=True)
+        ref.append(pipe.render(cu_fix, W, Hh))
+    pipe.update(path[1][0], cams[1][1], force_sort=True)
+    pipe.update(path[5][0], cams[5][1], force_sort=True)
+    ref_bb = pipe.render(cu_fix, W, Hh)
+    assert any(not np.array_equal(ref[0], r) for r in ref[1:])          # the events do change the image
+    renderer.set_option(L.GSWT_OPT_DEFER_SWAP, 1)
+    pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer, device_merge=True)
+    try:
+        for k, ((pos, _), (cu, vp)) in enumerate(zip(path, cams)):
+            pipe.update(pos, vp, force_sort=True)
+            early = pipe.render(cu_fix, W, Hh)          # may still be the previous event's list (never anything else)
+            assert np.array_equal(early, ref[k]) or (k > 0 and np.array_equal(early, ref[k - 1])), k
+            renderer.synchronize()
+            assert np.array_equal(pipe.render(cu_fix, W, Hh), ref[k]), k
+        # two events back to back: the second makes the first current, then lands itself
+        pipe.update(path[1][0], cams[1][1], force_sort=True)
+        pipe.update(path[5][0], cams[5][1], force_sort=True)
+        renderer.synchronize()
+        assert np.array_equal(pipe.render(cu_fix, W, Hh), ref_bb)
+    finally:
+        renderer.set_option(L.GSWT_OPT_DEFER_SWAP, 0)
