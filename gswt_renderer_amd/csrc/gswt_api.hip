@@ -156,6 +156,7 @@ struct DrawSet {
     bool g_valid = false;
     hipEvent_t ev_up = nullptr;            // behind the upload: the pinned block may be refilled once it has fired
     bool ev_up_pending = false;
+    bool built = false;                    // ev_up has been seen complete: frames on this set need not wait for it any more
     size_t n_merged = 0;
     uint32_t n_launch = 0;                 // length of chunk_tab_xcd (>= n_chunks: short per-XCD lists are padded)
     uint32_t n_draws = 0, n_chunks = 0;
@@ -248,6 +249,7 @@ struct gswt_ctx {
     int latest_set = 0;                    // the set filled last (== cur_set unless a deferred swap-in is pending)
     int pending_set = -1;                  // GSWT_OPT_DEFER_SWAP: filled, still being built on set_stream, not yet read by frames
     hipStream_t set_stream = nullptr;      // uploads and device-side builds of a sort event: beside the frames, not in front of them
+    hipStream_t pad_stream = nullptr;      // never used: steers the hardware-queue assignment (gswt_create)
     int opt_defer_swap = 0;
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
     // on-device merged lists
@@ -435,8 +437,13 @@ try {
     if (!c) return GSWT_ERR_CAPACITY;
     c->device = device_id;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
-    if (hipStreamCreateWithFlags(&c->set_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+    // Stream creation order matters: the runtime spreads streams over 4 hardware queues (GPU_MAX_HW_QUEUES) in creation order, and a
+    // frame slot that shares its queue with the ctx stream runs its frames behind whatever is recorded there.  A placeholder stream
+    // in front of the fourth slot keeps slots 0-2 on queues of their own and puts the build stream beside a slot, not beside the ctx
+    // (c3, one box: static camera 4 070 -> 4 900 frames/s, fly path unchanged; more hardware queues made the fly path slower).
+    int k_slot = 0;
     for (auto& sl : c->slots) {
+        if (k_slot++ == 3 && hipStreamCreateWithFlags(&c->pad_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         if (hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         for (auto& e : sl.ev)
@@ -445,6 +452,7 @@ try {
         memset(sl.hc, 0, 8 * sizeof(unsigned long long));
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.hc_dev), sl.hc, 0) != hipSuccess) sl.hc_dev = nullptr;   // then the copy stays
     }
+    if (hipStreamCreateWithFlags(&c->set_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
     *out = c;
     return GSWT_OK;
 } GSWT_CATCH("gswt_create")
@@ -472,6 +480,7 @@ void gswt_destroy(gswt_ctx* c)
     }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->set_stream) hipStreamDestroy(c->set_stream);
+    if (c->pad_stream) hipStreamDestroy(c->pad_stream);
     delete c;
 }
 
@@ -712,7 +721,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
         launch_chunk_tabs(s, D.draws.p, D.xcd_first.p, (uint32_t)n_draws, D.chunk_tab.p, D.chunk_tab_xcd.p, D.per_xcd, D.longest);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipEventRecord(D.ev_up, s));
-        D.ev_up_pending = true;
+        D.ev_up_pending = true; D.built = false;
     }
     // merged arrays: pack gs_index | lod << 28
     HIP_TRY(c, D.merged_list.ensure(n_merged + 1));
@@ -925,7 +934,7 @@ try {
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(D.ev_up, s));
-    D.ev_up_pending = true;
+    D.ev_up_pending = true; D.built = false;
     publish_set(c, target);
     c->draws_ready = true;
     return GSWT_OK;
@@ -1112,9 +1121,17 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // ---- cull (+ clears the frame's accumulators) + project
     // the frame starts after everything submitted to the ctx stream so far (inputs produced there, earlier readers of
     // the output buffer, the device-side merged-list build and the draw bounds of its draw set), on the slot's own stream
-    HIP_TRY(c, hipEventRecord(sl.ev_in, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(s, sl.ev_in, 0));
-    if (D.ev_up) HIP_TRY(c, hipStreamWaitEvent(s, D.ev_up, 0));        // and behind its draw set's upload / merged-list build (set_stream)
+    // (an idle ctx stream has nothing to wait for; a cross-stream event wait per frame is not free: c3 static camera 4 700 -> 4 900 frames/s)
+    if (hipStreamQuery(c->stream) != hipSuccess) {
+        HIP_TRY(c, hipEventRecord(sl.ev_in, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(s, sl.ev_in, 0));
+    }
+    // ... and behind its draw set's upload / merged-list build on set_stream, unless that has long finished (the usual case: a
+    // wait on another stream's event costs a barrier packet per frame)
+    if (D.ev_up && D.ev_up_pending && !D.built) {
+        if (hipEventQuery(D.ev_up) == hipSuccess) D.built = true;
+        else HIP_TRY(c, hipStreamWaitEvent(s, D.ev_up, 0));
+    }
     if (sc > 1 && out_px > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
     const uint32_t n_cells = f.band_cull ? (2u * su->map_half_wh[0] + 1u) * (2u * su->map_half_wh[1] + 1u) : 0u;
