@@ -505,9 +505,12 @@ def main():
     defer_swap = args.mode == "flypath" and world == 1 and not args.no_defer_swap
     if defer_swap:
         # a swap-in takes effect with the first frame submitted after its device-side list build has finished; frames submitted
-        # meanwhile keep the previous SortData (the reference's swap-in also lands one frame after the worker's message).  Not with
-        # N > 1: there every rank must switch at the same frame, and "finished" is a per-GPU event.
+        # meanwhile keep the previous SortData (the reference's swap-in also lands one frame after the worker's message)
         r.set_option(L.GSWT_OPT_DEFER_SWAP, 1)
+    elif args.mode == "flypath" and world > 1 and not args.no_defer_swap:
+        # N > 1: every rank must switch at the same frame, and "finished" is a per-GPU event: the swap-in lands with the third
+        # frame submitted after it on every rank (the build has two frames' time; a late one is waited for on the device)
+        r.set_option(L.GSWT_OPT_DEFER_SWAP, 3)
     if args.mode == "flypath":
         if args.device_worker:
             from gswt_renderer_amd.worker import DeviceWorker
@@ -653,7 +656,7 @@ def main():
             "frames_in_flight": slots,
             "sort_events": {"swapped_in": swaps, "swap_in_ms_mean": float(np.mean(swap_ms)) if swap_ms else None,
                             "merged_groups_sorted": mg_built, "merged_groups_copied_from_previous_event": mg_reused,
-                            "takes_effect": "first frame submitted after the event's device-side list build has finished (GSWT_OPT_DEFER_SWAP)" if defer_swap else "next frame (which waits for the build on the device)",
+                            "takes_effect": "first frame submitted after the event's device-side list build has finished (GSWT_OPT_DEFER_SWAP = 1)" if defer_swap else ("third frame submitted after the swap-in, on every rank (GSWT_OPT_DEFER_SWAP = 3)" if (world > 1 and args.mode == "flypath" and not args.no_defer_swap) else "next frame (which waits for the build on the device)"),
                             "note": "SortData swap-ins inside the timed region (gswt_set_draws_merge_groups: draw-list upload into the spare draw set + merged lists built on the device, on a stream of their own)"},
             "worker_ms": worker_ms,
             "host_submit_ms_mean": float(np.mean(st["submit_ms"])) if st["submit_ms"] else None,

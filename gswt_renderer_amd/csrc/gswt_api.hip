@@ -251,6 +251,7 @@ struct gswt_ctx {
     hipStream_t set_stream = nullptr;      // uploads and device-side builds of a sort event: beside the frames, not in front of them
     hipStream_t pad_stream = nullptr;      // never used: steers the hardware-queue assignment (gswt_create)
     int opt_defer_swap = 0;
+    int pending_frames = 0;                // GSWT_OPT_DEFER_SWAP >= 2: frames still to be submitted on the old set
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
     // on-device merged lists
     DevBuf<int32_t> raw_depth;
@@ -611,12 +612,17 @@ try {
 // free once the frames still reading it have been collected.  By default a new set is current at once (the next frame waits for its
 // build on the device).  With GSWT_OPT_DEFER_SWAP it becomes current with the first frame submitted AFTER its build has finished
 // on set_stream: frames submitted meanwhile keep the previous list and nothing waits -- the reference's swap-in likewise takes
-// effect with the frame after the worker's message (state.rs:361-376).  At most one set is pending: the next event makes it current.
+// effect with the frame after the worker's message (state.rs:361-376).  With a value n >= 2 it becomes current with the n-th frame
+// submitted after the call whatever the device is doing (that frame waits if the build is late): ranks that render the shards of
+// one frame stream then all switch at the same frame.  At most one set is pending: the next event makes it current.
 static void activate_pending(gswt_ctx* c, bool force)
 {
     if (c->pending_set < 0) return;
     DrawSet& P = c->sets[c->pending_set];
-    if (force || !P.ev_up || hipEventQuery(P.ev_up) == hipSuccess) { c->cur_set = c->pending_set; c->pending_set = -1; }
+    bool now = force;
+    if (!now && c->opt_defer_swap >= 2) now = c->pending_frames-- <= 0;                       // a fixed number of frames later: the same on every rank
+    else if (!now) now = !P.ev_up || hipEventQuery(P.ev_up) == hipSuccess;                    // as soon as it has been built
+    if (now) { c->cur_set = c->pending_set; c->pending_set = -1; }
 }
 static int next_target(gswt_ctx* c)
 {
@@ -627,7 +633,7 @@ static void publish_set(gswt_ctx* c, int target)
 {
     const bool first = !c->draws_ready || target == c->cur_set;
     c->latest_set = target;
-    if (c->opt_defer_swap && !first) c->pending_set = target;
+    if (c->opt_defer_swap && !first) { c->pending_set = target; c->pending_frames = c->opt_defer_swap - 1; }
     else { c->cur_set = target; c->pending_set = -1; }
 }
 

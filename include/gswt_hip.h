@@ -177,7 +177,9 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                       the groups that did not change since the previous one (results are identical) */,
        GSWT_OPT_DEFER_SWAP = 8 /* 1: a gswt_set_draws* call takes effect with the first frame submitted AFTER its uploads and device-side
                                   list builds have finished (frames submitted meanwhile keep the previous draw list and nothing waits);
-                                  0 (default): with the next frame, which then waits for them on the device */ };
+                                  n >= 2: with the n-th frame submitted after the call, finished or not (deterministic: for ranks that
+                                  render shards of the same frames); 0 (default): with the next frame, which then waits for them on
+                                  the device */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

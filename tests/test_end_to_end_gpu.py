@@ -416,5 +416,15 @@ def test_deferred_swap_in_takes_effect_once_built(renderer):
         pipe.update(path[5][0], cams[5][1], force_sort=True)
         renderer.synchronize()
         assert np.array_equal(pipe.render(cu_fix, W, Hh), ref_bb)
+        # value n >= 2: the n-th frame submitted after the call reads the new list, whatever the device is doing
+        renderer.set_option(L.GSWT_OPT_DEFER_SWAP, 3)
+        pipe.update(path[2][0], cams[2][1], force_sort=True)
+        before = pipe.render(cu_fix, W, Hh)
+        assert np.array_equal(before, ref_bb) and np.array_equal(pipe.render(cu_fix, W, Hh), ref_bb)
+        third = pipe.render(cu_fix, W, Hh)
+        assert not np.array_equal(third, ref_bb)
+        renderer.set_option(L.GSWT_OPT_DEFER_SWAP, 0)
+        pipe.update(path[2][0], cams[2][1], force_sort=True)
+        assert np.array_equal(pipe.render(cu_fix, W, Hh), third)
     finally:
         renderer.set_option(L.GSWT_OPT_DEFER_SWAP, 0)
