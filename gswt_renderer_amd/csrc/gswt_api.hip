@@ -1611,6 +1611,30 @@ try {
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_totals")
 
+int gswt_debug_sort(gswt_ctx* c, uint32_t* keys, uint32_t* vals, size_t n, int key_bits)
+try {
+    if (!c || !keys || !vals || n == 0 || n >= 0xFFFFFF00ull || key_bits < 1 || key_bits > 32) return GSWT_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    const uint32_t cap = (uint32_t)n;
+    DevBuf<uint32_t> ka, kb, va, vb, ws;
+    HIP_TRY(c, ka.ensure(n + 4)); HIP_TRY(c, kb.ensure(n + 4)); HIP_TRY(c, va.ensure(n + 1)); HIP_TRY(c, vb.ensure(n + 1));
+    const size_t words = radix_ws_words(cap, key_bits) + 16;
+    HIP_TRY(c, ws.ensure(words));
+    HIP_TRY(c, hipMemset(ws.p, 0, words * 4));
+    // the item count lives in device memory, as in a frame: {n, -, overflow flag = 0} in front of the histograms
+    unsigned long long hn[4] = {(unsigned long long)n, 0ull, 0ull, 0ull};
+    HIP_TRY(c, hipMemcpy(ws.p, hn, 32, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(ka.p, keys, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(va.p, vals, n * 4, hipMemcpyHostToDevice));
+    const int where = launch_sort(c->stream, ka.p, va.p, kb.p, vb.p, cap, reinterpret_cast<const unsigned long long*>(ws.p), key_bits, ws.p + 16);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(keys, where ? kb.p : ka.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(vals, where ? vb.p : va.p, n * 4, hipMemcpyDeviceToHost));
+    ka.release(); kb.release(); va.release(); vb.release(); ws.release();
+    return GSWT_OK;
+} GSWT_CATCH("gswt_debug_sort")
+
 int gswt_debug_merge_stats(const gswt_ctx* c, unsigned long long out[2])
 {
     if (!c || !out) return GSWT_ERR_BAD_ARG;

@@ -786,53 +786,76 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
 // A workgroup takes kEmitGroup consecutive chunks: most chunks emit nothing (culled draws, LOD rings) and a workgroup
 // that only learns so from a load costs a full memory round trip per chunk -- with one chunk per workgroup the kernel ran
 // as (chunks / 2048 resident workgroups) x ~1.07 us: 22 us on c3, 190 us on c5's 365 k chunks.
-// (The four chunks side by side in a 1024-thread workgroup with a single barrier: 32 us at c3 -- four times the waves for the
-// empty groups; per-slot pair offsets left by k_project so that no per-chunk scan is needed here: 18 us, +1.3 us there, no gain.)
-constexpr uint32_t kEmitGroup = 4;          // divides 256: a workgroup's chunks share one super-group
+// Measured and dropped: the four chunks side by side in a 1024-thread workgroup with a single barrier (32 us at c3 -- four times
+// the waves for the empty groups); per-slot pair offsets left by k_project so that no per-chunk scan is needed here (18 us, +1.3 us
+// there, no gain); groups of 8 / 16 (serialise the live chunks: 26 / 35 us at c3); launching over k_cull's table of LIVE chunks
+// (what k_project does: 18 k of c3's 39 k chunks, 76 k of c5's 366 k; groups of 1 / 2 / 4 table entries): one more dependent load in
+// front of everything, 24 / 22 / 24 us at c3 and 223 / 170 / 143 us at c5 against 23 / 130 for four consecutive chunks (stage
+// events, gpurun_out s6) -- the workgroups of empty groups are not what the kernel's time is made of.
+constexpr uint32_t kEmitGroup = 4;
+
+// block-wide (256 threads): exclusive scan of v and, in the same barrier pair, the sum of r
+__device__ __forceinline__ uint32_t block_scan_and_sum(uint32_t v, uint32_t r, uint32_t* s_w /*[8]*/, uint32_t* v_total, uint32_t* r_total)
+{
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+    if (lane == 63u) s_w[w] = inc;
+    if (lane == 0u) s_w[4u + w] = r;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < w; i++) base += s_w[i];
+    *v_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    *r_total = s_w[4] + s_w[5] + s_w[6] + s_w[7];
+    __syncthreads();
+    return base + inc - v;
+}
+
 __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __restrict__ rects,
                                               const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ super_excl,
                                               uint32_t n_chunks, uint32_t pair_cap, unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
 {
-    __shared__ uint32_t s_w[4];
-    const uint32_t c0 = blockIdx.x * kEmitGroup;
-    // All loads are issued together with clamped indices (masked loads are waited for one at a time): the chunks' pair
-    // counts, the two-level sums in front of them, and the tile rects of this thread's slot in every chunk.
-    const uint32_t sup = c0 >> 8;
-    const uint32_t cj = (sup << 8) + threadIdx.x;
-    uint32_t sums[kEmitGroup];
+    __shared__ uint32_t s_w[8];
+    uint32_t cid[kEmitGroup], sums[kEmitGroup], bs[kEmitGroup], sbase[kEmitGroup];
     uint2 rcs[kEmitGroup];
+    const uint32_t c0 = blockIdx.x * kEmitGroup;
+    const uint32_t n_mine = min(kEmitGroup, n_chunks - c0);
 #pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++) sums[k] = block_sums[min(c0 + k, n_chunks - 1u)];
-    const uint32_t bs = block_sums[min(cj, c0)];
-    const uint32_t sbase = super_excl[sup];                          // pairs of all chunks before this super-group (k_totals)
+    for (uint32_t k = 0; k < kEmitGroup; k++) cid[k] = min(c0 + k, n_chunks - 1u);
+    // All loads are issued together with clamped indices (masked loads are waited for one at a time): the chunks' pair counts, the
+    // sums of the chunks in front of each inside its super-group, the super-group prefixes and the tile rects of this thread's slot
+    // in every chunk.
 #pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++)                        // only meaningful when sums[k] != 0 (k_project wrote it then)
-        rcs[k] = rects[(size_t)min(c0 + k, n_chunks - 1u) * 256u + threadIdx.x];
+    for (uint32_t k = 0; k < kEmitGroup; k++) {
+        sums[k] = block_sums[cid[k]];
+        bs[k] = block_sums[min((cid[k] & ~255u) + threadIdx.x, cid[k])];
+        sbase[k] = super_excl[cid[k] >> 8];                          // pairs of all chunks before the chunk's super-group (k_totals)
+        rcs[k] = rects[(size_t)cid[k] * 256u + threadIdx.x];         // only meaningful when sums[k] != 0 (k_project wrote it then)
+    }
     uint32_t any = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++) { if (c0 + k >= n_chunks) sums[k] = 0u; any |= sums[k]; }
+    for (uint32_t k = 0; k < kEmitGroup; k++) { if (k >= n_mine) sums[k] = 0u; any |= sums[k]; }
     if (any == 0u) return;
-    // first pair of the first chunk = pairs of the earlier super-groups + of the earlier chunks of its own group
-    uint32_t chunk_base;
-    (void)block_excl_scan(cj < c0 ? bs : 0u, s_w, &chunk_base);
-    chunk_base += sbase;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
 #pragma unroll
     for (uint32_t k = 0; k < kEmitGroup; k++) {
         if (sums[k] == 0u) continue;                                 // workgroup-uniform
         const uint2 rc = rcs[k];
-        const uint32_t slot = (c0 + k) * 256u + threadIdx.x;
+        const uint32_t slot = cid[k] * 256u + threadIdx.x;
         const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
         uint32_t count = 0;
         if (tx1 >= tx0) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
-        uint32_t tot;
-        uint32_t off = chunk_base + block_excl_scan(count, s_w, &tot);
+        // first pair of the chunk = pairs of the earlier super-groups + of the earlier chunks of its own group; one barrier pair
+        // yields that sum and the exclusive scan of this chunk's per-slot pair counts
+        uint32_t tot, chunk_base;
+        uint32_t off = block_scan_and_sum(count, (cid[k] & ~255u) + threadIdx.x < cid[k] ? bs[k] : 0u, s_w, &tot, &chunk_base);
+        chunk_base += sbase[k];
+        off += chunk_base;
         if ((unsigned long long)chunk_base + tot > (unsigned long long)pair_cap) {   // pair buffers too small: host re-runs the frame
             if (threadIdx.x == 0) atomicOr(&counters[3], 1ull);
             return;
         }
-        chunk_base += sums[k];
         if (count == 0) continue;
         int ty = ty0;
         if (sc > 1) ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc;
@@ -868,7 +891,7 @@ __device__ __forceinline__ uint32_t clamped_count(const unsigned long long* n_pt
 // 77 / 69 / 76 us (other splits of the block: 1024x8 78, 512x16 82, 1024x2 95, 512x4 84).  launch_sort picks 512 threads up
 // to kSortWideMax pairs of capacity and 256 above.
 constexpr int kSortBlock = 4096;
-constexpr uint32_t kSortWideMax = 8u << 20;     // pair capacities up to this use 512-thread workgroups
+constexpr uint32_t kSortWideMax = 0xFFFFFFFFu;  // pair capacities up to this use 512-thread workgroups (every size since k_radix_supscan: the 256-thread build only won at c5 while each workgroup summed ~100 group rows)
 
 // Per pass: k_radix_hist leaves, for every digit d, the per-workgroup counts ghist[d][blk], the sums over
 // groups of 32 workgroups gsup[d][blk >> 5] and the digit totals gtot[d] (integer atomics, spread over
@@ -908,11 +931,24 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
         uint32_t key[kSortItems];
 #pragma unroll
         for (int k = 0; k < kSortItems; k++) key[k] = keys[min(base + (uint32_t)k * 64u + lane, n - 1u)];
-        // (one add per distinct digit of a round through match-any, as k_radix_scatter counts, was measured here: 12.1 us against
-        // 11.2 -- eight ballots per round cost this short kernel more than the same-address serialisation of the LDS adds)
+        // One LDS add per RUN of equal digits in a round, by the run's first lane: pairs of one screen tile are neighbours from the
+        // second pass on (the first pass ordered them by the low digit, stably), so a round's 64 lanes used to add 1 to the same one
+        // or two LDS words, which the LDS serialises -- the second pass's histogram took 13 us at c3 and 85 us at c5 against 4.7 / 28
+        // for the first.  (One add per distinct digit through match-any, as k_radix_scatter counts, was measured here earlier: 12.1 us
+        // against 11.2 -- eight ballots per round; a run needs one lane shift and one ballot.)
 #pragma unroll
-        for (int k = 0; k < kSortItems; k++)
-            if (base + (uint32_t)k * 64u + lane < n) atomicAdd(&s_h[(key[k] >> shift) & mask], 1u);
+        for (int k = 0; k < kSortItems; k++) {
+            const bool valid = base + (uint32_t)k * 64u + lane < n;           // valid lanes are a prefix of the wave
+            const uint32_t dgt = (key[k] >> shift) & mask;
+            const uint32_t prev = (uint32_t)__shfl_up((int)dgt, 1, 64);
+            const unsigned long long heads = __ballot(valid && (lane == 0u || prev != dgt));
+            const unsigned long long vmask = __ballot(valid);
+            if ((heads >> lane) & 1ull) {
+                const unsigned long long later = heads & ~((2ull << lane) - 1ull);      // run heads behind this lane
+                const uint32_t end = later ? (uint32_t)__ffsll((long long)later) - 1u : (uint32_t)__popcll(vmask);
+                atomicAdd(&s_h[dgt], end - lane);
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x >= 256u) return;
@@ -921,11 +957,35 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
     ghist[blockIdx.x * 256u + threadIdx.x] = cnt;
     if (cnt) {
         atomicAdd(&gsup[(blockIdx.x >> kSupShift) * 256u + threadIdx.x], cnt);
-        // digit totals: with few groups k_radix_scatter sums the group rows itself -- every workgroup adding to the same 256 words
-        // (650 adds per word at c3) is the most contended traffic of the sort
-        if (nsup > kSupDirect) atomicAdd(&gtot[threadIdx.x], cnt);
+        // digit totals: with few groups k_radix_scatter sums the group rows itself, with many k_radix_supscan leaves them -- every
+        // workgroup adding to the same 256 words (650 adds per word at c3, 5 300 at c5) was the most contended traffic of the sort
     }
-    (void)nblk; (void)nbits;
+    (void)nblk; (void)nbits; (void)gtot; (void)nsup;
+}
+
+// Large sorts only (more than kSupDirect groups of 32 workgroups: above ~4 M items): turns the group rows gsup[group][digit] into
+// their exclusive prefix over the groups and leaves the digit totals in gtot.  Without it every scatter workgroup summed the rows of
+// all groups in front of it -- at c5 (21.8 M pairs, 208 groups) on average 104 KB of L2 reads per workgroup, 690 MB per pass, more than
+// the pass moves in keys and values -- and the digit totals were 5 300-way contended atomics.  One wave per digit, 64 groups per round.
+__global__ __launch_bounds__(256) void k_radix_supscan(uint32_t* __restrict__ gsup, uint32_t* __restrict__ gtot, uint32_t nsup)
+{
+    const uint32_t lane = threadIdx.x & 63u, d = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t carry = 0;
+    for (uint32_t g0 = 0; g0 < nsup; g0 += 256u) {
+        // four rounds of loads in flight together (clamped, unmasked)
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) v[k] = gsup[(size_t)min(g0 + k * 64u + lane, nsup - 1u) * 256u + d];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t g = g0 + k * 64u + lane;
+            const uint32_t x = g < nsup ? v[k] : 0u;
+            const uint32_t inc = wave_incl_scan(x, lane);
+            if (g < nsup) gsup[(size_t)g * 256u + d] = carry + inc - x;
+            carry += (uint32_t)__shfl((int)inc, 63, 64);
+        }
+    }
+    if (lane == 0u) gtot[d] = carry;
 }
 
 // The block's 4096 items are first ranked INTO LDS (sorted by digit inside the block), then copied out: consecutive threads
@@ -982,15 +1042,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
             for (uint32_t u = 0; u < kSupDirect; u++) g[u] = gsup[min(u, nsup - 1u) * 256u + d];
 #pragma unroll
             for (uint32_t u = 0; u < kSupDirect; u++) { if (u < nsup) g_tot += g[u]; if (u < sb) pre += g[u]; }
-        } else {
+        } else {                                                                 // k_radix_supscan ran: exclusive group prefixes + digit totals
             g_tot = gtot[d];
-            for (uint32_t j0 = 0; j0 < sb; j0 += 16u) {                          // earlier groups, 16 loads in flight
-                uint32_t g[16];
-#pragma unroll
-                for (uint32_t u = 0; u < 16u; u++) g[u] = gsup[min(j0 + u, nsup - 1u) * 256u + d];
-#pragma unroll
-                for (uint32_t u = 0; u < 16u; u++) if (j0 + u < sb) pre += g[u];
-            }
+            pre = gsup[(size_t)sb * 256u + d];
         }
 #pragma unroll
         for (uint32_t u = 0; u < 32u; u++) if ((sb << kSupShift) + u < blockIdx.x) pre += t[u];
@@ -1718,12 +1772,21 @@ __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* 
     const int px = (tx + f.col0) * kTile + lxi, py = ty * kTile + lyi;
     if (px >= f.width || py >= f.height) return;
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
-    for (uint32_t sidx = 0; sidx < n_seg; sidx++) {
-        const float4 p = partials[(size_t)(i0 + sidx) * 256u + tid];
-        ar = fmaf(T, p.x, ar);
-        ag = fmaf(T, p.y, ag);
-        ab = fmaf(T, p.z, ab);
-        T = T * p.w;
+    // eight segments' partials in flight together (clamped, unmasked): a horizon tile of c5 has 40 segments, and one dependent
+    // 4-KB load per segment made the longest tile the kernel's duration (59 us at c5)
+    for (uint32_t s0 = 0; s0 < n_seg; s0 += 8u) {
+        float4 p[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) p[k] = partials[(size_t)(i0 + min(s0 + k, n_seg - 1u)) * 256u + tid];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; k++) {
+            if (s0 + k < n_seg) {                 // workgroup-uniform
+                ar = fmaf(T, p[k].x, ar);
+                ag = fmaf(T, p[k].y, ag);
+                ab = fmaf(T, p[k].z, ab);
+                T = T * p[k].w;
+            }
+        }
     }
     float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bg_rgba) bg = bg_rgba[(size_t)py * f.width + px];
@@ -1836,7 +1899,9 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
 {
     if (n_cap == 0) return 0;
     const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
-    const int threads = n_cap <= kSortWideMax ? 512 : 256;
+    // (GSWT_SORT_WIDE_MAX_M: tuning override of kSortWideMax in units of 2^20 items, read once)
+    static const uint32_t wide_max = [] { const char* e = getenv("GSWT_SORT_WIDE_MAX_M"); return e ? (uint32_t)atoi(e) << 20 : kSortWideMax; }();
+    const int threads = n_cap <= wide_max ? 512 : 256;
     int cur = 0;
     for (int shift = 0; shift < key_bits; shift += 8) {
         uint32_t nbits = (uint32_t)((key_bits - shift) < 8 ? (key_bits - shift) : 8);
@@ -1847,6 +1912,7 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
 #define GSWT_SORT_PASS(T)                                                                                                        \
         hipLaunchKernelGGL(k_radix_hist<T>, dim3(nblk), dim3(T), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup); \
+        if (nsup > kSupDirect) hipLaunchKernelGGL(k_radix_supscan, dim3(64), dim3(256), 0, s, gsup, gtot, nsup);                          \
         hipLaunchKernelGGL(k_radix_scatter<T>, dim3(nblk), dim3(T), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
                            ghist, gsup, gtot, nblk, nsup)
         if (threads == 512) { GSWT_SORT_PASS(512); }

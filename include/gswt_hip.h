@@ -470,6 +470,11 @@ GSWT_API int gswt_debug_read_projected(gswt_ctx *ctx, void *out, size_t capacity
 GSWT_API int gswt_debug_totals(gswt_ctx *ctx, const uint32_t *pair_sums, const uint32_t *visible_sums, uint32_t n_super,
                                uint32_t pair_cap, unsigned long long counters_out[4], uint32_t *super_excl_out);
 
+/* Test hook: the frame's stable LSD radix sort alone (k_radix_hist / k_radix_supscan / k_radix_scatter) on the low `key_bits` bits
+ * of n (key, value) pairs, in place.  Equal keys keep their input order (the order contract of scene.rs:685-695 rests on it).
+ * Host pointers. */
+GSWT_API int gswt_debug_sort(gswt_ctx *ctx, uint32_t *keys, uint32_t *vals, size_t n, int key_bits);
+
 /* Merged groups sorted / copied from the previous sort event by gswt_set_draws_merge_groups since gswt_create. */
 GSWT_API int gswt_debug_merge_stats(const gswt_ctx *ctx, unsigned long long out[2]);
 

@@ -250,3 +250,26 @@ def test_pair_total_is_carried_in_64_bits(renderer):
         assert (cnt[3] != 0) == (total > cap)
         want = np.concatenate([np.zeros(1, np.uint64), np.cumsum(pairs.astype(np.uint64))[:-1]]) & np.uint64(0xFFFFFFFF)
         assert np.array_equal(excl.astype(np.uint64), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,key_bits", [(1, 13), (4095, 13), (4097, 5), (1 << 20, 13), (5_000_003, 15), (12_345_678, 15), (9_000_000, 32)])
+def test_radix_sort_is_stable_at_every_size(renderer, n, key_bits):
+    """The frame's radix sort alone (gswt_debug_sort) against numpy's stable sort: one workgroup, a ragged last block, the
+    direct group sums (<= 32 groups of 32 workgroups), k_radix_supscan's group prefixes (more), the 256-thread build (> 8 M
+    items) and a four-pass 32-bit sort (the depth order's).  Keys are skewed the way pair keys are (runs of equal tiles)."""
+    rng = np.random.default_rng(n ^ key_bits)
+    runs = rng.integers(0, 1 << min(key_bits, 31), size=max(1, n // 3), dtype=np.uint64).astype(np.uint32)
+    keys = np.repeat(runs, 3)[:n].copy() if n >= 3 else runs[:n].copy()
+    if len(keys) < n:
+        keys = np.concatenate([keys, rng.integers(0, 1 << min(key_bits, 31), size=n - len(keys), dtype=np.uint64).astype(np.uint32)])
+    if key_bits == 32:
+        keys ^= rng.integers(0, 2, size=n, dtype=np.uint64).astype(np.uint32) << np.uint32(31)
+    vals = np.arange(n, dtype=np.uint32)
+    order = np.argsort(keys, kind="stable")
+    k2, v2 = keys.copy(), vals.copy()
+    lib = L.load()
+    rc = lib.gswt_debug_sort(renderer._h, k2.ctypes.data, v2.ctypes.data, n, key_bits)
+    assert rc == 0, renderer.last_error() if hasattr(renderer, "last_error") else rc
+    assert np.array_equal(k2, keys[order])
+    assert np.array_equal(v2, vals[order])          # equal keys keep their input order
