@@ -333,6 +333,9 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
 // (5) four table entries per workgroup, flags of the group fetched together and culled chunks settled at once (what
 // paid in k_emit): unrolled, four inlined bodies = 77 VGPRs, 95 -> 101 us and c5 unchanged (527 frames/s); as a loop
 // around one body the uniform float sub-expressions are hoisted into VGPRs (85).
+// (6) the static lists a second time as 32-byte records in list order (plain / blending draws read 256 consecutive records,
+// coalesced, addressed from the launch-table entry alone: no list word, no dependent gather; 150 MB at c3): 91.8 -> 88.2 us at c3,
+// 128.1 -> 128.6 on the HeightMap surface, 461 -> 457 at c5 (stage events) -- the gather latency is hidden by the other waves.
 template <bool DEBUG, bool FULL>
 __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
@@ -967,6 +970,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
 // their exclusive prefix over the groups and leaves the digit totals in gtot.  Without it every scatter workgroup summed the rows of
 // all groups in front of it -- at c5 (21.8 M pairs, 208 groups) on average 104 KB of L2 reads per workgroup, 690 MB per pass, more than
 // the pass moves in keys and values -- and the digit totals were 5 300-way contended atomics.  One wave per digit, 64 groups per round.
+// (Summing up to 64 group rows in the scatter workgroups, two rounds of 32, so that the fly path's frames whose pair capacity
+// crosses 4 M pairs need no launch of this kernel: 4 219 / 4 139 frames/s against 4 262 / 4 240 with it, same box -- not better.)
 __global__ __launch_bounds__(256) void k_radix_supscan(uint32_t* __restrict__ gsup, uint32_t* __restrict__ gtot, uint32_t nsup)
 {
     const uint32_t lane = threadIdx.x & 63u, d = blockIdx.x * 4u + (threadIdx.x >> 6);
