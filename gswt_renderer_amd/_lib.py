@@ -29,6 +29,7 @@ GSWT_OPT_TIMING = 5
 GSWT_OPT_PAIR_CAP = 6
 GSWT_OPT_NO_MERGE_REUSE = 7
 GSWT_OPT_DEFER_SWAP = 8
+GSWT_OPT_GRAPH = 9
 GSWT_SHARD_ROWS = 0
 GSWT_SHARD_COLUMNS = 1
 
@@ -196,6 +197,7 @@ SYMBOLS = {
     "gswt_debug_merge_stats": (C.c_int, [_P, _P]),
     "gswt_debug_totals": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "gswt_debug_sort": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
+    "gswt_debug_graph_stats": (C.c_int, [_P, _P]),
 }
 
 _lib = None

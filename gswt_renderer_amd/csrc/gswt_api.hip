@@ -212,6 +212,19 @@ struct FrameSlot {
     DevBuf<float4> partials;
     DevBuf<float4> col_f;                  // debug draw modes: float colours per slot
     DevBuf<float> depths;                  // per-slot depth: frames with a proxy depth buffer or GSWT_ORDER_DEPTH only
+    // hipGraph replay (GSWT_OPT_GRAPH): the chain of kernel nodes of this slot's frames and the argument records they were last set to
+    GraphRec grec;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipGraphNode_t graph_nodes[24] = {};
+    GraphNodeRec graph_last[24];
+    uint32_t graph_n = 0;
+    void release_graph()
+    {
+        if (graph_exec) hipGraphExecDestroy(graph_exec);
+        if (graph) hipGraphDestroy(graph);
+        graph_exec = nullptr; graph = nullptr; graph_n = 0;
+    }
     void release_buffers()
     {
         rects.release(); recs.release(); cell_culled.release(); live_tab.release(); live_cnt.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
@@ -251,6 +264,8 @@ struct gswt_ctx {
     hipStream_t set_stream = nullptr;      // uploads and device-side builds of a sort event: beside the frames, not in front of them
     hipStream_t pad_stream = nullptr;      // never used: steers the hardware-queue assignment (gswt_create)
     int opt_defer_swap = 0;
+    int opt_graph = 0;
+    unsigned long long stat_graph_launches = 0, stat_graph_rebuilds = 0, stat_graph_node_updates = 0;
     int pending_frames = 0;                // GSWT_OPT_DEFER_SWAP >= 2: frames still to be submitted on the old set
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
     // on-device merged lists
@@ -473,6 +488,7 @@ void gswt_destroy(gswt_ctx* c)
     c->raw_depth.release(); 
     c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
     for (auto& sl : c->slots) {
+        sl.release_graph();
         sl.release_buffers();
         for (auto& e : sl.ev) if (e) hipEventDestroy(e);
         if (sl.ev_in) hipEventDestroy(sl.ev_in);
@@ -509,6 +525,7 @@ try {
     case GSWT_OPT_TIMING: c->opt_timing = value; return GSWT_OK;
     case GSWT_OPT_NO_MERGE_REUSE: c->opt_no_merge_reuse = value; return GSWT_OK;
     case GSWT_OPT_DEFER_SWAP: c->opt_defer_swap = value; return GSWT_OK;
+    case GSWT_OPT_GRAPH: c->opt_graph = value; return GSWT_OK;
     case GSWT_OPT_PAIR_CAP:
         if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "pair capacity must be >= 0");
         c->opt_fixed_pair_cap = value > 0; if (value > 0) c->pair_cap = (uint32_t)value;
@@ -1013,6 +1030,52 @@ static int validate_frame(gswt_ctx* c, const gswt_camera_uniforms* cam, const gs
 }
 
 // Enqueues every kernel of one frame on the ctx stream.  All pointers in `a` are device pointers.
+// GSWT_OPT_GRAPH: the frame's launch sequence was recorded, not launched (gswt_device.h); replay it as one hipGraphLaunch on the
+// slot's stream.  The graph is a chain of kernel nodes; it is rebuilt when the sequence of kernels changes (another template
+// variant, a k_radix_supscan more or less) and otherwise only the nodes whose grid or arguments differ from the previous frame of
+// this slot are updated in the executable graph: with a moving camera the five kernels that take the frame constants, after a
+// sort event also those that take draw-set pointers or sizes.
+static int replay_graph(gswt_ctx* c, FrameSlot& sl)
+{
+    GraphRec& R = sl.grec;
+    if (R.overflow || R.n == 0) return fail(c, GSWT_ERR_STATE, "gswt_render: frame graph record overflow");
+    bool rebuild = !sl.graph_exec || sl.graph_n != R.n;
+    for (uint32_t i = 0; !rebuild && i < R.n; i++) rebuild = sl.graph_last[i].fn != R.nodes[i].fn;
+    void* ptrs[40];
+    auto fill = [&](GraphNodeRec& nd, hipKernelNodeParams& kp) {
+        memset(&kp, 0, sizeof(kp));
+        for (uint32_t a = 0; a < nd.n_args; a++) ptrs[a] = nd.args + nd.offs[a];
+        kp.func = const_cast<void*>(nd.fn);
+        kp.gridDim = nd.grid; kp.blockDim = nd.block; kp.sharedMemBytes = 0;
+        kp.kernelParams = ptrs; kp.extra = nullptr;
+    };
+    if (rebuild) {
+        sl.release_graph();
+        HIP_TRY(c, hipGraphCreate(&sl.graph, 0));
+        for (uint32_t i = 0; i < R.n; i++) {
+            hipKernelNodeParams kp;
+            fill(R.nodes[i], kp);
+            HIP_TRY(c, hipGraphAddKernelNode(&sl.graph_nodes[i], sl.graph, i ? &sl.graph_nodes[i - 1] : nullptr, i ? 1 : 0, &kp));
+            sl.graph_last[i] = R.nodes[i];
+        }
+        HIP_TRY(c, hipGraphInstantiate(&sl.graph_exec, sl.graph, nullptr, nullptr, 0));
+        sl.graph_n = R.n;
+        c->stat_graph_rebuilds++;
+    } else {
+        for (uint32_t i = 0; i < R.n; i++) {
+            if (sl.graph_last[i].same(R.nodes[i])) continue;
+            hipKernelNodeParams kp;
+            fill(R.nodes[i], kp);
+            HIP_TRY(c, hipGraphExecKernelNodeSetParams(sl.graph_exec, sl.graph_nodes[i], &kp));
+            sl.graph_last[i] = R.nodes[i];
+            c->stat_graph_node_updates++;
+        }
+    }
+    HIP_TRY(c, hipGraphLaunch(sl.graph_exec, sl.stream));
+    c->stat_graph_launches++;
+    return GSWT_OK;
+}
+
 static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
 {
     const FrameArgs& a = sl.args;
@@ -1139,6 +1202,13 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         else HIP_TRY(c, hipStreamWaitEvent(s, D.ev_up, 0));
     }
     if (sc > 1 && out_px > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
+    // GSWT_OPT_GRAPH: from here to the end of the frame the launch sites record instead of launching (frames that carry timing
+    // events, the depth-ordered path with its host-to-device word, debug varyings and shards without tiles launch as before)
+    const bool use_graph = c->opt_graph != 0 && c->opt_timing == 0 && !depth_order && !dbg && n_tiles > 0 && sl.hc_dev != nullptr;
+    struct RecorderScope {
+        explicit RecorderScope(GraphRec* r) { if (r) { r->n = 0; r->overflow = false; } graph_recorder() = r; }
+        ~RecorderScope() { graph_recorder() = nullptr; }
+    } recorder_scope(use_graph ? &sl.grec : nullptr);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
     const uint32_t n_cells = f.band_cull ? (2u * su->map_half_wh[0] + 1u) * (2u * su->map_half_wh[1] + 1u) : 0u;
     HIP_TRY(c, sl.cell_culled.ensure((size_t)n_cells + 1));
@@ -1176,6 +1246,11 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     c->last_n_tiles = (uint32_t)n_tiles;
     c->last_slot = (int)(&sl - c->slots);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));
+    if (use_graph) {
+        graph_recorder() = nullptr;
+        const int grc = replay_graph(c, sl);
+        if (grc != GSWT_OK) return grc;
+    }
     HIP_TRY(c, hipGetLastError());
     // k_combine (the frame's last kernel) stores the result counters into the pinned host words itself; only a frame
     // without screen tiles has no such launch
@@ -1634,6 +1709,13 @@ try {
     ka.release(); kb.release(); va.release(); vb.release(); ws.release();
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_sort")
+
+int gswt_debug_graph_stats(const gswt_ctx* c, unsigned long long out[3])
+{
+    if (!c || !out) return GSWT_ERR_BAD_ARG;
+    out[0] = c->stat_graph_launches; out[1] = c->stat_graph_rebuilds; out[2] = c->stat_graph_node_updates;
+    return GSWT_OK;
+}
 
 int gswt_debug_merge_stats(const gswt_ctx* c, unsigned long long out[2])
 {

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <string.h>
+#include <type_traits>
 
 namespace gswt {
 
@@ -131,5 +133,58 @@ struct ProxyArgs {
     uint32_t mip_off[16];          // float4 offsets of the mip levels
     int width, height;
 };
+
+// ---- hipGraph replay of a frame's launch sequence (GSWT_OPT_GRAPH) -------------------------------------------------------------
+// The frame is a fixed chain of kernel launches whose grids follow capacities; what changes from frame to frame is a handful of
+// kernel arguments (the camera block, the output pointer).  With a recorder set, the launch sites of the frame path do not
+// launch: they leave (function, grid, block, packed arguments) per kernel, and the caller replays the chain as ONE
+// hipGraphLaunch, after updating only the kernel nodes whose record differs from the previous frame's.
+struct GraphNodeRec {
+    const void* fn = nullptr;
+    dim3 grid, block;
+    uint32_t n_args = 0, n_bytes = 0;
+    uint16_t offs[40];
+    alignas(16) unsigned char args[1280];
+    template <typename T>
+    void push(const T& v)
+    {
+        static_assert(alignof(T) <= 16, "kernel argument alignment");
+        n_bytes = (n_bytes + (uint32_t)alignof(T) - 1u) & ~((uint32_t)alignof(T) - 1u);
+        if (n_args >= 40u || n_bytes + sizeof(T) > sizeof(args)) { fn = nullptr; return; }      // (checked by the caller: a null fn fails the frame)
+        memcpy(args + n_bytes, &v, sizeof(T));
+        offs[n_args++] = (uint16_t)n_bytes;
+        n_bytes += (uint32_t)sizeof(T);
+    }
+    bool same(const GraphNodeRec& o) const
+    {
+        return fn == o.fn && grid.x == o.grid.x && grid.y == o.grid.y && grid.z == o.grid.z && block.x == o.block.x && n_args == o.n_args &&
+               n_bytes == o.n_bytes && memcmp(args, o.args, n_bytes) == 0;
+    }
+};
+struct GraphRec {
+    GraphNodeRec nodes[24];
+    uint32_t n = 0;
+    bool overflow = false;
+};
+// the recorder of the calling thread (null: the launch sites launch); set around the frame's launch sequence by gswt_api.hip
+GraphRec*& graph_recorder();
+
+template <typename... KA, typename... A>
+inline void graph_record(GraphRec* rec, void (*k)(KA...), dim3 g, dim3 b, A&&... a)
+{
+    static_assert(sizeof...(KA) == sizeof...(A), "kernel argument count");
+    if (rec->n >= 24u) { rec->overflow = true; return; }
+    GraphNodeRec& nd = rec->nodes[rec->n++];
+    nd.fn = reinterpret_cast<const void*>(k);
+    nd.grid = g; nd.block = b; nd.n_args = 0; nd.n_bytes = 0;
+    memset(nd.args, 0, sizeof(nd.args));            // padding bytes take part in the comparison
+    (nd.push(static_cast<typename std::decay<KA>::type>(a)), ...);
+    if (!nd.fn) rec->overflow = true;
+}
+#define GSWT_LAUNCH(K, G, B, S, ...)                                                                     \
+    do {                                                                                                 \
+        if (GraphRec* rec_ = graph_recorder()) graph_record(rec_, K, G, B, __VA_ARGS__);                 \
+        else hipLaunchKernelGGL(K, G, B, 0, S, __VA_ARGS__);                                             \
+    } while (0)
 
 }  // namespace gswt

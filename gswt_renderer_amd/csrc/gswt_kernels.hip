@@ -1834,13 +1834,19 @@ void launch_chunk_tabs(hipStream_t s, const DrawDev* draws, const uint32_t* xcd_
     if (n_draws) hipLaunchKernelGGL(k_chunk_tabs, dim3(n_draws + 8u), dim3(256), 0, s, draws, xcd_first, n_draws, chunk_tab, chunk_tab_xcd, xl);
 }
 
+GraphRec*& graph_recorder()
+{
+    static thread_local GraphRec* rec = nullptr;
+    return rec;
+}
+
 void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, uint32_t* cell_culled, uint32_t n_cells,
                  uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b, uint32_t* zero_c, uint32_t n_zero_c,
                  uint32_t* live_cnt, uint4* live_tab)
 {
     uint32_t grid = (n_draws * 8u + 255u) / 256u;          // eight lanes per draw
     if (grid < 32) grid = 32;
-    hipLaunchKernelGGL(k_cull, dim3(grid), dim3(256), 0, s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, live_cnt, live_tab);
+    GSWT_LAUNCH(k_cull, dim3(grid), dim3(256), s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, live_cnt, live_tab);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
@@ -1852,14 +1858,14 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs x n_super][visible x n_super], zeroed by the caller
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
 #define GSWT_LAUNCH_PROJECT(D, F)                                                                                              \
-    hipLaunchKernelGGL((k_project<D, F>), dim3(n_launch), dim3(256), 0, s, f, draws, chunk_tab, static_list, merged_list,        \
+    GSWT_LAUNCH((k_project<D, F>), dim3(n_launch), dim3(256), s, f, draws, chunk_tab, static_list, merged_list,        \
                        merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f)
     if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
     else if (debug) { GSWT_LAUNCH_PROJECT(true, false); }
     else if (full) { GSWT_LAUNCH_PROJECT(false, true); }
     else { GSWT_LAUNCH_PROJECT(false, false); }
 #undef GSWT_LAUNCH_PROJECT
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, live_cnt);
+    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, live_cnt);
 }
 
 // exclusive scan of `n` u32 in `data` -> `out` (may alias), total -> *total_out.
@@ -1884,7 +1890,7 @@ void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* 
 {
     if (n_chunks == 0) return;
     const uint32_t n_super = n_chunks / 256u + 1u;      // [pairs x n_super][visible x n_super][exclusive pair prefix x n_super]
-    hipLaunchKernelGGL(k_emit, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), 0, s, f, rects, block_sums, super_sums + 2u * n_super,
+    GSWT_LAUNCH(k_emit, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), s, f, rects, block_sums, super_sums + 2u * n_super,
                        n_chunks, pair_cap, counters, keys, vals);
 }
 
@@ -1916,9 +1922,9 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
 #define GSWT_SORT_PASS(T)                                                                                                        \
-        hipLaunchKernelGGL(k_radix_hist<T>, dim3(nblk), dim3(T), 0, s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup); \
-        if (nsup > kSupDirect) hipLaunchKernelGGL(k_radix_supscan, dim3(64), dim3(256), 0, s, gsup, gtot, nsup);                          \
-        hipLaunchKernelGGL(k_radix_scatter<T>, dim3(nblk), dim3(T), 0, s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
+        GSWT_LAUNCH(k_radix_hist<T>, dim3(nblk), dim3(T), s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup); \
+        if (nsup > kSupDirect) GSWT_LAUNCH(k_radix_supscan, dim3(64), dim3(256), s, gsup, gtot, nsup);                          \
+        GSWT_LAUNCH(k_radix_scatter<T>, dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
                            ghist, gsup, gtot, nblk, nsup)
         if (threads == 512) { GSWT_SORT_PASS(512); }
         else { GSWT_SORT_PASS(256); }
@@ -1972,7 +1978,7 @@ void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const un
 {
     (void)n_tiles;
     if (n_cap == 0) return;
-    hipLaunchKernelGGL(k_ranges, dim3((n_cap + 1023) / 1024), dim3(256), 0, s, keys, n_ptr, n_cap, ranges);
+    GSWT_LAUNCH(k_ranges, dim3((n_cap + 1023) / 1024), dim3(256), s, keys, n_ptr, n_cap, ranges);
 }
 
 // ranges -> per-tile segment counts -> item_base (exclusive scan, item_base[n_tiles] = #items) ->
@@ -1988,11 +1994,11 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         return;
     }
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
-    hipLaunchKernelGGL(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), 0, s, ranges, n_tiles, seg, item_base, item_tab, max_items);
+    GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
 #define GSWT_LAUNCH_COMPOSITE(E, D, C)                                                                                         \
-    hipLaunchKernelGGL((k_composite<E, D, C>), dim3(max_items), dim3(256), 0, s, f, ranges, item_base, item_tab, seg, vals, recs, \
+    GSWT_LAUNCH((k_composite<E, D, C>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
         if (colf) {                       // debug draw modes: float colours from the side buffer
         if (depth) GSWT_LAUNCH_COMPOSITE(false, true, true);
@@ -2004,7 +2010,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     else GSWT_LAUNCH_COMPOSITE(false, false, false);
 #undef GSWT_LAUNCH_COMPOSITE
     if (ev_end) hipEventRecord(ev_end, s);
-    hipLaunchKernelGGL(k_combine, dim3(n_tiles), dim3(256), 0, s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+    GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
 }
 
 // k_totals alone on caller-provided sums (unit test of the 64-bit pair count)

@@ -129,6 +129,12 @@ class GSWTRenderer:
         """The same from C arrays (WangTile.sort_tiles_raw): no per-draw Python work on the render thread."""
         self._check(self._lib.gswt_set_draws_merge_groups(self._h, draws_arr, n_draws, groups_arr, n_groups, members_arr, n_members))
 
+    def graph_stats(self):
+        """GSWT_OPT_GRAPH bookkeeping: [frames replayed through hipGraphLaunch, graphs (re)built, kernel nodes updated]."""
+        a = (C.c_ulonglong * 3)()
+        self._check(self._lib.gswt_debug_graph_stats(self._h, a))
+        return [int(x) for x in a]
+
     def merge_stats(self):
         """(merged groups sorted, merged groups copied from the previous sort event) since the ctx was created."""
         out = (C.c_ulonglong * 2)()

@@ -179,7 +179,12 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                   list builds have finished (frames submitted meanwhile keep the previous draw list and nothing waits);
                                   n >= 2: with the n-th frame submitted after the call, finished or not (deterministic: for ranks that
                                   render shards of the same frames); 0 (default): with the next frame, which then waits for them on
-                                  the device */ };
+                                  the device */,
+       GSWT_OPT_GRAPH = 9 /* 1: a frame's kernel launches are replayed as ONE hipGraphLaunch per frame slot (a chain of kernel nodes;
+                             only the nodes whose grid or arguments changed since the slot's previous frame are updated in the
+                             executable graph) instead of ~13 separate launches: less submitting-thread time per frame, same
+                             kernels, same results.  Frames with GSWT_OPT_TIMING > 0, GSWT_ORDER_DEPTH or debug varyings
+                             launch as before.  0 (default): separate launches */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data
@@ -474,6 +479,9 @@ GSWT_API int gswt_debug_totals(gswt_ctx *ctx, const uint32_t *pair_sums, const u
  * of n (key, value) pairs, in place.  Equal keys keep their input order (the order contract of scene.rs:685-695 rests on it).
  * Host pointers. */
 GSWT_API int gswt_debug_sort(gswt_ctx *ctx, uint32_t *keys, uint32_t *vals, size_t n, int key_bits);
+
+/* GSWT_OPT_GRAPH bookkeeping since gswt_create: {frames replayed through hipGraphLaunch, graphs (re)built, kernel nodes updated}. */
+GSWT_API int gswt_debug_graph_stats(const gswt_ctx *ctx, unsigned long long out[3]);
 
 /* Merged groups sorted / copied from the previous sort event by gswt_set_draws_merge_groups since gswt_create. */
 GSWT_API int gswt_debug_merge_stats(const gswt_ctx *ctx, unsigned long long out[2]);

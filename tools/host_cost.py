@@ -14,8 +14,9 @@ su = wang.scene_uniforms()
 r = GSWTRenderer(0)
 wang.upload_to(r); r.configure(None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
-for timing in (0, 1, 2):
+for timing, graph in ((0, 0), (0, 1), (1, 0), (2, 0)):
     r.set_option(L.GSWT_OPT_TIMING, timing)
+    r.set_option(L.GSWT_OPT_GRAPH, graph)
     for shard in ((0, 1), (0, 8, "cols")):
         bw = r.shard_cols_padded(W, shard[1]) if len(shard) > 2 else W
         outs = [torch.empty((H, bw, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
@@ -29,4 +30,4 @@ for timing in (0, 1, 2):
             ts.append(time.perf_counter() - t0)
             r.render_wait(tk)
         ts.sort()
-        print(f"timing={timing} shard={shard}: host enqueue median {ts[len(ts)//2]*1e6:.0f} us, min {ts[0]*1e6:.0f} us", flush=True)
+        print(f"timing={timing} graph={graph} shard={shard}: host enqueue median {ts[len(ts)//2]*1e6:.0f} us, min {ts[0]*1e6:.0f} us", flush=True)
