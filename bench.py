@@ -264,7 +264,8 @@ def main():
                     "reference GUI, gui.rs:599-605); separates the per-view workload from the cost of the sort events")
     ap.add_argument("--no-defer-swap", action="store_true", help="fly path: every swap-in is current at once (the next frame waits for its merged-list build on the device)")
     ap.add_argument("--device-worker", action="store_true", help="fly path: run the per-sort-event worker stages on the GPU (gswt_worker_*) instead of libgswt_host")
-    ap.add_argument("--graph", action="store_true", help="GSWT_OPT_GRAPH: replay each frame's launch sequence as one hipGraphLaunch (frames that carry timing events still launch kernel by kernel)")
+    ap.add_argument("--graph", action="store_true", help="GSWT_OPT_GRAPH: replay each frame's launch sequence as one hipGraphLaunch (frames that carry timing events still launch kernel by kernel); default with --gpus N > 1, where a rank's frame is short enough for the submitting thread to matter")
+    ap.add_argument("--no-graph", action="store_true", help="never use GSWT_OPT_GRAPH")
     ap.add_argument("--static-steps", type=int, default=100, help="flypath mode: frames of the static-camera comparison run (0: skip)")
     args = ap.parse_args()
     if args.timing_every <= 0:
@@ -499,7 +500,8 @@ def main():
             dt = float(tt.item())
         return dt
 
-    if args.graph:
+    use_graph = (args.graph or world > 1) and not args.no_graph
+    if use_graph:
         r.set_option(L.GSWT_OPT_GRAPH, 1)
     worker = None
     if args.mode == "static" and args.static_at >= 0:
@@ -663,7 +665,7 @@ def main():
                             "note": "SortData swap-ins inside the timed region (gswt_set_draws_merge_groups: draw-list upload into the spare draw set + merged lists built on the device, on a stream of their own)"},
             "worker_ms": worker_ms,
             "host_submit_ms_mean": float(np.mean(st["submit_ms"])) if st["submit_ms"] else None,
-            "graph": ({"launches_rebuilds_node_updates": r.graph_stats(), "note": "GSWT_OPT_GRAPH: one hipGraphLaunch per frame; frames that carry timing events (every --timing-every-th) launch kernel by kernel"} if args.graph else None),
+            "graph": ({"launches_rebuilds_node_updates": r.graph_stats(), "note": "GSWT_OPT_GRAPH: one hipGraphLaunch per frame; frames that carry timing events (every --timing-every-th) launch kernel by kernel"} if use_graph else None),
             "stage_ms": stage_ms,
             "static_camera": static,
             "roofline": {"bound": "hbm", "kernel": "k_composite", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
