@@ -336,6 +336,16 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
 // (6) the static lists a second time as 32-byte records in list order (plain / blending draws read 256 consecutive records,
 // coalesced, addressed from the launch-table entry alone: no list word, no dependent gather; 150 MB at c3): 91.8 -> 88.2 us at c3,
 // 128.1 -> 128.6 on the HeightMap surface, 461 -> 457 at c5 (stage events) -- the gather latency is hidden by the other waves.
+// (7) column-band shards: a per-entry pre-pass (k_cull's cell table for merged groups, then position, the frustum test and a
+// per-splat bound of the pixel extent against the band) followed by a compaction of the surviving entries to the front of the
+// workgroup (ballot ranks + LDS exchange of entry / map id / slot), so that only ceil(survivors / 64) waves run the projection: the
+// splats a rank of 8 carries through the whole projection fell from 471-619 k to 217-266 k (union of the bands still bitwise the
+// unsharded image), and the kernel's time did not move (49-66 us per rank before and after; c5 441 -> 451 us per frame): in band
+// mode, too, the kernel is paced by its workgroups' load chains, not by the projection's instructions.
+// (8) the grid sized from the previous frame's table of live chunks (+ 50 % + 64 per XCD list; k_totals flags a frame whose table
+// outgrew its grid and the host re-runs it) instead of from the whole table: the dispatcher hands out ~4.6 k workgroups per us
+// (flag 256: c5's 366 k workgroups that only read the launch table and leave take ~80 us), but the workgroups of culled chunks
+// overlap with the live ones: project stage 461 -> 433 us at c5, 87 -> 87 us at c3, frame rates unchanged.
 template <bool DEBUG, bool FULL>
 __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
@@ -362,6 +372,7 @@ __global__ __launch_bounds__(256) void k_project(
         const uint4 lt = live_tab[blockIdx.x];
         ct = make_uint2(lt.x, lt.y);
         list_top = lt.z; list_cnt = lt.w;
+        if (f.dbg_flags & 256) return;      // ablation: nothing behind the launch-table entry
     }
     const DrawDev& d = draws[ct.x];
     const uint32_t tid = threadIdx.x;
@@ -393,6 +404,7 @@ __global__ __launch_bounds__(256) void k_project(
             if (f.band_cull && d.single_draw == 1u && cell_culled[map_id_m] != 0u) break;
             // A1 gswt.wgsl:38-42
             if (d.valid_lod_id >= 0 && d.valid_lod_id != (int32_t)lod_id) break;
+            if (f.dbg_flags & 128) break;       // ablation: stop behind the list word, in front of the record gather
             // A2 :45-49
             const uint4 w0 = tex[2 * (size_t)gs_index];
             const uint4 w1 = tex[2 * (size_t)gs_index + 1];

@@ -20,13 +20,13 @@ r.configure(wang.height_map() if int(wang.user.surface_type) == 1 else None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
-for flags, what in ((0, "full"), (16, "stop after the frustum cull"), (8, "no record / rect stores, no pairs"), (24, "both")):
+for flags, what in ((0, "full"), (16, "stop after the frustum cull"), (128, "stop behind the list word (no record gather)"), (256, "return behind the launch-table entry"), (8, "no record / rect stores, no pairs"), (24, "both")):
     r.set_option(L.GSWT_OPT_DEBUG_FLAGS, flags)
     ts = []
     for i in range(12):
         r.render_wait(r.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
         ts.append(r.timings())
     ts = ts[4:]
-    print(f"flags {flags:2d} ({what}): project stage {1e3 * np.median([t['ms_project'] for t in ts]):.1f} us, frame {1e3 * np.median([t['ms_total'] for t in ts]):.1f} us, "
+    print(f"flags {flags:3d} ({what}): project stage {1e3 * np.median([t['ms_project'] for t in ts]):.1f} us, frame {1e3 * np.median([t['ms_total'] for t in ts]):.1f} us, "
           f"visible {ts[-1]['n_visible']}, pairs {ts[-1]['n_pairs']}")
 r.set_option(L.GSWT_OPT_DEBUG_FLAGS, 0)

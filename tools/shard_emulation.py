@@ -17,6 +17,8 @@ W, H = w["width"], w["height"]
 su = wang.scene_uniforms()
 r = GSWTRenderer(0)
 r.set_option(L.GSWT_OPT_TIMING, 0)
+r.set_option(L.GSWT_OPT_GRAPH, int(os.environ.get("GSWT_GRAPH", "0")))      # GSWT_GRAPH=1: one hipGraphLaunch per frame
+print(f"workload {name}, GSWT_OPT_GRAPH = {os.environ.get('GSWT_GRAPH', '0')}", flush=True)
 wang.upload_to(r)
 r.configure(None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
