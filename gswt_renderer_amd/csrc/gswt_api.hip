@@ -31,6 +31,7 @@ void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*,
 void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
 void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
+size_t radix_ws_zero_words(uint32_t, int);
 void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long long*, const uint2*, const float*, const uint32_t*,
                        uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                        unsigned long long*, uint32_t*, uint32_t*);
@@ -1212,7 +1213,9 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
     const uint32_t n_cells = f.band_cull ? (2u * su->map_half_wh[0] + 1u) * (2u * su->map_half_wh[1] + 1u) : 0u;
     HIP_TRY(c, sl.cell_culled.ensure((size_t)n_cells + 1));
-    launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)(16 + n_super2 + radix_words),
+    // cleared per frame: counters, super-group sums and the atomically accumulated part of the sort's tables (depth order: both sorts' tables whole)
+    const size_t n_zero_a = 16 + n_super2 + (depth_order ? radix_words : radix_ws_zero_words(cap, key_bits));
+    launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,

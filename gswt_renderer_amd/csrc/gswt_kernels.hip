@@ -1916,6 +1916,16 @@ size_t radix_ws_words(uint32_t n_cap, int key_bits)
     const int passes = (key_bits + 7) / 8;
     return (size_t)passes * ((size_t)256 * nblk + (size_t)256 * nsup + 256);
 }
+// The part of the workspace that has to be zero when a sort starts: the group rows and digit totals of every pass (targets of
+// atomic adds), which come first.  The per-workgroup rows behind them are written in full by k_radix_hist (every launched
+// workgroup stores its 256 counts, zeros past the item count) -- a frame used to clear them too: 2 MB at c3, 13.6 MB at c5, by
+// k_cull's 32 workgroups.
+size_t radix_ws_zero_words(uint32_t n_cap, int key_bits)
+{
+    const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
+    const int passes = (key_bits + 7) / 8;
+    return (size_t)passes * ((size_t)256 * nsup + 256);
+}
 
 int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n_cap,
                 const unsigned long long* n_ptr, int key_bits, uint32_t* ws)
@@ -1926,11 +1936,15 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
     static const uint32_t wide_max = [] { const char* e = getenv("GSWT_SORT_WIDE_MAX_M"); return e ? (uint32_t)atoi(e) << 20 : kSortWideMax; }();
     const int threads = n_cap <= wide_max ? 512 : 256;
     int cur = 0;
+    const int passes = (key_bits + 7) / 8;
+    uint32_t* hist_rows = ws + (size_t)passes * ((size_t)256 * nsup + 256);      // behind the zeroed part (radix_ws_zero_words)
     for (int shift = 0; shift < key_bits; shift += 8) {
         uint32_t nbits = (uint32_t)((key_bits - shift) < 8 ? (key_bits - shift) : 8);
         uint32_t mask = (1u << nbits) - 1u;
-        uint32_t* ghist = ws; uint32_t* gsup = ghist + (size_t)256 * nblk; uint32_t* gtot = gsup + (size_t)256 * nsup;
+        uint32_t* gsup = ws; uint32_t* gtot = gsup + (size_t)256 * nsup;
         ws = gtot + 256;
+        uint32_t* ghist = hist_rows;
+        hist_rows += (size_t)256 * nblk;
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
 #define GSWT_SORT_PASS(T)                                                                                                        \
