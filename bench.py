@@ -393,6 +393,7 @@ def main():
     else:
         cams = [(tuple(cam0["pos"]), cu0, vp0)]
 
+    trace = [] if os.environ.get("GSWT_BENCH_TRACE") else None      # host-side timeline of submits and waits (stderr, after the run)
     state = {"su": su0, "swaps": 0, "swap_ms": [], "slots": slots}
     stats = {"comp_ms": [], "comp_slot": [], "pairs": [], "stage": [], "submit_ms": []}
     inflight = []
@@ -406,6 +407,8 @@ def main():
             draws, nd, groups, ng, members, nm = raw
             r.set_draws_merge_groups_raw(draws, nd, groups, ng, members, nm)     # SortData swap-in, state.rs:361-376
         state["swap_ms"].append(1e3 * (time.perf_counter() - t0))
+        if trace is not None:
+            trace.append(("swap", state["swaps"] + 1, t0, time.perf_counter(), state["swaps"] + 1))
         state["su"] = su
         state["swaps"] += 1
 
@@ -425,6 +428,8 @@ def main():
         r.set_option(L.GSWT_OPT_TIMING, args.timing if timed else 0)      # per frame: the slot remembers its own level
         ticket = r.render_async(cu, state["su"], W, H, o.data_ptr(), transmittance_eps=args.t_eps, shard=shard, bg_rgba_ptr=bgp, bg_depth_ptr=dpp)
         stats["submit_ms"].append(1e3 * (time.perf_counter() - t0))
+        if trace is not None:
+            trace.append(("submit", i, t0, time.perf_counter(), state["swaps"]))
         inflight.append((ticket, o, timed))
         state["ticket"] = ticket
 
@@ -440,7 +445,10 @@ def main():
                 else:
                     dist.all_gather_into_tensor(gathered, o)
                 r.unshard_mode(gathered.data_ptr(), W, H, world, "cols", frame.data_ptr())
+        tw0 = time.perf_counter()
         r.render_wait(ticket)
+        if trace is not None:
+            trace.append(("wait", int(ticket), tw0, time.perf_counter(), state["swaps"]))
         t = r.timings()
         stats["pairs"].append(t["n_pairs"])
         stats["last"] = t
@@ -528,6 +536,11 @@ def main():
         worker.close()
     dt = timed_run(args.steps, None if args.freeze_sort else worker, args.warmup)
     main_stats = {k: (list(v) if isinstance(v, list) else v) for k, v in stats.items()}
+    if trace is not None:
+        tb = trace[0][2]
+        for kind, idx, a, b, sw in trace:
+            print(f"trace {kind:6s} {idx:4d} start {1e6 * (a - tb):9.1f} us  dur {1e6 * (b - a):8.1f} us  swaps {sw}", file=sys.stderr)
+        trace = None
     mg_built, mg_reused = r.merge_stats()
     swaps, swap_ms = state["swaps"], list(state["swap_ms"])
     w_build, w_sort = (list(worker.build_ms), list(worker.sort_ms)) if worker is not None else ([], [])

@@ -67,6 +67,10 @@ struct DevBuf {
         if (n <= cap) return hipSuccess;
         size_t ncap = n + n / 4 + 1024;
         T* np = nullptr;
+        // (GSWT_LOG_ALLOC=1: every device allocation of the library on stderr -- a growth inside a frame loop frees the old buffer,
+        // which waits for the device)
+        static const bool log_alloc = getenv("GSWT_LOG_ALLOC") != nullptr;
+        if (log_alloc) fprintf(stderr, "gswt alloc: %zu -> %zu bytes%s\n", cap * sizeof(T), ncap * sizeof(T), p ? " (grow: frees the old buffer)" : "");
         hipError_t e = hipMalloc(&np, ncap * sizeof(T));
         if (e != hipSuccess) return e;
         if (keep && p && cap) hipMemcpy(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice);
@@ -75,6 +79,11 @@ struct DevBuf {
         p = np; cap = ncap;
         return hipSuccess;
     }
+    // Buffers whose size follows the frame's pair count or a sort event's list sizes: when one has to grow it grows to TWICE the
+    // request.  Growing frees the old buffer, which waits for the device -- with four frames in flight most of a millisecond, and
+    // each frame slot / draw set repeats it when its turn comes (a fly path whose pair count crosses the old capacity stalled ~1 ms
+    // per slot); 288 GB of HBM make the headroom cheap.
+    hipError_t ensure_roomy(size_t n) { return n <= cap ? hipSuccess : ensure(2 * n); }
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -136,9 +145,9 @@ struct DrawSet {
         off_remap = take((n_members + 1) * sizeof(uint2)); off_segs = take((2 * n_members + 1) * sizeof(MergeSeg));
         off_blocks = take(n_blk * sizeof(uint2)); off_cblocks = take(n_blk * sizeof(uint2)); off_n64 = take(64);
         blob_bytes = o;
-        hipError_t e = h_blob.ensure(o);
+        hipError_t e = o <= h_blob.cap ? hipSuccess : h_blob.ensure(2 * o);      // (grows to twice the request, like DevBuf::ensure_roomy)
         if (e != hipSuccess) return e;
-        e = d_blob.ensure(o);
+        e = d_blob.ensure_roomy(o);
         if (e != hipSuccess) return e;
         draws.p = dp<DrawDev>(off_draws); xcd_first.p = dp<uint32_t>(off_xcd);
         return hipSuccess;
@@ -734,8 +743,8 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     size_t longest = 0;
     for (int x = 0; x < 8; x++) longest = std::max<size_t>(longest, (size_t)per_xcd[x]);
     if (longest * 8 >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: chunk table too large");
-    HIP_TRY(c, D.chunk_tab.ensure(n_chunks + 1));
-    HIP_TRY(c, D.chunk_tab_xcd.ensure(longest * 8 + 1));
+    HIP_TRY(c, D.chunk_tab.ensure_roomy(n_chunks + 1));
+    HIP_TRY(c, D.chunk_tab_xcd.ensure_roomy(longest * 8 + 1));
     D.n_launch = (uint32_t)(longest * 8);
     for (int x = 0; x < 8; x++) D.per_xcd[x] = per_xcd[x];
     D.longest = longest;
@@ -748,8 +757,8 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
         D.ev_up_pending = true; D.built = false;
     }
     // merged arrays: pack gs_index | lod << 28
-    HIP_TRY(c, D.merged_list.ensure(n_merged + 1));
-    HIP_TRY(c, D.merged_map.ensure(n_merged + 1));
+    HIP_TRY(c, D.merged_list.ensure_roomy(n_merged + 1));
+    HIP_TRY(c, D.merged_map.ensure_roomy(n_merged + 1));
     D.n_merged = n_merged;
     if (n_merged && !device_merge) {
         std::vector<uint32_t> packed(n_merged);
@@ -773,6 +782,24 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     D.n_chunks = (uint32_t)n_chunks;
     D.g_valid = false;
     D.n_entries = entries;
+    // The first draw list of a scene sizes the other draw sets too: every set's first fill used to allocate its own buffers (a
+    // pinned upload block, its device mirror, chunk tables, merged arrays) inside the sort event that reached it -- the first five
+    // swap-ins of a run each stalled the render thread for most of a millisecond.
+    // A set that already has buffers grows with the largest one seen only while nothing reads it (no frame in flight, not the
+    // current / pending / latest set: the next event's group copies read the latest one).
+    for (int k = 0; k < kDrawSets; k++) {
+        DrawSet& o = c->sets[k];
+        if (&o == &D) continue;
+        const bool empty = !o.d_blob.p && !o.chunk_tab.p && !o.merged_list.p;
+        bool used = k == c->cur_set || k == c->pending_set || k == c->latest_set || o.ev_up_pending;
+        for (const FrameSlot& fs : c->slots) used = used || (fs.pending && fs.set == k);
+        if (used && !empty) continue;
+        if (o.h_blob.cap >= D.h_blob.cap && o.d_blob.cap >= D.d_blob.cap && o.chunk_tab.cap >= D.chunk_tab.cap &&
+            o.chunk_tab_xcd.cap >= D.chunk_tab_xcd.cap && o.merged_list.cap >= D.merged_list.cap && o.merged_map.cap >= D.merged_map.cap) continue;
+        HIP_TRY(c, o.h_blob.ensure(D.h_blob.cap)); HIP_TRY(c, o.d_blob.ensure(D.d_blob.cap));
+        HIP_TRY(c, o.chunk_tab.ensure(D.chunk_tab.cap)); HIP_TRY(c, o.chunk_tab_xcd.ensure(D.chunk_tab_xcd.cap));
+        HIP_TRY(c, o.merged_list.ensure(D.merged_list.cap)); HIP_TRY(c, o.merged_map.ensure(D.merged_map.cap));
+    }
     if (!device_merge) { publish_set(c, target); c->draws_ready = true; }      // (gswt_set_draws_merge_groups publishes behind its builds)
     return GSWT_OK;
 }
@@ -948,7 +975,7 @@ try {
         int gbits = 1;
         while ((1u << gbits) < n_build) gbits++;
         const size_t radix_words = radix_ws_words(n_total, 16 + gbits);
-        HIP_TRY(c, c->mg_ws.ensure(4 * (size_t)n_total + radix_words + 16));        // sort workspace, shared by all events (stream-ordered)
+        HIP_TRY(c, c->mg_ws.ensure_roomy(4 * (size_t)n_total + radix_words + 16));        // sort workspace, shared by all events (stream-ordered)
         uint32_t* w = c->mg_ws.p;
         uint32_t* radix = w + 4 * (size_t)n_total;
         HIP_TRY(c, hipMemsetAsync(radix, 0, (radix_words + 16) * 4, s));
@@ -1091,10 +1118,10 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         const size_t n_slots_all = (size_t)D.n_chunks * kChunk;
         HIP_TRY(c, sl.rects.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
-        HIP_TRY(c, sl.block_sums.ensure((size_t)D.n_chunks + 1));
-        HIP_TRY(c, sl.live_tab.ensure((size_t)D.n_launch + 8));
+        HIP_TRY(c, sl.block_sums.ensure_roomy((size_t)D.n_chunks + 1));
+        HIP_TRY(c, sl.live_tab.ensure_roomy((size_t)D.n_launch + 8));
         if (!sl.live_cnt.p) { HIP_TRY(c, sl.live_cnt.ensure(8)); HIP_TRY(c, hipMemset(sl.live_cnt.p, 0, sl.live_cnt.cap * 4)); }
-        HIP_TRY(c, sl.draw_culled.ensure((size_t)D.n_draws + 1));
+        HIP_TRY(c, sl.draw_culled.ensure_roomy((size_t)D.n_draws + 1));
         if (su->draw_mode != 0u) HIP_TRY(c, sl.col_f.ensure(n_slots_all + 1));
         if (a.d_bgd || cfg->order_mode == GSWT_ORDER_DEPTH) HIP_TRY(c, sl.depths.ensure(n_slots_all + 1));
     }
@@ -1165,8 +1192,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(D.n_entries / 4, 1u << 20), 0xFFFFFF00ull);
     const uint32_t cap = c->pair_cap;
     sl.cap = cap;
-    HIP_TRY(c, sl.keys_a.ensure((size_t)cap + 4)); HIP_TRY(c, sl.keys_b.ensure((size_t)cap + 4));     // k_ranges reads whole quads
-    HIP_TRY(c, sl.vals_a.ensure((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure((size_t)cap + 1));
+    HIP_TRY(c, sl.keys_a.ensure_roomy((size_t)cap + 4)); HIP_TRY(c, sl.keys_b.ensure_roomy((size_t)cap + 4));     // k_ranges reads whole quads
+    HIP_TRY(c, sl.vals_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure_roomy((size_t)cap + 1));
     const size_t n_super2 = 3 * ((size_t)D.n_chunks / 256 + 1);     // pair sums, visible sums, exclusive pair prefix (k_totals)
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
     const uint32_t n_slots = D.n_chunks * (uint32_t)kChunk;
@@ -1177,15 +1204,15 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         HIP_TRY(c, sl.scan_ws.ensure((size_t)D.n_chunks / 1024 + 4096));
     }
     // one contiguous u32 region cleared by k_cull: [counters: 16][super_sums: n_super2][radix histograms]
-    HIP_TRY(c, sl.ghist.ensure(16 + n_super2 + radix_words + 16));
+    HIP_TRY(c, sl.ghist.ensure_roomy(16 + n_super2 + radix_words + 16));
     uint32_t* const zero_a = sl.ghist.p;
     unsigned long long* const d_counters = reinterpret_cast<unsigned long long*>(zero_a);
     uint32_t* const d_super = zero_a + 16;
     uint32_t* const d_radix = d_super + n_super2;
     const uint32_t seg = (uint32_t)c->opt_segment;
-    HIP_TRY(c, sl.item_base.ensure((size_t)n_tiles + 2));
-    HIP_TRY(c, sl.partials.ensure(((size_t)n_tiles + cap / seg + 1) * 256));
-    HIP_TRY(c, sl.item_tab.ensure((size_t)n_tiles + cap / seg + 2));
+    HIP_TRY(c, sl.item_base.ensure_roomy((size_t)n_tiles + 2));
+    HIP_TRY(c, sl.partials.ensure_roomy(((size_t)n_tiles + cap / seg + 1) * 256));
+    HIP_TRY(c, sl.item_tab.ensure_roomy((size_t)n_tiles + cap / seg + 2));
     unsigned long long* const d_P = d_counters + 1;
     hipEvent_t* ev = sl.ev;
     // ---- cull (+ clears the frame's accumulators) + project
