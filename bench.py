@@ -269,7 +269,7 @@ def main():
     ap.add_argument("--static-steps", type=int, default=100, help="flypath mode: frames of the static-camera comparison run (0: skip)")
     args = ap.parse_args()
     if args.timing_every <= 0:
-        args.timing_every = 1 if args.steps < 64 else 3       # 0 = auto: short runs time every frame; 3 is coprime with the 4 frame slots, so every slot is sampled
+        args.timing_every = 2 if args.steps < 64 else 3       # 0 = auto: short runs time every other frame (10 samples in the driver's 20 steps; the frames between them can go through GSWT_OPT_GRAPH); 3 is coprime with the 4 frame slots, so every slot is sampled
 
     # Only the final JSON line may reach stdout (RCCL prints a version banner there): park the real stdout and point
     # fd 1 at stderr for the rest of the run.
