@@ -703,6 +703,25 @@ def main():
                                     "what the kernel actually runs against is in `valu`",
                          "traffic_note": traffic_note, "valu": valu},
         }
+        # the fraction of a MEASURED device-copy kernel beside the nominal peak (512 MB copied device to device: bytes
+        # read + bytes written over the best of five copies)
+        try:
+            ca = torch.empty(128 << 20, dtype=torch.float32, device=dev); cb = torch.empty_like(ca)
+            ca.fill_(1.0); cb.copy_(ca); torch.cuda.synchronize()
+            best = None
+            for _ in range(5):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); cb.copy_(ca); e1.record(); e1.synchronize()
+                msc = e0.elapsed_time(e1)
+                best = msc if best is None else min(best, msc)
+            copy_gbs = 2.0 * ca.numel() * 4 / (best * 1e-3) / 1e9
+            res["roofline"]["measured_copy_GBps"] = copy_gbs
+            res["roofline"]["frac_of_measured_copy"] = achieved / copy_gbs
+            res["roofline"]["frac_isolated_of_measured_copy"] = (algo_bytes / (iso_ms * 1e-3) / 1e9) / copy_gbs if iso_ms > 0 else None
+            del ca, cb
+        except Exception as e:      # noqa: BLE001 - the copy is a side measurement
+            res["roofline"]["measured_copy_GBps"] = None
+            print(f"[bench] device-copy measurement failed: {e}", file=sys.stderr)
         if use_dist:
             res["dist_check_max_abs_diff"] = dist_check
             res["collective"] = "gswt_render_gather (ncclAllGather behind the C ABI)" if abi_comm else "torch.distributed.all_gather_into_tensor + gswt_unshard_mode"
