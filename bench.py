@@ -303,6 +303,10 @@ def main():
     W, H = w["width"], w["height"]
     from gswt_renderer_amd import workloads
     cam0 = workloads.camera_for(args.workload)
+    if world > 1 or fake_world > 1 or args.device_worker:
+        # stream creation order of the library (hardware-queue sharing): the layout measured best for a rank's band frames + gather
+        # (and for the device-side worker, whose kernels run on a stream of their own: 3 950 against 3 250 frames/s)
+        os.environ.setdefault("GSWT_STREAM_LAYOUT", "c012p3s")
     r = GSWTRenderer(local_rank)                       # raises when libgswt_hip.so / the GPU is missing
     stream = torch.cuda.Stream(device=dev)
     r.set_stream(stream.cuda_stream)                    # ctx stream: fences, all-gather and unshard are ordered on it
@@ -356,6 +360,8 @@ def main():
     # three frames in flight on a static camera (a fourth costs 6 %: four buffer sets in rotation), four on the fly path (the
     # fourth covers the bubble a SortData swap-in leaves in the frame stream: +5 %)
     slots_static = min(slots, 3)
+    if world > 1 or args.device_worker:
+        slots = min(slots, 4)           # a rank's band frames: the fifth frame in flight gains nothing there (rank 0 of 8: 7.8-8.9 k frames/s with four or five)
     if args.in_flight > 0:
         slots = slots_static = max(1, min(slots, args.in_flight))
     elif per_slot_bytes > 2e9:

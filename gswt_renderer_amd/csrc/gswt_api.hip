@@ -115,7 +115,22 @@ struct HostBuf {
 // frame stream a fourth frame in flight covers the bubble a swap-in leaves (fly path 3 570 -> 3 770 frames/s) while it still costs
 // a static camera 6 % (4 476 -> 4 214), so the library offers four and the caller decides how many it keeps in flight:
 // gswt_render_async takes the lowest free slot, unused slots cost nothing.
-constexpr int kFrameSlots = 4;
+// Frame slots = frames that can be in flight.  c3 fly path (worker thread + swap-ins), frames/s on one box with every slot in flight:
+// 2: 3 770, 3: 4 095, 4: 4 445-4 500, 5: 4 770-4 790, 6: 4 700-4 765.  A static camera peaks at three in flight (bench.py keeps three
+// there): more frames rotate over more sets of per-frame buffers and the working set outgrows the Infinity Cache.
+#ifndef GSWT_FRAME_SLOTS
+#define GSWT_FRAME_SLOTS 5
+#endif
+constexpr int kFrameSlots = GSWT_FRAME_SLOTS;
+// Stream creation order (see gswt_create).  Measured on one box, c3 (tools: GSWT_STREAM_LAYOUT sweeps, gpurun_out/stream_layouts.txt):
+//   layout        fly path, 4 / 5 in flight   static, 3 in flight   rank 0 of 8 (fake world): fly / static
+//   c012p3s       4 492 / 4 658                4 924                 8 240 / 11 099      (fifth slot stream created at first use)
+//   c012p34s      4 490 / 4 821                4 857                 8 055 /  8 849
+//   c012p3ps      4 510 / 4 321                4 901                 7 790 /  8 767
+//   c0123s        4 506 / 4 621                4 899                 7 317 / 10 241
+// Four frames in flight do not care; the fifth frame pays only with its stream created in front of the build stream (which then
+// shares its hardware queue with slot 2), and band frames of a sharded run want the older layout (bench.py sets it for --gpus N > 1).
+constexpr const char* kStreamLayout = "c012p34s";
 
 // The per-sort-event state (GSWTRenderer's swap-in of a SortData, state.rs:361-376): draw descriptors, chunk tables, merged
 // lists, band-cull bounds.  Double-buffered: gswt_set_draws* fills the set that is NOT current while the frames in flight
@@ -272,7 +287,7 @@ struct gswt_ctx {
     int latest_set = 0;                    // the set filled last (== cur_set unless a deferred swap-in is pending)
     int pending_set = -1;                  // GSWT_OPT_DEFER_SWAP: filled, still being built on set_stream, not yet read by frames
     hipStream_t set_stream = nullptr;      // uploads and device-side builds of a sort event: beside the frames, not in front of them
-    hipStream_t pad_stream = nullptr;      // never used: steers the hardware-queue assignment (gswt_create)
+    std::vector<hipStream_t> pad_streams;  // never used: they steer the hardware-queue assignment (gswt_create)
     int opt_defer_swap = 0;
     int opt_graph = 0;
     unsigned long long stat_graph_launches = 0, stat_graph_rebuilds = 0, stat_graph_node_updates = 0;
@@ -462,15 +477,27 @@ try {
     gswt_ctx* c = new (std::nothrow) gswt_ctx();
     if (!c) return GSWT_ERR_CAPACITY;
     c->device = device_id;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
-    // Stream creation order matters: the runtime spreads streams over 4 hardware queues (GPU_MAX_HW_QUEUES) in creation order, and a
-    // frame slot that shares its queue with the ctx stream runs its frames behind whatever is recorded there.  A placeholder stream
-    // in front of the fourth slot keeps slots 0-2 on queues of their own and puts the build stream beside a slot, not beside the ctx
-    // (c3, one box: static camera 4 070 -> 4 900 frames/s, fly path unchanged; more hardware queues made the fly path slower).
-    int k_slot = 0;
+    // Stream creation order matters: the runtime spreads streams over 4 hardware queues (GPU_MAX_HW_QUEUES) in creation order, and
+    // streams that share a queue run one behind the other.  The layout string names the order: c = ctx stream, 0-4 = frame slot
+    // streams, s = the stream of the sort-event builds, p = a placeholder that is never used; a slot stream the string leaves out is
+    // created when that slot is first used.  (GSWT_STREAM_LAYOUT overrides it: tuning only.)
+    const char* layout = getenv("GSWT_STREAM_LAYOUT");
+    if (!layout || !*layout) layout = kStreamLayout;
+    for (const char* q = layout; *q; q++) {
+        hipStream_t* dst = nullptr;
+        hipStream_t pad = nullptr;
+        if (*q == 'c') dst = &c->stream;
+        else if (*q == 's') dst = &c->set_stream;
+        else if (*q >= '0' && *q < '0' + kFrameSlots) dst = &c->slots[*q - '0'].stream;
+        else if (*q == 'p') dst = &pad;
+        else continue;
+        if (*dst) continue;
+        if (hipStreamCreateWithFlags(dst, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+        if (dst == &pad) c->pad_streams.push_back(pad);
+    }
+    if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+    if (!c->set_stream && hipStreamCreateWithFlags(&c->set_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
     for (auto& sl : c->slots) {
-        if (k_slot++ == 3 && hipStreamCreateWithFlags(&c->pad_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
-        if (hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         if (hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         for (auto& e : sl.ev)
             if (hipEventCreate(&e) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
@@ -478,7 +505,6 @@ try {
         memset(sl.hc, 0, 8 * sizeof(unsigned long long));
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&sl.hc_dev), sl.hc, 0) != hipSuccess) sl.hc_dev = nullptr;   // then the copy stays
     }
-    if (hipStreamCreateWithFlags(&c->set_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
     *out = c;
     return GSWT_OK;
 } GSWT_CATCH("gswt_create")
@@ -507,7 +533,7 @@ void gswt_destroy(gswt_ctx* c)
     }
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
     if (c->set_stream) hipStreamDestroy(c->set_stream);
-    if (c->pad_stream) hipStreamDestroy(c->pad_stream);
+    for (hipStream_t ps : c->pad_streams) hipStreamDestroy(ps);
     delete c;
 }
 
@@ -1359,6 +1385,7 @@ try {
     for (int k = 0; k < kFrameSlots; k++) if (!c->slots[k].pending) { si0 = k; break; }
     FrameSlot& sl = c->slots[si0];
     if (sl.pending) return fail(c, GSWT_ERR_STATE, "gswt_render: every frame slot holds an uncollected gswt_render_async ticket");
+    if (!sl.stream) HIP_TRY(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
     activate_pending(c, false);
     sl.set = c->cur_set;
     fill_args(sl.args, cam, su, cfg, width, height, d_bg, d_bgd, d_out);
@@ -1389,6 +1416,7 @@ try {
         for (int k = 1; k < kFrameSlots; k++) if (c->slots[k].seq < c->slots[si].seq) si = k;
     }
     FrameSlot& sl = c->slots[si];
+    if (!sl.stream) HIP_TRY(c, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));      // a slot past the fourth: first use
     if (sl.pending) {                   // every slot in flight: the oldest frame is collected here and its slot reused
         sl.pending = false;
         if (sl.collected) { sl.collected = false; rc = sl.collected_rc; } else rc = finish_frame(c, sl);
