@@ -492,6 +492,11 @@ try {
         else if (*q == 'p') dst = &pad;
         else continue;
         if (*dst) continue;
+        if ((q[1] == '+' || q[1] == '-')) {                   // "s+" / "s-": highest / lowest stream priority (tuning experiments)
+            int lo = 0, hi = 0;
+            hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo = least, hi = greatest priority (numerically lower)
+            if (hipStreamCreateWithPriority(dst, hipStreamNonBlocking, q[1] == '+' ? hi : lo) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+        } else
         if (hipStreamCreateWithFlags(dst, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         if (dst == &pad) c->pad_streams.push_back(pad);
     }
