@@ -1151,7 +1151,10 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.block_sums.ensure_roomy((size_t)D.n_chunks + 1));
         HIP_TRY(c, sl.live_tab.ensure_roomy((size_t)D.n_launch + 8));
-        if (!sl.live_cnt.p) { HIP_TRY(c, sl.live_cnt.ensure(8)); HIP_TRY(c, hipMemset(sl.live_cnt.p, 0, sl.live_cnt.cap * 4)); }
+        // (cleared ON THE SLOT'S STREAM: the slot streams are non-blocking, so a null-stream hipMemset -- asynchronous to the host for
+        // device memory -- could land after this frame's k_cull had filled the counts: the slot's FIRST frame then projected nothing
+        // and came back as background.  Seen once five slots made test_async_all_slots_in_flight_and_slot_reuse the first user of slot 4.)
+        if (!sl.live_cnt.p) { HIP_TRY(c, sl.live_cnt.ensure(8)); HIP_TRY(c, hipMemsetAsync(sl.live_cnt.p, 0, sl.live_cnt.cap * 4, s)); }
         HIP_TRY(c, sl.draw_culled.ensure_roomy((size_t)D.n_draws + 1));
         if (su->draw_mode != 0u) HIP_TRY(c, sl.col_f.ensure(n_slots_all + 1));
         if (a.d_bgd || cfg->order_mode == GSWT_ORDER_DEPTH) HIP_TRY(c, sl.depths.ensure(n_slots_all + 1));

@@ -997,8 +997,10 @@ int gswt_worker_create(gswt_ctx* ctx, const gswt_worker_config* cfg, gswt_worker
     for (auto& h : w->hs) { A(h.tiles.alloc(cells)); A(h.groups.alloc(cells)); A(h.members.alloc(cells)); A(h.draws.alloc(cells)); }
     A(w->h_counts.alloc(C_COUNT));
     if (e != hipSuccess) { gswt_worker_destroy(w); return GSWT_ERR_HIP; }
-    A(hipMemset(w->st.p, 0, cells * sizeof(gswt_cell_state))); A(hipMemset(w->head_len.p, 0, cells * 4)); A(hipMemset(w->counts.p, 0, C_COUNT * 4));
-    A(hipMemset(w->n64.p, 0, 8 * sizeof(unsigned long long)));
+    // (stream-ordered: the worker's stream is non-blocking and does not wait for null-stream memsets)
+    A(hipMemsetAsync(w->st.p, 0, cells * sizeof(gswt_cell_state), w->stream)); A(hipMemsetAsync(w->head_len.p, 0, cells * 4, w->stream));
+    A(hipMemsetAsync(w->counts.p, 0, C_COUNT * 4, w->stream)); A(hipMemsetAsync(w->n64.p, 0, 8 * sizeof(unsigned long long), w->stream));
+    A(hipStreamSynchronize(w->stream));
     if (e != hipSuccess) { gswt_worker_destroy(w); return GSWT_ERR_HIP; }
     d.sp.height_map = w->height_map.p; d.lod_dist = w->lod_dist.p; d.tile_center = w->tile_center.p; d.tile_aabb = w->tile_aabb.p;
     d.presort_dirs = w->presort_dirs.p; d.splat_count = w->splat_count.p; d.nb = w->nb.p; d.cell = w->cell.p; d.st = w->st.p;
@@ -1049,9 +1051,9 @@ int gswt_worker_set_cells(gswt_worker* w, const gswt_cell* cells, size_t n_cells
     w->dev.sp.center_x = center_coord[0]; w->dev.sp.center_y = center_coord[1];
     if (w->dev.sp.surface_type != 2) {
         // update_tile_map re-creates every instance with merge_status None (:1745-1760); the sphere map is never rebuilt
-        WHIP(hipMemset(w->st.p, 0, n_cells * sizeof(gswt_cell_state)));
-        WHIP(hipMemset(w->head_len.p, 0, n_cells * 4));
-        WHIP(hipMemset(w->counts.p, 0, C_COUNT * 4));
+        WHIP(hipMemsetAsync(w->st.p, 0, n_cells * sizeof(gswt_cell_state), w->stream));
+        WHIP(hipMemsetAsync(w->head_len.p, 0, n_cells * 4, w->stream));
+        WHIP(hipMemsetAsync(w->counts.p, 0, C_COUNT * 4, w->stream));
     }
     w->have_cells = true; w->have_lod = false; w->have_sort = false; w->sort_pending = false;
     return GSWT_OK;

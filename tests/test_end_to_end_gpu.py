@@ -428,3 +428,38 @@ def test_deferred_swap_in_takes_effect_once_built(renderer):
         assert np.array_equal(pipe.render(cu_fix, W, Hh), third)
     finally:
         renderer.set_option(L.GSWT_OPT_DEFER_SWAP, 0)
+
+
+def test_first_frames_of_fresh_contexts_fill_every_slot():
+    """The FIRST frame of every frame slot of a new context, all in flight at once (first use allocates and clears the slot's
+    buffers: a clear that is not ordered on the slot's non-blocking stream can land after the frame's own kernels -- the slot's
+    first frame then came back as background).  Several fresh contexts, each compared with its own synchronous frames."""
+    import torch
+    from gswt_renderer_amd.renderer import GSWTRenderer
+    cfg = dict(tile_map_half_wh=(3, 3), surface_type=0, lod_max_dist=20.0, tile_sort_type=3, merge_type=2)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=700)
+    W, Hh = 240, 160
+    pos = (4.2, 1.0, 2.0)
+    for rep in range(4):
+        r = GSWTRenderer(0)
+        try:
+            pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=r)
+            slots = r.frame_slots()
+            tgts = [(5.0 - 0.3 * k, 3.0 + 0.2 * k, 1.5 - 0.05 * k) for k in range(slots)]
+            cams = [host.camera_uniforms(pos, t, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh) for t in tgts]
+            pipe.update(pos, cams[0][1])
+            su = pipe.wang.scene_uniforms()
+            outs = [torch.zeros((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+            torch.cuda.synchronize()
+            tickets = [r.render_async(cu, su, W, Hh, o.data_ptr()) for (cu, _), o in zip(cams, outs)]      # every slot's first frame
+            assert sorted(tickets) == list(range(slots))
+            for t in tickets:
+                r.render_wait(t)
+            torch.cuda.synchronize()
+            got = [o.cpu().numpy() for o in outs]
+            want = [r.render(cu, su, W, Hh) for cu, _ in cams]
+            for k in range(slots):
+                assert got[k].any(), (rep, k)
+                assert np.array_equal(got[k], want[k]), (rep, k)
+        finally:
+            r.close()
