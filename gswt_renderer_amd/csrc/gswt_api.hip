@@ -89,6 +89,10 @@ struct DevBuf {
 
 struct ListRef { uint32_t pair_base, pair_count, self_base, self_count; };
 
+// Behind synchronous copies whose data the frames read: the frame slots' streams are non-blocking, i.e. not ordered behind the
+// null stream, and a synchronous copy from pageable memory may return once the data is staged.  Setup paths only.
+static inline hipError_t null_stream_done() { return hipStreamSynchronize(nullptr); }
+
 // pinned host staging (asynchronous uploads read it after the call has returned)
 template <typename T>
 struct HostBuf {
@@ -645,6 +649,7 @@ try {
     if (arena.size() >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_upload_scene: static lists exceed 2^32 entries");
     HIP_TRY(c, c->static_list.ensure(arena.size() + 1));
     HIP_TRY(c, hipMemcpy(c->static_list.p, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, null_stream_done());
     c->n_lod = n_lod; c->n_tile = n_tile; c->n_view = n_view;
     c->scene_ready = true;
     return GSWT_OK;
@@ -658,6 +663,7 @@ try {
     if (!height_map || hm_w <= 0 || hm_h <= 0) { c->hm_w = c->hm_h = 0; return GSWT_OK; }
     HIP_TRY(c, c->hmap.ensure((size_t)hm_w * hm_h));
     HIP_TRY(c, hipMemcpy(c->hmap.p, height_map, (size_t)hm_w * hm_h * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, null_stream_done());
     c->hm_w = hm_w; c->hm_h = hm_h;
     return GSWT_OK;
 } GSWT_CATCH("gswt_configure")
@@ -808,6 +814,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
         }
         HIP_TRY(c, hipMemcpy(D.merged_list.p, packed.data(), n_merged * 4, hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(D.merged_map.p, merged_map_id, n_merged * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, null_stream_done());
     }
     D.n_draws = (uint32_t)n_draws;
     D.n_chunks = (uint32_t)n_chunks;
@@ -862,6 +869,7 @@ try {
         }
     HIP_TRY(c, c->raw_depth.ensure(total + 1));
     if (total) HIP_TRY(c, hipMemcpy(c->raw_depth.p, arena.data(), total * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, null_stream_done());
     return GSWT_OK;
 } GSWT_CATCH("gswt_upload_raw_depth")
 
@@ -1488,6 +1496,7 @@ try {
     const size_t n = (size_t)6 * face_size * face_size;
     HIP_TRY(c, c->sky_faces.ensure(n));
     HIP_TRY(c, hipMemcpy(c->sky_faces.p, faces_rgba, n * 16, hipMemcpyHostToDevice));
+    HIP_TRY(c, null_stream_done());
     c->sky_size = face_size; c->sky_equi = equirectangular ? 1 : 0;
     return GSWT_OK;
 } GSWT_CATCH("gswt_skybox_configure")
@@ -1522,6 +1531,7 @@ try {
     HIP_TRY(c, c->proxy_tex.ensure(total));
     for (int l = 0; l < n_mips; l++)
         HIP_TRY(c, hipMemcpy(c->proxy_tex.p + c->proxy_mip_off[l], mips[l], (size_t)(tex_size >> l) * (tex_size >> l) * 16, hipMemcpyHostToDevice));
+    HIP_TRY(c, null_stream_done());
     c->proxy_size = tex_size; c->proxy_mips = n_mips; c->proxy_grid_dim = grid_dim;
     return GSWT_OK;
 } GSWT_CATCH("gswt_proxy_configure")

@@ -924,7 +924,7 @@ template <typename T>
 int upload(gswt_worker* w, Dev<T>& d, const T* src, size_t n)
 {
     WHIP(d.alloc(n));
-    if (n) WHIP(hipMemcpy(d.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    if (n) { WHIP(hipMemcpy(d.p, src, n * sizeof(T), hipMemcpyHostToDevice)); WHIP(hipStreamSynchronize(nullptr)); }      // (the worker's stream is non-blocking: not ordered behind the null stream)
     return GSWT_OK;
 }
 
@@ -1048,6 +1048,7 @@ int gswt_worker_set_cells(gswt_worker* w, const gswt_cell* cells, size_t n_cells
     WHIP(hipSetDevice(w->device));
     WHIP(hipStreamSynchronize(w->stream));
     WHIP(hipMemcpy(w->cell.p, cells, n_cells * sizeof(gswt_cell), hipMemcpyHostToDevice));
+    WHIP(hipStreamSynchronize(nullptr));
     w->dev.sp.center_x = center_coord[0]; w->dev.sp.center_y = center_coord[1];
     if (w->dev.sp.surface_type != 2) {
         // update_tile_map re-creates every instance with merge_status None (:1745-1760); the sphere map is never rebuilt
