@@ -22,6 +22,7 @@ from __future__ import annotations
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -266,6 +267,7 @@ def main():
     ap.add_argument("--device-worker", action="store_true", help="fly path: run the per-sort-event worker stages on the GPU (gswt_worker_*) instead of libgswt_host")
     ap.add_argument("--graph", action="store_true", help="GSWT_OPT_GRAPH: replay each frame's launch sequence as one hipGraphLaunch (frames that carry timing events still launch kernel by kernel); default with --gpus N > 1, where a rank's frame is short enough for the submitting thread to matter")
     ap.add_argument("--no-graph", action="store_true", help="never use GSWT_OPT_GRAPH")
+    ap.add_argument("--segment", type=int, default=0, help="GSWT_OPT_SEGMENT, pairs per compositor work item (multiple of 256); 0 = from the first frame's pairs per screen tile: 4 x that, between the library's default and 4096 (dense scenes with the early-out on gain from long segments)")
     ap.add_argument("--static-steps", type=int, default=100, help="flypath mode: frames of the static-camera comparison run (0: skip)")
     args = ap.parse_args()
     if args.timing_every <= 0:
@@ -357,6 +359,16 @@ def main():
     # slot, so keeping fewer frames in flight also keeps fewer buffer sets in rotation.
     r.render_wait(r.render_async(cu0, su0, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, shard=shard))
     per_slot_bytes = 60.0 * float(r.timings()["n_instanced"])           # rects + records per list entry, roughly
+    # compositor work-item size: a segment of a tile's list cannot skip what the segments in front of it already saturated, so a dense
+    # frame (many pairs per screen tile) wants long segments; a sparse one is indifferent up to ~2 k (gswt_api.hip, opt_segment)
+    t0f = r.timings()
+    pairs_per_tile = float(t0f["n_pairs"]) / max(1.0, float(t0f["n_tiles"]))
+    if world > 1 and dist is not None and fake_world <= 1:
+        ppt = torch.tensor([pairs_per_tile], dtype=torch.float64, device=dev)
+        dist.all_reduce(ppt, op=dist.ReduceOp.MAX)             # every rank composites with the same segment length
+        pairs_per_tile = float(ppt.item())
+    segment = args.segment if args.segment > 0 else int(min(4096, max(L.GSWT_DEFAULT_SEGMENT, 256 * math.ceil(4.0 * pairs_per_tile / 256.0))))
+    r.set_option(L.GSWT_OPT_SEGMENT, segment)
     # three frames in flight on a static camera (a fourth costs 6 %: four buffer sets in rotation), four on the fly path (the
     # fourth covers the bubble a SortData swap-in leaves in the frame stream: +5 %)
     slots_static = min(slots, 3)
@@ -690,6 +702,7 @@ def main():
                        "transmittance_eps": args.t_eps, "skybox_proxy_passes": bool(use_passes),
                        "parallelism": f"screen-tile-column bands x{world} (projection culled per band) + RCCL all-gather" if world > 1 else "single GPU"},
             "frames_in_flight": slots,
+            "segment": segment,
             "sort_events": {"swapped_in": swaps, "swap_in_ms_mean": float(np.mean(swap_ms)) if swap_ms else None,
                             "merged_groups_sorted": mg_built, "merged_groups_copied_from_previous_event": mg_reused,
                             "takes_effect": "first frame submitted after the event's device-side list build has finished (GSWT_OPT_DEFER_SWAP = 1)" if defer_swap else ("third frame submitted after the swap-in, on every rank (GSWT_OPT_DEFER_SWAP = 3)" if (world > 1 and args.mode == "flypath" and not args.no_defer_swap) else "next frame (which waits for the build on the device)"),

@@ -24,6 +24,7 @@ GSWT_ORDER_DEPTH = 1
 GSWT_OPT_NO_LOD_PREFILTER = 1
 GSWT_OPT_DEBUG_VARYINGS = 2
 GSWT_OPT_SEGMENT = 3
+GSWT_DEFAULT_SEGMENT = 1536      # the library's default for GSWT_OPT_SEGMENT (tests that change it put this back)
 GSWT_OPT_DEBUG_FLAGS = 4
 GSWT_OPT_TIMING = 5
 GSWT_OPT_PAIR_CAP = 6

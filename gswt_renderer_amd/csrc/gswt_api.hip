@@ -317,7 +317,15 @@ struct gswt_ctx {
     int opt_debug_varyings = 0;
     int opt_dbg_flags = 0;
     int opt_timing = 2;      // 0: no events, 1: frame + k_composite, 2: every stage
-    int opt_segment = 512;   // pairs per compositor work item (multiple of 256); c3 sweep: 512 best
+    // pairs per compositor work item (multiple of 256).  A tile's list is cut into segments that are composited in parallel and folded
+    // by k_combine; a segment cannot know that the segments in front of it already saturated its pixels, so with the early-out on
+    // (transmittance_eps > 0) short segments redo work that a longer one would have skipped.  k_composite alone, us (stage events):
+    //   segment   512    768   1024   1536   2048   4096
+    //   c3        96.3   96.9   96.0   95.7   97.9  141.5     (horizon tiles of 5-7 k pairs serialise at 4096)
+    //   c3d (P = 8.2 M)  430    385    342    298    268    236
+    //   c5        551     -     542     -     540     -
+    // 1536 is the default; a host that knows its scene is dense raises it (bench.py: from the first frame's pairs per screen tile).
+    int opt_segment = 1536;
     int opt_fixed_pair_cap = 0;   // test hook (GSWT_OPT_PAIR_CAP): the pair capacity is pinned until a frame overflows it
     uint32_t last_n_tiles = 0;
     gswt_timings timings = {};

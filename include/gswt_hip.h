@@ -169,7 +169,8 @@ GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
  *   are identical (gswt.wgsl:38-42 discards the other LOD), only the entry count differs.
  * DEBUG_VARYINGS: keep vs_main's per-entry outputs for gswt_debug_read_projected. */
 enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
-       GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 512) */,
+       GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 1536; dense scenes with the early-out on
+                               gain from up to 4096: a segment cannot skip what the segments in front of it already saturated) */,
        GSWT_OPT_DEBUG_FLAGS = 4 /* ablation bits for profiling; output is wrong when nonzero */,
        GSWT_OPT_TIMING = 5 /* hipEvent timing: 0 none, 1 frame + k_composite, 2 every stage (default) */,
        GSWT_OPT_PAIR_CAP = 6 /* test hook: pin the pair-buffer capacity to `value` pairs until a frame overflows it (0: automatic) */,

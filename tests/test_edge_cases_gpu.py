@@ -76,14 +76,14 @@ def test_huge_splats_cover_many_tiles(renderer):
     cam = orc.default_camera(W, Hh).uniforms()
     su = orc.scene_uniforms(num_lod=pp.n_lod, map_half_wh=(1, 2), splat_scale=80.0)
     ref, st = orc.render(cam, su, pp.tex, case.orc_draws, W, Hh)
-    for seg in (256, 512, 2048):
+    for seg in (256, 512, 1536, 4096):
         renderer.set_option(L.GSWT_OPT_SEGMENT, seg)
         img = renderer.render(cam, su, W, Hh)
         assert renderer.timings()["n_pairs"] == st["n_pairs16"] > 100000
         assert H.max_abs_diff(img, ref) <= TOL
         img = renderer.render(cam, su, W, Hh, transmittance_eps=1e-5)
         assert H.max_abs_diff(img, ref) <= TOL
-    renderer.set_option(L.GSWT_OPT_SEGMENT, 512)
+    renderer.set_option(L.GSWT_OPT_SEGMENT, L.GSWT_DEFAULT_SEGMENT)
 
 
 def test_point_cloud_clip_and_scene_scale(renderer):

@@ -95,7 +95,7 @@ def test_more_than_8192_screen_tiles(renderer):
     try:
         img, ref, kinds, st = _run_case(renderer, cfg, ((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)), 2304, 1296, bg=True)
     finally:
-        renderer.set_option(L.GSWT_OPT_SEGMENT, 512)
+        renderer.set_option(L.GSWT_OPT_SEGMENT, L.GSWT_DEFAULT_SEGMENT)
     assert st["n_visible"] > 500
     assert H.max_abs_diff(img, ref) <= TOL
 

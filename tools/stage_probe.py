@@ -16,6 +16,8 @@ W, H = w["width"], w["height"]
 su = wang.scene_uniforms()
 r = GSWTRenderer(0)
 r.set_option(L.GSWT_OPT_TIMING, 2)
+if os.environ.get("GSWT_SEGMENT"):
+    r.set_option(L.GSWT_OPT_SEGMENT, int(os.environ["GSWT_SEGMENT"]))      # pairs per compositor work item
 if os.environ.get("GSWT_EXPANDED") is not None:
     r.set_option(L.GSWT_OPT_EXPANDED_LISTS, int(os.environ["GSWT_EXPANDED"]))
 wang.upload_to(r)
@@ -30,4 +32,4 @@ for i in range(n + 3):
         for k, v in r.timings().items():
             if k.startswith("ms_"):
                 acc[k] = acc.get(k, 0.0) + v / n
-print(os.path.basename(os.environ.get("GSWT_HIP_LIB", "default")), "expanded=" + os.environ.get("GSWT_EXPANDED", "default"), name, " ".join(f"{k[3:]}={v * 1e3:.1f}" for k, v in acc.items()), "us; pairs", r.timings()["n_pairs"], "checksum", float(out.sum()))
+print(os.path.basename(os.environ.get("GSWT_HIP_LIB", "default")), "segment=" + os.environ.get("GSWT_SEGMENT", "default"), name, " ".join(f"{k[3:]}={v * 1e3:.1f}" for k, v in acc.items()), "us; pairs", r.timings()["n_pairs"], "checksum", float(out.sum()))
