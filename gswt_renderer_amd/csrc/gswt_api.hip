@@ -1,6 +1,8 @@
-// gswt_api.hip -- C ABI of libgswt_hip.so (include/gswt_hip.h): context, HBM buffers, frame slots (two frames in flight,
-// each on its own stream with its own per-frame buffers) and the per-frame launch sequence
-// cull -> project -> totals -> emit -> sort -> ranges -> items -> composite -> combine; background passes; sharding.
+// gswt_api.hip -- C ABI of libgswt_hip.so (include/gswt_hip.h): context, HBM buffers, frame slots (up to five frames in flight,
+// each on its own stream with its own per-frame buffers), draw sets (one per frame in flight + 1, filled by sort events on a stream
+// of their own) and the per-frame launch sequence
+// cull -> project -> totals -> emit -> sort -> ranges -> items -> composite -> combine, launched kernel by kernel or replayed as one
+// hipGraphLaunch (GSWT_OPT_GRAPH); background passes; sharding; the framebuffer gather (RCCL or peer copies).
 //
 // HBM layout (all resident, sized for a 288 GB part; nothing is re-uploaded per frame):
 //   tex          U x 32 B      packed splat records, exactly Scene.tex_data (scene.rs:306-411)
@@ -10,7 +12,7 @@
 //   merged_*     4+4 B / entry per-sort-event merged-group lists (gs_index|lod, map_id)
 //   draws        DrawDev[]     one per reference draw call; chunk_tab maps a 256-entry workgroup
 //                              to (draw, first entry)
-//   rects/recs   8 + 48 B / slot  per-frame projection output, slot = composite order
+//   rects/recs   8 + 32 B / slot  per-frame projection output, slot = composite order (+ 4 B depth side array when depth-tested)
 //   keys/vals    2 x (4+4) B / pair  ping-pong for the tile sort
 #include "../../include/gswt_hip.h"
 #include "gswt_device.h"

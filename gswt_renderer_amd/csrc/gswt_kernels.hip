@@ -5,7 +5,7 @@
 //                   LOD blend, EWA projection, debug draw modes
 //   k_totals/k_emit : (splat, 16x16 screen tile) pair emission in composite order, no scan launches
 //   radix sort    : stable LSD sort of the pairs on the tile bits only; k_mg_* : merged-group lists on the device
-//   k_ranges/k_items : per-screen-tile [start, end) of the sorted pair list; work items (tile, <= 512-pair segment)
+//   k_ranges/k_items : per-screen-tile [start, end) of the sorted pair list; work items (tile, segment of its list: GSWT_OPT_SEGMENT pairs)
 //   k_composite   : front-to-back alpha compositing (fs_main gswt.wgsl:425-435 + blend/depth state
 //                   renderer.rs:118-129,179-185): LDS-staged batches, per-sub-block lists, wave ballot early termination
 //   k_combine     : folds the segment partials of long tile lists; k_unshard : all-gathered shards -> frame
