@@ -46,8 +46,7 @@ void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2
 void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
                  uint32_t*, uint32_t*);
-int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*);
-void launch_ranges(hipStream_t, const uint32_t*, uint32_t, const unsigned long long*, uint2*, uint32_t);
+int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, const unsigned long long*, unsigned long long*);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
@@ -1314,12 +1313,11 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     }
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
     // ---- stable sort on the tile bits
-    int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix);
-    const uint32_t* keys_sorted = where ? sl.keys_b.p : sl.keys_a.p;
+    // (the last pass also leaves every screen tile's [start, end) of the sorted pair list in sl.ranges, zeroed by k_cull)
+    int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p);
     const uint32_t* vals_sorted = where ? sl.vals_b.p : sl.vals_a.p;
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[4], s));
     // ---- ranges
-    launch_ranges(s, keys_sorted, cap, d_P, sl.ranges.p, (uint32_t)n_tiles);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[5], s));
     // ---- composite
     launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.depths.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
@@ -1819,6 +1817,8 @@ try {
     hipSetDevice(c->device);
     HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(out, c->slots[c->last_slot].ranges.p, (size_t)c->last_n_tiles * 8, hipMemcpyDeviceToHost));
+    for (uint32_t t = 0; t < c->last_n_tiles; t++)         // the device keeps (~start, end), (0, 0) for a tile without pairs
+        out[2 * (size_t)t] = out[2 * (size_t)t + 1] ? ~out[2 * (size_t)t] : 0u;
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_read_ranges")
 

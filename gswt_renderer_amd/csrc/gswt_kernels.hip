@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
                                                        const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
                                                        uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist,
                                                        const uint32_t* __restrict__ gsup, const uint32_t* __restrict__ gtot,
-                                                       uint32_t nblk, uint32_t nsup)
+                                                       uint32_t nblk, uint32_t nsup, uint2* __restrict__ ranges)
 {
     constexpr int kSortItems = kSortBlock / kSortThreads, kSortWaves = kSortThreads / 64;
     const uint32_t n = clamped_count(n_ptr, n_cap);
@@ -1144,8 +1144,18 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         if (i < n_blk) {
             const uint2 kv = s_kv[i];
             const uint32_t gp = s_g[(kv.x >> shift) & mask] + i;
-            keys_out[gp] = kv.x;
             vals_out[gp] = kv.y;
+            if (!ranges) keys_out[gp] = kv.x;
+            else {
+                // LAST pass of the frame's pair sort: the block in LDS is sorted by the whole key (the passes before ordered the
+                // input by the lower digits, stably), so the first and last item of every run of equal keys are neighbours' business --
+                // they leave the tile's [start, end) in the sorted pair list: start as ~start, both through atomicMax on the zeroed
+                // table, because a tile's run can continue in the next block.  This replaces a pass over the sorted keys (k_ranges,
+                // 5 us + a launch at c3), and the sorted keys themselves are not written any more: nothing reads them.
+                const uint32_t kp = s_kv[i == 0u ? 0u : i - 1u].x, kn = s_kv[min(i + 1u, n_blk - 1u)].x;
+                if (i == 0u || kp != kv.x) atomicMax(&ranges[kv.x].x, ~gp);
+                if (i == n_blk - 1u || kn != kv.x) atomicMax(&ranges[kv.x].y, gp + 1u);
+            }
         }
     }
 }
@@ -1337,28 +1347,10 @@ __global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ j
 }
 
 // ------------------------------------------------------------------------------------
-// k_ranges: [start, end) of each screen tile in the sorted pair list (ranges pre-zeroed)
+// [start, end) of each screen tile in the sorted pair list: left by the LAST pass of the pair sort (k_radix_scatter, `ranges`) as
+// (~start, end) per tile, (0, 0) for a tile without pairs; k_items decodes it.  (Until the end of round 2 a kernel of its own,
+// k_ranges, read the sorted keys back for it: 5 us + a launch at c3, 18 us at c5.)
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ranges(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
-                                                uint32_t n_cap, uint2* __restrict__ ranges)
-{
-    // four consecutive pairs per thread: one 16-byte load + the neighbour on either side (the key buffers are padded by four
-    // words); a quarter of the workgroups of the one-pair-per-thread form (c5, 21 M pairs: 34 us)
-    const uint32_t n = clamped_count(n_ptr, n_cap);
-    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-    if (i0 >= n) return;
-    const uint4 k4 = *reinterpret_cast<const uint4*>(keys + i0);
-    const uint32_t kp = keys[i0 == 0u ? 0u : i0 - 1u], kn = keys[min(i0 + 4u, n - 1u)];   // all three loads in flight together
-    const uint32_t k[6] = {kp, k4.x, k4.y, k4.z, k4.w, kn};
-#pragma unroll
-    for (uint32_t j = 0; j < 4u; j++) {
-        const uint32_t i = i0 + j;
-        if (i >= n) break;
-        if (i == 0u || k[j] != k[j + 1u]) ranges[k[j + 1u]].x = i;
-        if (i == n - 1u || k[j + 2u] != k[j + 1u]) ranges[k[j + 1u]].y = i + 1u;
-    }
-}
-
 // ------------------------------------------------------------------------------------
 // k_composite: one workgroup (4 wave64) per work item = (16x16 screen tile, segment of its pair list).
 // Wave w owns the 16x4 pixel strip of rows 4w .. 4w+3; inside a wave the four 16-lane groups own the
@@ -1395,8 +1387,9 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
     const uint32_t seg_sh = (uint32_t)__ffs((int)seg) - 1u;
     const int base = (int)blockIdx.x * 1024 * kPer;
     uint2 r[kPer];
+    // (ranges[t] = (~start, end) as the last sort pass leaves it, (0, 0) for a tile without pairs)
 #pragma unroll
-    for (int j = 0; j < kPer; j++) r[j] = ranges[min(base + j * 1024 + (int)threadIdx.x, last)];
+    for (int j = 0; j < kPer; j++) { r[j] = ranges[min(base + j * 1024 + (int)threadIdx.x, last)]; r[j].x = r[j].y ? ~r[j].x : 0u; }
     // segments of the tiles in front of this workgroup
     uint32_t carry = 0;
     if (base > 0) {
@@ -1404,7 +1397,7 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
         for (int t0 = 0; t0 < base; t0 += 1024 * kPer) {
             uint2 e[kPer];
 #pragma unroll
-            for (int j = 0; j < kPer; j++) e[j] = ranges[t0 + j * 1024 + (int)threadIdx.x];      // t0 + 8191 < base <= n_tiles
+            for (int j = 0; j < kPer; j++) { e[j] = ranges[t0 + j * 1024 + (int)threadIdx.x]; e[j].x = e[j].y ? ~e[j].x : 0u; }      // t0 + 8191 < base <= n_tiles
 #pragma unroll
             for (int j = 0; j < kPer; j++) {
                 const uint32_t len = e[j].y - e[j].x;
@@ -1937,7 +1930,7 @@ size_t radix_ws_zero_words(uint32_t n_cap, int key_bits)
 }
 
 int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n_cap,
-                const unsigned long long* n_ptr, int key_bits, uint32_t* ws)
+                const unsigned long long* n_ptr, int key_bits, uint32_t* ws, uint2* ranges = nullptr)
 {
     if (n_cap == 0) return 0;
     const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
@@ -1960,7 +1953,7 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         GSWT_LAUNCH(k_radix_hist<T>, dim3(nblk), dim3(T), s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup); \
         if (nsup > kSupDirect) GSWT_LAUNCH(k_radix_supscan, dim3(64), dim3(256), s, gsup, gtot, nsup);                          \
         GSWT_LAUNCH(k_radix_scatter<T>, dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
-                           ghist, gsup, gtot, nblk, nsup)
+                           ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr)
         if (threads == 512) { GSWT_SORT_PASS(512); }
         else { GSWT_SORT_PASS(256); }
 #undef GSWT_SORT_PASS
@@ -2009,12 +2002,6 @@ void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks
 }
 
 // `ranges` must be zero on entry (k_cull clears it each frame)
-void launch_ranges(hipStream_t s, const uint32_t* keys, uint32_t n_cap, const unsigned long long* n_ptr, uint2* ranges, uint32_t n_tiles)
-{
-    (void)n_tiles;
-    if (n_cap == 0) return;
-    GSWT_LAUNCH(k_ranges, dim3((n_cap + 1023) / 1024), dim3(256), s, keys, n_ptr, n_cap, ranges);
-}
 
 // ranges -> per-tile segment counts -> item_base (exclusive scan, item_base[n_tiles] = #items) ->
 // k_composite over an upper bound of items -> k_combine.
