@@ -53,8 +53,9 @@ def build_workload(name: str, lod0_override: int | None = None):
     return w, wang, cu, vp, sort
 
 
-def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, height_map=None):
-    """Times the CPU oracle (oracle/gswt_oracle.c, OpenMP) on ONE frame of the same workload."""
+def oracle_draws(wang, sort, vp, culling_dist=1.0):
+    """The draw list of a sort event as the CPU oracle takes it (tex, [orc.Draw]): the CPU viewport cull of renderer.rs:472-494
+    applied on the host (the HIP path does it on the device).  Checker-side only (cpu_baseline leg and tests)."""
     from oracle import gswt_oracle as orc
     tex, gi, li = wang.preload()
     draws = []
@@ -77,6 +78,13 @@ def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, he
             draws.append(orc.Draw(tu, sort.merged_gs_index[a:b], sort.merged_map_id[a:b], sort.merged_lod_id[a:b]))
         else:
             draws.append(orc.Draw(tu, gi[d.base_lod][d.base_tile][d.base_view], None, li[d.base_lod][d.base_tile][d.base_view]))
+    return tex, draws
+
+
+def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, height_map=None):
+    """Times the CPU oracle (oracle/gswt_oracle.c, OpenMP) on ONE frame of the same workload."""
+    from oracle import gswt_oracle as orc
+    tex, draws = oracle_draws(wang, sort, vp, culling_dist)
     ocu = orc.Camera176.from_buffer_copy(bytes(cu))
     osu = orc.Scene160.from_buffer_copy(bytes(su))
     # the GPU box gives one GPU's job a 16-core CPU share; the oracle's OpenMP team is sized to that

@@ -280,6 +280,10 @@ struct gswt_ctx {
     bool scene_ready = false;
     DevBuf<float> hmap;
     int hm_w = 0, hm_h = 0;
+    // bounds of the height map for the column-band cull on the HeightMap surface: texel min / max, and the largest texel-to-texel
+    // step along u and along v (repeat addressing) times the map's width / height = the largest slope of the bilinear surface
+    // per unit of u / v (a bilinear sample lies between its texels, a difference quotient of it below the largest texel slope)
+    float hm_min = 0.f, hm_max = 0.f, hm_du = 0.f, hm_dv = 0.f;
     // background passes
     DevBuf<float4> sky_faces;
     int sky_size = 0, sky_equi = 0;
@@ -337,6 +341,8 @@ struct gswt_ctx {
     int group_rank = 0;
     DevBuf<float4> gather_buf;             // world x shard image, as an all-gather delivers them
     hipEvent_t ev_push = nullptr;          // local group: this rank's shard has been pushed to every peer
+    hipEvent_t ev_unshard = nullptr;       // local group: this rank's re-assembly of the PREVIOUS gather has read its gather buffer
+    bool unshard_pending = false;          // ... and has been recorded at least once
 };
 
 namespace {
@@ -537,6 +543,7 @@ void gswt_destroy(gswt_ctx* c)
     c->group.clear();
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->ev_push) hipEventDestroy(c->ev_push);
+    if (c->ev_unshard) hipEventDestroy(c->ev_unshard);
     c->gather_buf.release();
     c->tex.release(); c->static_list.release(); c->hmap.release(); for (auto& ds : c->sets) ds.release();
     c->raw_depth.release(); 
@@ -672,6 +679,20 @@ try {
     if (!height_map || hm_w <= 0 || hm_h <= 0) { c->hm_w = c->hm_h = 0; return GSWT_OK; }
     HIP_TRY(c, c->hmap.ensure((size_t)hm_w * hm_h));
     HIP_TRY(c, hipMemcpy(c->hmap.p, height_map, (size_t)hm_w * hm_h * 4, hipMemcpyHostToDevice));
+    {
+        float mn = height_map[0], mx = height_map[0], du = 0.f, dv = 0.f;
+        bool finite = true;
+        for (int y = 0; y < hm_h; y++)
+            for (int x = 0; x < hm_w; x++) {
+                const float h = height_map[(size_t)y * hm_w + x];
+                const float hr = height_map[(size_t)y * hm_w + (x + 1 == hm_w ? 0 : x + 1)], hd = height_map[(size_t)(y + 1 == hm_h ? 0 : y + 1) * hm_w + x];
+                if (!(h == h) || h > 3e38f || h < -3e38f) finite = false;
+                mn = std::min(mn, h); mx = std::max(mx, h);
+                du = std::max(du, std::fabs(hr - h)); dv = std::max(dv, std::fabs(hd - h));
+            }
+        c->hm_min = mn; c->hm_max = mx; c->hm_du = du * (float)hm_w; c->hm_dv = dv * (float)hm_h;
+        if (!finite) { c->hm_min = -3e38f; c->hm_max = 3e38f; c->hm_du = c->hm_dv = 3e38f; }      // the band cull then keeps everything
+    }
     HIP_TRY(c, null_stream_done());
     c->hm_w = hm_w; c->hm_h = hm_h;
     return GSWT_OK;
@@ -1214,11 +1235,25 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         f.col1 = std::min(f.col0 + band_tiles, tiles_x_full);
         f.tiles_x = f.col1 - f.col0;
         f.out_w = band_tiles * kTile; f.out_x0 = cfg->shard_index * band_tiles * kTile;
-        // band culling needs positions that are the list positions: no surface mapping, no point-cloud covariance
-        f.band_cull = (su->surface_type == 0u && !(su->point_cloud_radius > 0.0f)) ? 1 : 0;
+        // band culling bounds where a cell's splats can land: the plain surface (positions are the list positions) and the
+        // HeightMap surface (the reference's default, structure.rs:75: the mapped centre is (x, y, h(x, y) hz) + n z with |n| = 1 and h
+        // between the map's extremes; the covariance becomes F Vrk F^T with |F|_F^2 <= 3 + slope_x^2 + slope_y^2).  Not the Sphere
+        // surface (its parametrisation has seams and poles: no cheap conservative bound) and not the point-cloud covariance.
+        f.band_cull = (su->surface_type <= 1u && !(su->point_cloud_radius > 0.0f)) ? 1 : 0;
     }
     for (int k = 0; k < 3; k++) { f.loc_lo[k] = c->loc_lo[k]; f.loc_hi[k] = c->loc_hi[k]; }
     f.loc_max_trace = c->loc_max_trace;
+    f.surf_zlo = f.surf_zhi = 0.0f; f.surf_f2 = 1.0f;
+    if (su->surface_type == 1u) {
+        const float hz = su->height_map_scale[2];
+        f.surf_zlo = std::min(c->hm_min * hz, c->hm_max * hz); f.surf_zhi = std::max(c->hm_min * hz, c->hm_max * hz);
+        // slopes of the mapped surface per world unit: |dh/du| hz / x_range, |dh/dv| hz / y_range (gswt.wgsl:565-599)
+        const float xr = (2.0f * (float)su->map_half_wh[0] + 1.0f) * su->tile_width * su->height_map_scale[0];
+        const float yr = (2.0f * (float)su->map_half_wh[1] + 1.0f) * su->tile_width * su->height_map_scale[1];
+        const float sx = c->hm_du * std::fabs(hz) / std::fabs(xr), sy = c->hm_dv * std::fabs(hz) / std::fabs(yr);
+        f.surf_f2 = (3.0f + sx * sx + sy * sy) * 1.01f;
+        if (!(f.surf_f2 == f.surf_f2) || !(f.surf_zlo == f.surf_zlo) || !(f.surf_zhi == f.surf_zhi)) f.band_cull = 0;
+    }
     f.hm_w = c->hm_w; f.hm_h = c->hm_h;
     f.dbg_flags = c->opt_dbg_flags;
 
@@ -1243,7 +1278,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     if (c->pair_cap == 0) c->pair_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(D.n_entries / 4, 1u << 20), 0xFFFFFF00ull);
     const uint32_t cap = c->pair_cap;
     sl.cap = cap;
-    HIP_TRY(c, sl.keys_a.ensure_roomy((size_t)cap + 4)); HIP_TRY(c, sl.keys_b.ensure_roomy((size_t)cap + 4));     // k_ranges reads whole quads
+    HIP_TRY(c, sl.keys_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.keys_b.ensure_roomy((size_t)cap + 1));
     HIP_TRY(c, sl.vals_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure_roomy((size_t)cap + 1));
     const size_t n_super2 = 3 * ((size_t)D.n_chunks / 256 + 1);     // pair sums, visible sums, exclusive pair prefix (k_totals)
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
@@ -1658,6 +1693,7 @@ try {
                 if (can) { hipError_t e = hipDeviceEnablePeerAccess(ctxs[p]->device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) HIP_TRY(c, e); (void)hipGetLastError(); }
             }
         if (!c->ev_push) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_push, hipEventDisableTiming));
+        if (!c->ev_unshard) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_unshard, hipEventDisableTiming));
         c->group.assign(ctxs, ctxs + n);
         c->group_rank = r;
     }
@@ -1708,11 +1744,15 @@ try {
         hipSetDevice(c->device);
         HIP_TRY(c, c->gather_buf.ensure((size_t)n * g.px));
     }
-    // 2. push: rank r copies its shard into slot r of every peer's gather buffer (xGMI peer copies; a plain copy on one device)
+    // 2. push: rank r copies its shard into slot r of every peer's gather buffer (xGMI peer copies; a plain copy on one device).
+    // A peer's gather buffer may still be read by the re-assembly of the PREVIOUS gather on the peer's own stream (gathers are
+    // issued back to back with frames in flight): the pushing stream first waits for that re-assembly (write-after-read).
     for (int r = 0; r < n; r++) {
         gswt_ctx* c = ctxs[r];
         hipSetDevice(c->device);
         const FrameSlot& sl = c->slots[tickets[r]];
+        for (int p = 0; p < n; p++)
+            if (p != r && ctxs[p]->unshard_pending) HIP_TRY(c, hipStreamWaitEvent(c->stream, ctxs[p]->ev_unshard, 0));
         for (int p = 0; p < n; p++)
             HIP_TRY(c, hipMemcpyPeerAsync(ctxs[p]->gather_buf.p + (size_t)r * g0.px, ctxs[p]->device, sl.args.d_out, c->device, g0.px * 16, c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_push, c->stream));
@@ -1731,6 +1771,8 @@ try {
                            gswt_shard_rows_padded(sl.args.height, n), g0.mode == GSWT_SHARD_COLUMNS ? g0.out_w : 0);
             HIP_TRY(c, hipGetLastError());
         }
+        HIP_TRY(c, hipEventRecord(c->ev_unshard, c->stream));
+        c->unshard_pending = true;
     }
     return GSWT_OK;
 } catch (...) { return GSWT_ERR_HIP; }

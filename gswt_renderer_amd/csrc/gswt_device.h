@@ -67,6 +67,8 @@ struct Frame {
     int32_t band_cull;                     // 1: k_cull drops the draws / merged-group members whose splats cannot reach the band
     float loc_lo[3], loc_hi[3];            // tile-local bounds of every splat centre of the scene (gswt_upload_scene)
     float loc_max_trace;                   // largest trace of a stored covariance (>= its largest eigenvalue)
+    float surf_zlo, surf_zhi;              // HeightMap surface: range of the mapped height h(x, y) * height_map_scale.z (0, 0 on the plain surface)
+    float surf_f2;                         // bound of |F|^2 of the surface frame F (1 on the plain surface): Vrk -> F Vrk F^T
     int32_t hm_w, hm_h;
     int32_t dbg_flags;       // profiling ablations (GSWT_OPT_DEBUG_FLAGS); 0 in normal operation
 };

@@ -221,13 +221,26 @@ __global__ __launch_bounds__(256) void k_chunk_tabs(const DrawDev* __restrict__ 
 // rank's pixel columns?  Conservative: the centres lie in the convex hull of the 8 projected box corners (all in front of
 // the camera, else keep), and a splat's pixel half extent is <= 2 s sqrt(lambda1) with lambda1 <= |J|_F^2 max(scene_scale)^2
 // trace(Vrk) at the nearest depth, capped by the 1024-px axis clamp (gswt.wgsl:257-258); 25 % + 2 px of slack on top.
+// lo / hi: bounds of the splat centres BEFORE scene_scale and surface mapping (cell origin + the scene's tile-local bounds).
+// HeightMap surface (gswt.wgsl:565-599): the mapped centre is (x, y, h(x, y) hz) + n z with |n| = 1, so x and y move by at most
+// |z| and the height lies in [surf_zlo - |z|, surf_zhi + |z|]; the covariance is F Vrk F^T, lambda1 <= |F|_F^2 trace(Vrk).
 __device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], const float hi[3])
 {
+    float blo[3], bhi[3];
+    for (int k = 0; k < 3; k++) {
+        const float a = lo[k] * f.scene_scale[k], b = hi[k] * f.scene_scale[k];
+        blo[k] = fminf(a, b); bhi[k] = fmaxf(a, b);
+    }
+    if (f.surface_type == 1u) {
+        const float zp = fmaxf(fabsf(blo[2]), fabsf(bhi[2])) * 1.0001f;
+        blo[0] -= zp; bhi[0] += zp; blo[1] -= zp; bhi[1] += zp;
+        blo[2] = f.surf_zlo - zp; bhi[2] = f.surf_zhi + zp;
+    }
     float xmin = 3.402823466e+38f, xmax = -3.402823466e+38f, wmin = 3.402823466e+38f;
     for (int k = 0; k < 8; k++) {
-        const float px = ((k & 1) ? hi[0] : lo[0]) * f.scene_scale[0];
-        const float py = ((k & 2) ? hi[1] : lo[1]) * f.scene_scale[1];
-        const float pz = ((k & 4) ? hi[2] : lo[2]) * f.scene_scale[2];
+        const float px = (k & 1) ? bhi[0] : blo[0];
+        const float py = (k & 2) ? bhi[1] : blo[1];
+        const float pz = (k & 4) ? bhi[2] : blo[2];
         const float cx = ((f.VP[0] * px + f.VP[4] * py) + f.VP[8] * pz) + f.VP[12];
         const float cw = ((f.VP[3] * px + f.VP[7] * py) + f.VP[11] * pz) + f.VP[15];
         wmin = fminf(wmin, cw);
@@ -238,7 +251,7 @@ __device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], c
     const float smax = fmaxf(fabsf(f.scene_scale[0]), fmaxf(fabsf(f.scene_scale[1]), fabsf(f.scene_scale[2])));
     const float hx = 1.3f * f.htan[0], hy = 1.3f * f.htan[1];
     const float jn2 = (f.focal[0] * f.focal[0] * (1.0f + hx * hx) + f.focal[1] * f.focal[1] * (1.0f + hy * hy)) / (wmin * wmin);
-    const float lam = jn2 * smax * smax * fmaxf(f.loc_max_trace, 0.0f);
+    const float lam = jn2 * smax * smax * fmaxf(f.loc_max_trace, 0.0f) * f.surf_f2;
     const float ss = fabsf(f.splat_scale);
     const float rad = fminf(2.0f * ss * sqrtf(lam), 1448.2f * ss) * 1.25f + 2.0f;
     if (!(rad == rad)) return false;
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
     for (uint32_t j = gtid; j < n_zero_b; j += gridDim.x * 256u) zero_b[j] = 0u;
     for (uint32_t j = gtid; j < n_zero_c; j += gridDim.x * 256u) zero_c[j] = 0u;       // per-chunk pair counts: culled chunks never run
     if (f.band_cull) {
-        uint32_t map_wh_y = 2u * f.map_half_wh[1] + 1u;                      // plain surface only (band_cull is off otherwise)
+        uint32_t map_wh_y = 2u * f.map_half_wh[1] + 1u;                      // plain / HeightMap surface (band_cull is off on the Sphere)
         for (uint32_t j = gtid; j < n_cells; j += gridDim.x * 256u) {
             // the merged-member offset of gswt.wgsl:52-63, same expression as k_project
             const float ox = (float)((int32_t)(j / map_wh_y - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
@@ -1446,6 +1459,18 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
     if (threadIdx.x == 0 && base + 1024 * kPer >= n_tiles) item_base[n_tiles] = carry + s_tot;      // the last workgroup
 }
 
+// -DGSWT_TRACE (tools/composite_trace.py): per work item, 100 MHz wall-clock stamps of the compositor's phases, left by lane 0 of wave 0:
+// [0] entry, [1] item known, [2] first batch staged (gathers have arrived), [3] last walk done, [4] pairs of the item,
+// [5] walk steps of wave 0 / of the wave, [6] ticks wave 0 spent in bin + walk, [7] hardware id (HW_ID | XCC_ID << 32)
+#ifdef GSWT_TRACE
+constexpr uint32_t kTraceItems = 1u << 17;
+__device__ unsigned long long g_trace[kTraceItems * 8];
+#define GSWT_TR(K, V) { if (tr_on) g_trace[(size_t)tr_item * 8u + (K)] = (unsigned long long)(V); }
+#define GSWT_NOW() wall_clock64()
+#else
+#define GSWT_TR(K, V)
+#define GSWT_NOW() 0ull
+#endif
 #ifdef GSWT_STATS
 __device__ unsigned long long g_stats[8];
 #define GSWT_STAT_STEP(C) { unsigned long long cm_ = __ballot(C); if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[0], 1ull); \
@@ -1627,9 +1652,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     // work item -> (tile, segment) through the table k_items left behind.  Consecutive items are dealt
     // round-robin over the 8 XCDs by the dispatcher, which balances the skewed tile-list lengths.
     const uint32_t item = blockIdx.x;
+#ifdef GSWT_TRACE
+    const bool tr_on = threadIdx.x == 0 && item < kTraceItems;
+    const uint32_t tr_item = item;
+    unsigned long long tr_walk = 0, tr_steps = 0;
+    bool tr_first = true;
+    GSWT_TR(0, GSWT_NOW())
+#endif
     const uint32_t n_items = item_base[n_tiles];
     const uint4 it = item_tab[item];                 // (in flight together with n_items; garbage past n_items, unused)
     if (item >= n_items) return;
+    GSWT_TR(1, GSWT_NOW())
+    GSWT_TR(4, it.w - it.z)
+#ifdef GSWT_TRACE
+    { unsigned hwid, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); GSWT_TR(7, (unsigned long long)hwid | ((unsigned long long)xcc << 32)) }
+#endif
     const int tile = (int)it.x;
     const bool multi_seg = (it.y & 1u) != 0u;
     const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
@@ -1721,6 +1758,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
             if (COLF) s_q2[tid] = rd;
         }
         __syncthreads();
+#ifdef GSWT_TRACE
+        if (tr_first) { GSWT_TR(2, GSWT_NOW()) tr_first = false; }
+        const unsigned long long tr_t0 = GSWT_NOW();
+#endif
         {
             if (abl_recs) slot_nxt = 0u;
             GSWT_LOAD_REC(slot_nxt)
@@ -1729,10 +1770,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
         }
         if (wave_live && !(f.dbg_flags & 2))               // ablation bit 2: stage only
             composite_bin_walk<EARLY, DEPTH, COLF>(f, cl, n, s_q0, s_q1, s_q2, s_bb, s_dep, wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
+#ifdef GSWT_TRACE
+        tr_walk += GSWT_NOW() - tr_t0;
+#endif
         if (base + 256u >= rg.y) break;                     // last batch of the item: nothing is staged after it, no barrier needed
         if (EARLY) { if (__syncthreads_and(wave_live ? 0 : 1)) break; }
         else __syncthreads();
     }
+    GSWT_TR(3, GSWT_NOW())
+    GSWT_TR(6, tr_walk)
     const float k255 = 1.0f / 255.0f;      // colour is continuous: sum(w * byte) / 255 vs sum(w * (byte / 255)) differ in the last bits only
     if (!COLF) { ar *= k255; ag *= k255; ab *= k255; }
     if (multi_seg) {
@@ -1767,6 +1813,292 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
 // The phases of this kernel add up (round-2 ablations at c3: 15 us launch + output, 28 us record gathers, 2.5 us binning,
 // 50 us walk), but hiding the gathers behind another item's walk inside a workgroup is not what makes them overlap: the
 // dispatcher's dynamic hand-out of ~16 k short workgroups does that better than a static stride over them.
+
+// ------------------------------------------------------------------------------------
+// k_composite_w (round 3): ONE WAVE per work item.  The wave owns the whole 16x16 tile -- a lane holds the pixel
+// (4 grp + (gi & 3), 4 s + (gi >> 2)) of each of the four 16x4 strips s -- and walks the strips one after the other, every
+// strip with the bin + walk of k_composite (four 4x4 sub-block lists, one splat per 16-lane group per step).  Same
+// canonical F3 / F4, same blend order per pixel, same partials layout: the image is bit-identical to k_composite's.
+// Why: in the four-wave workgroup a batch lasts as long as the slowest of its four strips (41 % of the wave-slots idle
+// at the two barriers per batch), and the four waves wait for ONE gather; a CU held 8 such chains.  Here nothing waits
+// for another wave (no s_barrier at all: a single-wave workgroup orders its LDS traffic by program order), a CU holds
+// up to 32 independent gather -> stage -> walk chains, and a chain carries four strips of walk per gather latency.
+// Batch = NB x 64 pairs (lane stages NB records).  The blend takes its colour as f16 (bytes 0..255 are exact) through
+// v_fma_mix_f32: fma(wgt, byte, acc) with the conversion folded in -- the same IEEE result as v_cvt_f32_ubyteN + v_fmac,
+// three VALU instructions per step less.  The staged record is q0 = (iu.x, iu.y, -ku, log2 alpha), q1 = (iv.x, iv.y, -kv,
+// red | green << 16 as halves) and a side word x = (pixel box bytes, blue as a half, depth bits); all three arrays are
+// addressed with the list entry (record index x 16) plus an immediate offset.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_lo_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
+__device__ __forceinline__ float half_hi_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
+
+template <bool EARLY, bool DEPTH, bool COLF, int NB, bool MIX>
+__device__ __forceinline__ void wave_bin_walk(const Frame& f, const int r0, const float lx, const float ly, const uint32_t lane, const uint32_t grp,
+                                              const uint32_t n, const char* const q0b, const char* const q1b, const char* const xb,
+                                              const char* const q2b, uint16_t* const wlist, const uint32_t list_stride, const float dbuf,
+                                              const float t_eps, float& T, float& ar, float& ag, float& ab, bool& live)
+{
+    constexpr uint32_t PB = (uint32_t)NB * 64u;
+    uint16_t* const my_list = wlist + grp * list_stride;
+    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) {
+        const uint32_t idx = (uint32_t)c * 64u + lane;
+        bool h0 = false, h1 = false, h2 = false, h3 = false;
+        if (idx < n) {
+            const uint32_t bb = *reinterpret_cast<const uint32_t*>(xb + idx * 16u);
+            const int xa = __builtin_amdgcn_sbfe((int)bb, 0, 8), xb2 = __builtin_amdgcn_sbfe((int)bb, 8, 8);
+            const int ya = __builtin_amdgcn_sbfe((int)bb, 16, 8), yb = __builtin_amdgcn_sbfe((int)bb, 24, 8);
+            const bool hy = yb >= r0 && ya <= r0 + 3;
+            h0 = hy && xa <= 3 && xb2 >= 0;
+            h1 = hy && xb2 >= 4 && xa <= 7;
+            h2 = hy && xb2 >= 8 && xa <= 11;
+            h3 = hy && xb2 >= 12 && xa <= 15;
+        }
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+#define GSWT_APPEND(H, M, CNT, G)                                                                                         \
+        if (M) {                                                                                                            \
+            if (H) wlist[(G) * list_stride + (CNT) + __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))] = (uint16_t)(idx * 16u); \
+            CNT += (uint32_t)__popcll(M);                                                                                   \
+        }
+        GSWT_APPEND(h0, m0, cnt0, 0u) GSWT_APPEND(h1, m1, cnt1, 1u) GSWT_APPEND(h2, m2, cnt2, 2u) GSWT_APPEND(h3, m3, cnt3, 3u)
+#undef GSWT_APPEND
+    }
+    const uint32_t n_mine = grp == 0u ? cnt0 : grp == 1u ? cnt1 : grp == 2u ? cnt2 : cnt3;
+    const uint32_t n_max = max(max(cnt0, cnt1), max(cnt2, cnt3));
+    if ((f.dbg_flags & 1) || n_max == 0u) return;
+    const uint32_t n_steps = (n_max + 1u) & ~1u;
+    for (uint32_t p = n_mine + (lane & 15u); p < n_steps + 2u; p += 16u) my_list[p] = (uint16_t)(PB * 16u);      // the null record
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#define GSWT_WREC0(O) (*reinterpret_cast<const float4*>(q0b + (O)))
+#define GSWT_WREC1(O) (*reinterpret_cast<const float4*>(q1b + (O)))
+#define GSWT_WREC2(O) (*reinterpret_cast<const float4*>(q2b + (O)))
+#define GSWT_WRECC(O) (*reinterpret_cast<const uint32_t*>(xb + (O) + 4u))      /* blue as a half */
+#define GSWT_WRECD(O) (*reinterpret_cast<const float*>(xb + (O) + 8u))         /* depth */
+#define GSWT_WSTEP(Q0, Q1, Q2, XC, XD)                                                                \
+    {                                                                                               \
+        const float pu_y = fmaf(Q0.y, ly, Q0.z);                                                    \
+        const float pv_y = fmaf(Q1.y, ly, Q1.z);                                                    \
+        const float ppx = fmaf(Q0.x, lx, pu_y);                                                     \
+        const float ppy = fmaf(Q1.x, lx, pv_y);                                                     \
+        const float r2 = fmaf(ppy, ppy, ppx * ppx);                                                 \
+        bool cover = r2 <= 4.0f;                                                                    \
+        if (DEPTH) cover = cover && XD < dbuf;                                                      \
+        if (__ballot(cover) != 0ull) {                                                              \
+            const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q0.w));           \
+            const float Bv = cover ? e : 0.0f;                                                      \
+            const float wgt = T * Bv;                                                               \
+            const uint32_t cw = __float_as_uint(Q1.w);                                              \
+            ar = fmaf(wgt, COLF ? Q2.x : MIX ? half_lo_f32(cw) : (float)(cw & 0xFFu), ar);          \
+            ag = fmaf(wgt, COLF ? Q2.y : MIX ? half_hi_f32(cw) : (float)((cw >> 8) & 0xFFu), ag);   \
+            ab = fmaf(wgt, COLF ? Q2.z : MIX ? half_lo_f32(XC) : (float)((cw >> 16) & 0xFFu), ab);  \
+            T = T - wgt;                                                                            \
+        }                                                                                           \
+    }
+    {
+        uint32_t kA = my_list[0], kB = my_list[1];
+        asm("" : "+v"(kA)); asm("" : "+v"(kB));
+        float4 a0 = GSWT_WREC0(kA), a1 = GSWT_WREC1(kA);
+        float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a2;
+        if (COLF) a2 = GSWT_WREC2(kA);
+        uint32_t ca = 0u, cb = 0u;
+        float da = 0.0f, db = 0.0f;
+        if (!COLF && MIX) ca = GSWT_WRECC(kA);
+        if (DEPTH) da = GSWT_WRECD(kA);
+        for (uint32_t i = 0; i < n_steps; i += 2u) {
+            const float4 b0 = GSWT_WREC0(kB), b1 = GSWT_WREC1(kB);
+            if (COLF) b2 = GSWT_WREC2(kB);
+            if (!COLF && MIX) cb = GSWT_WRECC(kB);
+            if (DEPTH) db = GSWT_WRECD(kB);
+            kA = my_list[i + 2u];
+            asm("" : "+v"(kA));
+            GSWT_WSTEP(a0, a1, a2, ca, da)
+            a0 = GSWT_WREC0(kA); a1 = GSWT_WREC1(kA);
+            if (COLF) a2 = GSWT_WREC2(kA);
+            if (!COLF && MIX) ca = GSWT_WRECC(kA);
+            if (DEPTH) da = GSWT_WRECD(kA);
+            kB = my_list[i + 3u];
+            asm("" : "+v"(kB));
+            GSWT_WSTEP(b0, b1, b2, cb, db)
+        }
+    }
+#undef GSWT_WSTEP
+#undef GSWT_WREC0
+#undef GSWT_WREC1
+#undef GSWT_WREC2
+#undef GSWT_WRECC
+#undef GSWT_WRECD
+    if (EARLY && __ballot(T >= t_eps) == 0ull) live = false;
+}
+
+template <bool EARLY, bool DEPTH, bool COLF, int NB, bool MIX>
+__global__ __launch_bounds__(64) void k_composite_w(const Frame f, const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
+                                                     const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
+                                                     const float* __restrict__ depths, const float4* __restrict__ col_f,
+                                                     const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
+                                                     float4* __restrict__ out, float4* __restrict__ partials, int n_tiles, int out_rows)
+{
+    constexpr uint32_t PB = (uint32_t)NB * 64u;          // pairs per batch
+    constexpr uint32_t kStride = PB + 8u;                // u16 entries per sub-block list (hits + even padding + 2 of prefetch overrun)
+    __shared__ float4 s_q0[PB + 1], s_q1[PB + 1];        // [PB] = the null record
+    __shared__ uint4 s_x[PB + 1];                        // (pixel box bytes, blue as a half, depth bits, -)
+    __shared__ float4 s_q2[COLF ? PB + 1 : 1];
+    __shared__ uint16_t s_list[4][kStride];
+    const uint32_t item = blockIdx.x;
+#ifdef GSWT_TRACE
+    const bool tr_on = threadIdx.x == 0 && item < kTraceItems;
+    const uint32_t tr_item = item;
+    unsigned long long tr_walk = 0;
+    bool tr_first = true;
+    GSWT_TR(0, GSWT_NOW())
+#endif
+    const uint32_t n_items = item_base[n_tiles];
+    const uint4 it = item_tab[item];
+    if (item >= n_items) return;
+    GSWT_TR(1, GSWT_NOW())
+    GSWT_TR(4, it.w - it.z)
+#ifdef GSWT_TRACE
+    { unsigned hwid, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); GSWT_TR(7, (unsigned long long)hwid | ((unsigned long long)xcc << 32)) }
+#endif
+    const int tile = (int)it.x;
+    const bool multi_seg = (it.y & 1u) != 0u;
+    const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
+    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
+    const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
+    const int bx = (tx + f.col0) * kTile, by = ty * kTile;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t grp = lane >> 4, gi = lane & 15u;
+    const int lxi = (int)grp * 4 + (int)(gi & 3u), lyi0 = (int)(gi >> 2);
+    const float lx = (float)lxi + 0.5f, ly0 = (float)lyi0 + 0.5f;
+    const float fbx = (float)bx, fby = (float)by;
+    const uint2 rg = make_uint2(it.z, it.w);
+    float T[4], ar[4], ag[4], ab[4], dbuf[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int px = bx + lxi, py = by + 4 * s + lyi0;
+        const bool inside = px < f.width && py < f.height;
+        T[s] = (EARLY && !inside) ? 0.0f : 1.0f; ar[s] = ag[s] = ab[s] = 0.0f;
+        dbuf[s] = 1.0f;
+        if (DEPTH && inside) dbuf[s] = bg_depth[(size_t)py * f.width + px];
+    }
+    const float t_eps = f.t_eps;
+    bool live0 = true, live1 = true, live2 = true, live3 = true;
+    if (lane == 0) {
+        s_q0[PB] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);       // r^2 = +inf for every pixel
+        s_q1[PB] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_x[PB] = make_uint4(0u, 0u, 0u, 0u);
+        if (COLF) s_q2[PB] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 ra[NB], rb[NB], rd[NB];
+    float rbw[NB];
+    uint32_t slot_nxt[NB];
+    const uint32_t last_pair = rg.y - 1u;
+#pragma unroll
+    for (int k = 0; k < NB; k++) { ra[k] = rb[k] = rd[k] = make_float4(0.f, 0.f, 0.f, 0.f); rbw[k] = 0.f; slot_nxt[k] = 0u; }
+    if (rg.x < rg.y) {
+        uint32_t s0[NB];
+#pragma unroll
+        for (int k = 0; k < NB; k++) s0[k] = vals[min(rg.x + (uint32_t)k * 64u + lane, last_pair)];
+#pragma unroll
+        for (int k = 0; k < NB; k++) slot_nxt[k] = vals[min(rg.x + PB + (uint32_t)k * 64u + lane, last_pair)];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const float4* rp = reinterpret_cast<const float4*>(recs + s0[k]);
+            ra[k] = rp[0]; rb[k] = rp[1];
+            if (DEPTH) rbw[k] = depths[s0[k]];
+            if (COLF) rd[k] = col_f[s0[k]];
+        }
+    }
+    const char* const q0b = reinterpret_cast<const char*>(s_q0);
+    const char* const q1b = reinterpret_cast<const char*>(s_q1);
+    const char* const xb = reinterpret_cast<const char*>(s_x);
+    const char* const q2b = reinterpret_cast<const char*>(s_q2);
+    for (uint32_t base = rg.x; base < rg.y; base += PB) {
+        const uint32_t n = min(PB, rg.y - base);
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const uint32_t idx = (uint32_t)k * 64u + lane;
+            if (idx < n) {
+                // F3 and the tile-local pixel-centre box: as in k_composite
+                const float ox = rb[k].x - fbx, oy = rb[k].y - fby;
+                const float nku = -fmaf(ra[k].x, ox, ra[k].y * oy);
+                const float nkv = -fmaf(ra[k].z, ox, ra[k].w * oy);
+                const uint32_t cw = __float_as_uint(rb[k].w);
+                const uint32_t rgh = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)(float)(cw & 0xFFu)) |
+                                     ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)(float)((cw >> 8) & 0xFFu)) << 16);
+                const uint32_t bh = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)(float)((cw >> 16) & 0xFFu));
+                s_q0[idx] = make_float4(ra[k].x, ra[k].y, nku, __builtin_amdgcn_logf(rb[k].z));
+                s_q1[idx] = make_float4(ra[k].z, ra[k].w, nkv, MIX ? __uint_as_float(rgh) : rb[k].w);
+                const float ria = __builtin_amdgcn_rcpf(fmaf(ra[k].y, ra[k].y, ra[k].x * ra[k].x)), rib = __builtin_amdgcn_rcpf(fmaf(ra[k].w, ra[k].w, ra[k].z * ra[k].z));
+                const float qux = ra[k].x * ria, quy = ra[k].y * ria, qwx = ra[k].z * rib, qwy = ra[k].w * rib;
+                const float bhx = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwx, qwx, qux * qux)), 1.0001f, 0.002f);
+                const float bhy = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwy, qwy, quy * quy)), 1.0001f, 0.002f);
+                const int xa = min(max((int)ceilf((ox - bhx) - 0.5f), -2), 17), xb2 = min(max((int)floorf((ox + bhx) - 0.5f), -2), 17);
+                const int ya = min(max((int)ceilf((oy - bhy) - 0.5f), -2), 17), yb = min(max((int)floorf((oy + bhy) - 0.5f), -2), 17);
+                const uint32_t bb = (uint32_t)(xa & 0xFF) | ((uint32_t)(xb2 & 0xFF) << 8) | ((uint32_t)(ya & 0xFF) << 16) | ((uint32_t)(yb & 0xFF) << 24);
+                s_x[idx] = make_uint4(bb, bh, __float_as_uint(rbw[k]), 0u);
+                if (COLF) s_q2[idx] = rd[k];
+            }
+        }
+        // one wave: LDS operations complete in program order, the fences only keep the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef GSWT_TRACE
+        if (tr_first) { GSWT_TR(2, GSWT_NOW()) tr_first = false; }
+        const unsigned long long tr_t0 = GSWT_NOW();
+#endif
+        // the next batch's records and the one-after-next's slot indices are in flight during the walk
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const float4* rp = reinterpret_cast<const float4*>(recs + slot_nxt[k]);
+            ra[k] = rp[0]; rb[k] = rp[1];
+            if (DEPTH) rbw[k] = depths[slot_nxt[k]];
+            if (COLF) rd[k] = col_f[slot_nxt[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) slot_nxt[k] = vals[min(base + 2u * PB + (uint32_t)k * 64u + lane, last_pair)];
+        if (!(f.dbg_flags & 2)) {
+            if (live0) wave_bin_walk<EARLY, DEPTH, COLF, NB, MIX>(f, 0, lx, ly0, lane, grp, n, q0b, q1b, xb, q2b, &s_list[0][0], kStride, dbuf[0], t_eps, T[0], ar[0], ag[0], ab[0], live0);
+            if (live1) wave_bin_walk<EARLY, DEPTH, COLF, NB, MIX>(f, 4, lx, ly0 + 4.0f, lane, grp, n, q0b, q1b, xb, q2b, &s_list[0][0], kStride, dbuf[1], t_eps, T[1], ar[1], ag[1], ab[1], live1);
+            if (live2) wave_bin_walk<EARLY, DEPTH, COLF, NB, MIX>(f, 8, lx, ly0 + 8.0f, lane, grp, n, q0b, q1b, xb, q2b, &s_list[0][0], kStride, dbuf[2], t_eps, T[2], ar[2], ag[2], ab[2], live2);
+            if (live3) wave_bin_walk<EARLY, DEPTH, COLF, NB, MIX>(f, 12, lx, ly0 + 12.0f, lane, grp, n, q0b, q1b, xb, q2b, &s_list[0][0], kStride, dbuf[3], t_eps, T[3], ar[3], ag[3], ab[3], live3);
+        }
+#ifdef GSWT_TRACE
+        tr_walk += GSWT_NOW() - tr_t0;
+#endif
+        if (EARLY && !(live0 || live1 || live2 || live3)) break;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    GSWT_TR(3, GSWT_NOW())
+    GSWT_TR(6, tr_walk)
+    const float k255 = 1.0f / 255.0f;
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        float cr = ar[s], cg = ag[s], cb = ab[s];
+        if (!COLF) { cr *= k255; cg *= k255; cb *= k255; }
+        if (multi_seg) {
+            partials[(size_t)item * 256u + (uint32_t)s * 64u + lane] = make_float4(cr, cg, cb, T[s]);
+            continue;
+        }
+        const int px = bx + lxi, lyi = 4 * s + lyi0, py = by + lyi;
+        if (px < f.width && py < f.height) {
+            float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bg_rgba) bg = bg_rgba[(size_t)py * f.width + px];
+            float4 o;
+            o.x = fmaf(T[s], bg.x, cr);
+            o.y = fmaf(T[s], bg.y, cg);
+            o.z = fmaf(T[s], bg.z, cb);
+            o.w = fmaf(T[s], bg.w, 1.0f - T[s]);
+            const int orow = tyl * kTile + lyi;
+            if (orow < out_rows) out[(size_t)orow * f.out_w + (px - f.out_x0)] = o;
+        }
+    }
+}
 
 // Folds the per-segment partials of multi-segment tiles: (C1,T1) o (C2,T2) = (C1 + T1*C2, T1*T2).
 // One workgroup per tile, same lane -> pixel mapping as k_composite.
@@ -2019,6 +2351,32 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
+    if (f.dbg_flags & 0x1000) {          // experiment: the one-wave-per-item compositor (0x2000: 64-pair batches instead of 128)
+#define GSWT_LAUNCH_COMPOSITE_W(E, D, C, NB, MIX)                                                                               \
+        GSWT_LAUNCH((k_composite_w<E, D, C, NB, MIX>), dim3(max_items), dim3(64), s, f, item_base, item_tab, vals, recs, depths, col_f, \
+                    bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
+        // 0x2000: 64-pair batches instead of 128; 0x4000: byte colours (v_cvt_f32_ubyteN) instead of halves (v_fma_mix_f32)
+#define GSWT_LAUNCH_COMPOSITE_WN(E, D, C) { GSWT_LAUNCH_COMPOSITE_W(E, D, C, 2, true); }
+        if (colf) {
+            if (depth) GSWT_LAUNCH_COMPOSITE_WN(false, true, true)
+            else GSWT_LAUNCH_COMPOSITE_WN(false, false, true)
+        }
+        else if (early && depth) GSWT_LAUNCH_COMPOSITE_WN(true, true, false)
+        else if (depth) GSWT_LAUNCH_COMPOSITE_WN(false, true, false)
+        else if (early) {
+            const int v = (f.dbg_flags >> 13) & 3;
+            if (v == 0) GSWT_LAUNCH_COMPOSITE_W(true, false, false, 2, true);
+            else if (v == 1) GSWT_LAUNCH_COMPOSITE_W(true, false, false, 1, true);
+            else if (v == 2) GSWT_LAUNCH_COMPOSITE_W(true, false, false, 2, false);
+            else GSWT_LAUNCH_COMPOSITE_W(true, false, false, 1, false);
+        }
+        else GSWT_LAUNCH_COMPOSITE_WN(false, false, false)
+#undef GSWT_LAUNCH_COMPOSITE_WN
+#undef GSWT_LAUNCH_COMPOSITE_W
+        if (ev_end) hipEventRecord(ev_end, s);
+        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+        return;
+    }
 #define GSWT_LAUNCH_COMPOSITE(E, D, C)                                                                                         \
     GSWT_LAUNCH((k_composite<E, D, C>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
@@ -2047,6 +2405,14 @@ void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int widt
 }
 
 }  // namespace gswt
+#ifdef GSWT_TRACE
+extern "C" __attribute__((visibility("default"))) int gswt_debug_trace(unsigned long long* out, unsigned n_items)
+{
+    hipDeviceSynchronize();
+    if (n_items > gswt::kTraceItems) n_items = gswt::kTraceItems;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(gswt::g_trace), (size_t)n_items * 64);
+}
+#endif
 #ifdef GSWT_STATS
 extern "C" __attribute__((visibility("default"))) int gswt_debug_stats(unsigned long long* out)
 {

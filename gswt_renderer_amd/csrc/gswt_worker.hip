@@ -943,10 +943,16 @@ int read_counts(gswt_worker* w)
 
 }  // namespace
 
+// No C++ exception may unwind through the C ABI (std::string / std::mutex / std::lock_guard can throw, and these entry points are
+// called from a second host thread): every int-returning entry point below is a function-try-block.
+#define GSWT_WCATCH                                             \
+    catch (const std::bad_alloc&) { return GSWT_ERR_CAPACITY; } \
+    catch (...) { return GSWT_ERR_HIP; }
+
 extern "C" {
 
 int gswt_worker_create(gswt_ctx* ctx, const gswt_worker_config* cfg, gswt_worker** out)
-{
+try {
     if (!ctx || !cfg || !out) return GSWT_ERR_BAD_ARG;
     *out = nullptr;
     gswt_worker* w = new (std::nothrow) gswt_worker();
@@ -999,7 +1005,21 @@ int gswt_worker_create(gswt_ctx* ctx, const gswt_worker_config* cfg, gswt_worker
     if (e != hipSuccess) { gswt_worker_destroy(w); return GSWT_ERR_HIP; }
     // (stream-ordered: the worker's stream is non-blocking and does not wait for null-stream memsets)
     A(hipMemsetAsync(w->st.p, 0, cells * sizeof(gswt_cell_state), w->stream)); A(hipMemsetAsync(w->head_len.p, 0, cells * 4, w->stream));
-    A(hipMemsetAsync(w->counts.p, 0, C_COUNT * 4, w->stream)); A(hipMemsetAsync(w->n64.p, 0, 8 * sizeof(unsigned long long), w->stream));
+    A(hipMemsetAsync(w->counts.p, 0, C_COUNT * 4, w->stream));
+    {
+        // item counts of the two sorts a sort event may run (edge candidates, cells): fixed for the worker's life, so they are
+        // written here, once, from pinned memory and before the synchronize -- not per event from a stack array that an
+        // asynchronous copy could outlive
+        Pinned<unsigned long long> h;
+        A(h.alloc(8));
+        if (e == hipSuccess) {
+            for (int k = 0; k < 8; k++) h.p[k] = 0ull;
+            h.p[0] = n_cand; h.p[4] = cells;
+            A(hipMemcpyAsync(w->n64.p, h.p, 8 * sizeof(unsigned long long), hipMemcpyHostToDevice, w->stream));
+            A(hipStreamSynchronize(w->stream));
+        }
+        h.release();
+    }
     A(hipStreamSynchronize(w->stream));
     if (e != hipSuccess) { gswt_worker_destroy(w); return GSWT_ERR_HIP; }
     d.sp.height_map = w->height_map.p; d.lod_dist = w->lod_dist.p; d.tile_center = w->tile_center.p; d.tile_aabb = w->tile_aabb.p;
@@ -1020,7 +1040,7 @@ int gswt_worker_create(gswt_ctx* ctx, const gswt_worker_config* cfg, gswt_worker
 #undef WTRY
     *out = w;
     return GSWT_OK;
-}
+} GSWT_WCATCH
 
 void gswt_worker_destroy(gswt_worker* w)
 {
@@ -1040,7 +1060,7 @@ void gswt_worker_destroy(gswt_worker* w)
 const char* gswt_worker_last_error(const gswt_worker* w) { return w ? w->err.c_str() : "null worker"; }
 
 int gswt_worker_set_cells(gswt_worker* w, const gswt_cell* cells, size_t n_cells, const int32_t center_coord[2])
-{
+try {
     if (!w) return GSWT_ERR_BAD_ARG;
     if (!cells || !center_coord || n_cells != (size_t)w->cells) return wfail(w, GSWT_ERR_BAD_ARG, "gswt_worker_set_cells: expected the whole map");
     for (size_t i = 0; i < n_cells; i++)
@@ -1058,10 +1078,10 @@ int gswt_worker_set_cells(gswt_worker* w, const gswt_cell* cells, size_t n_cells
     }
     w->have_cells = true; w->have_lod = false; w->have_sort = false; w->sort_pending = false;
     return GSWT_OK;
-}
+} GSWT_WCATCH
 
 int gswt_worker_update_lod(gswt_worker* w, const float cam_pos[3])
-{
+try {
     if (!w) return GSWT_ERR_BAD_ARG;
     if (!cam_pos) return wfail(w, GSWT_ERR_BAD_ARG, "gswt_worker_update_lod: null argument");
     if (!w->have_cells) return wfail(w, GSWT_ERR_STATE, "gswt_worker_update_lod before gswt_worker_set_cells");
@@ -1071,10 +1091,10 @@ int gswt_worker_update_lod(gswt_worker* w, const float cam_pos[3])
     WHIP(hipGetLastError());
     w->have_lod = true;
     return GSWT_OK;
-}
+} GSWT_WCATCH
 
 int gswt_worker_sort_tiles(gswt_worker* w, const float cam_pos[3], const float vp16[16])
-{
+try {
     if (!w) return GSWT_ERR_BAD_ARG;
     if (!cam_pos || !vp16) return wfail(w, GSWT_ERR_BAD_ARG, "gswt_worker_sort_tiles: null argument");
     if (!w->have_lod) return wfail(w, GSWT_ERR_STATE, "WangTile::sort_tiles before build_tiles (gswt_worker_set_cells + gswt_worker_update_lod)");
@@ -1091,8 +1111,7 @@ int gswt_worker_sort_tiles(gswt_worker* w, const float cam_pos[3], const float v
     if (need_edges) hipLaunchKernelGGL(k_w_edges, dim3((n_cand + 255) / 256), dim3(256), 0, s, d, cam, vp, w->keys_a.p, w->vals_a.p, w->gdir.p);
     const uint32_t* sk = w->keys_a.p; const uint32_t* sv = w->vals_a.p;
     if (d.merge_type == MERGE_EDGE) {
-        const unsigned long long n64[4] = {n_cand, 0, 0, 0};
-        WHIP(hipMemcpyAsync(w->n64.p, n64, sizeof(n64), hipMemcpyHostToDevice, s));
+        // (w->n64[0] = n_cand, w->n64[4] = cells: written once by gswt_worker_create)
         WHIP(hipMemsetAsync(w->radix_ws.p, 0, w->radix_words * sizeof(uint32_t), s));
         const int where = gswt::launch_sort(s, w->keys_a.p, w->vals_a.p, w->keys_b.p, w->vals_b.p, n_cand, w->n64.p, 32, w->radix_ws.p);
         if (where) { sk = w->keys_b.p; sv = w->vals_b.p; }
@@ -1100,8 +1119,6 @@ int gswt_worker_sort_tiles(gswt_worker* w, const float cam_pos[3], const float v
     if (d.merge_type != MERGE_NONE) hipLaunchKernelGGL(k_w_merge, dim3(1), dim3(64), w->lds_merge, s, d, cam, vp, sk, sv);
     if (d.sort_type == SORT_DISTANCE || d.sort_type == SORT_VIEWPORT) {
         hipLaunchKernelGGL(k_w_order_keys, dim3((cells + 255) / 256), dim3(256), 0, s, d, cam, vp, w->keys_a.p, w->vals_a.p);
-        const unsigned long long n64[4] = {cells, 0, 0, 0};
-        WHIP(hipMemcpyAsync(w->n64.p + 4, n64, sizeof(n64), hipMemcpyHostToDevice, s));
         WHIP(hipMemsetAsync(w->radix_ws.p, 0, w->radix_words * sizeof(uint32_t), s));
         const int where = gswt::launch_sort(s, w->keys_a.p, w->vals_a.p, w->keys_b.p, w->vals_b.p, cells, w->n64.p + 4, 32, w->radix_ws.p);
         hipLaunchKernelGGL(k_w_order_reverse, dim3((cells + 255) / 256), dim3(256), 0, s, d, where ? w->vals_b.p : w->vals_a.p, w->order.p);
@@ -1115,10 +1132,10 @@ int gswt_worker_sort_tiles(gswt_worker* w, const float cam_pos[3], const float v
     WHIP(hipGetLastError());
     w->have_sort = true; w->sort_pending = true;
     return GSWT_OK;
-}
+} GSWT_WCATCH
 
 int gswt_worker_read_cell_state(gswt_worker* w, gswt_cell_state* out, size_t capacity)
-{
+try {
     if (!w) return GSWT_ERR_BAD_ARG;
     if (!out || capacity < (size_t)w->cells) return wfail(w, GSWT_ERR_BAD_ARG, "gswt_worker_read_cell_state: capacity");
     WHIP(hipSetDevice(w->device));
@@ -1126,10 +1143,10 @@ int gswt_worker_read_cell_state(gswt_worker* w, gswt_cell_state* out, size_t cap
     WHIP(hipMemcpy(out, w->st.p, (size_t)w->cells * sizeof(gswt_cell_state), hipMemcpyDeviceToHost));
     for (int i = 0; i < w->cells; i++) if (out[i].merge != MS_TO) out[i].merged_to = 0;
     return GSWT_OK;
-}
+} GSWT_WCATCH
 
 int gswt_worker_fetch(gswt_worker* w)
-{
+try {
     if (!w) return GSWT_ERR_BAD_ARG;
     if (!w->have_sort) return wfail(w, GSWT_ERR_STATE, "gswt_worker_fetch before gswt_worker_sort_tiles");
     WHIP(hipSetDevice(w->device));
@@ -1157,10 +1174,10 @@ int gswt_worker_fetch(gswt_worker* w)
     }
     w->sort_pending = false;
     return GSWT_OK;
-}
+} GSWT_WCATCH
 
 int gswt_worker_read_sort(gswt_worker* w, gswt_sort_data* out)
-{
+try {
     if (!w) return GSWT_ERR_BAD_ARG;
     if (!out) return wfail(w, GSWT_ERR_BAD_ARG, "gswt_worker_read_sort: null argument");
     if (!w->have_sort) return wfail(w, GSWT_ERR_STATE, "gswt_worker_read_sort before gswt_worker_sort_tiles");
@@ -1176,10 +1193,10 @@ int gswt_worker_read_sort(gswt_worker* w, gswt_sort_data* out)
     out->n_groups = c[C_N_GROUPS]; out->n_members = c[C_N_MEMBERS];
     out->groups = h.groups.p; out->members = h.members.p;
     return GSWT_OK;
-}
+} GSWT_WCATCH
 
 int gswt_set_draws_from_worker(gswt_ctx* ctx, gswt_worker* w)
-{
+try {
     if (!ctx || !w) return GSWT_ERR_BAD_ARG;
     if (w->ctx != ctx) return GSWT_ERR_BAD_ARG;
     int b;
@@ -1197,6 +1214,6 @@ int gswt_set_draws_from_worker(gswt_ctx* ctx, gswt_worker* w)
         w->in_use = -1;
     }
     return r;                                          // failure text: gswt_last_error(ctx)
-}
+} GSWT_WCATCH
 
 }  // extern "C"

@@ -506,11 +506,33 @@ static void debug_draw_color(const orc_scene *s, const orc_tile *u, const float 
     }
 }
 
+/* ------------------------------------------------------------------------- */
+/* STRICT mode: the shader text, operator by operator.                         */
+/*                                                                             */
+/* The default sequence ("v2", what the HIP kernels reproduce bit for bit)      */
+/* evaluates A6..A10 and F1/F2 with fma chains and ONE reciprocal per quotient. */
+/* WGSL permits that, but it is a CHOSEN rounding sequence.  With strict mode   */
+/* on, orc_project evaluates gswt.wgsl:152-258,402-419 as written -- every `*`, */
+/* `+`, `-`, `/` its own correctly rounded binary32 operation, matrix * vector  */
+/* as the left-to-right sum of column products, length() = sqrt(x*x + y*y),     */
+/* normalize() = v / length(v), no fused multiply-add anywhere -- and the       */
+/* fragment stage takes v_position at a pixel centre from the exact (double     */
+/* precision) affine inverse of the quad (the hardware interpolator is not in   */
+/* the shader text), rounds it to binary32 and evaluates fs_main                */
+/* (gswt.wgsl:425-435) as written: A = -dot(p, p); discard if A < -4;           */
+/* B = exp(A) * alpha.  The strict image is the anchor the v2 image and the GPU */
+/* image are both measured against (tests/test_strict_oracle*.py).             */
+/* Process-wide switch; set it before orc_render / orc_project_draws.          */
+/* ------------------------------------------------------------------------- */
+static int g_strict = 0;
+ORC_API void orc_set_strict(int on) { g_strict = on ? 1 : 0; }
+ORC_API int orc_get_strict(void) { return g_strict; }
+
 /* vs_main, gswt.wgsl:27-422, every draw_mode.  Canonical float sequence "A1..A10"
  * of DESIGN.md.  Returns out->visible. */
-ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_tile *u,
+static int project_impl(const orc_camera *cam, const orc_scene *s, const orc_tile *u,
                         const uint32_t *tex, uint32_t gs_index, uint32_t map_id, uint32_t lod_id,
-                        const float *hmap, int hm_w, int hm_h, orc_splat *out)
+                        const float *hmap, int hm_w, int hm_h, orc_splat *out, int strict_mode)
 {
     memset(out, 0, sizeof(*out));
     /* A1 :38-42 */
@@ -573,6 +595,111 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
         t_ratio = clampf((cam_dist - td) / thw + 0.5f, 0.0f, 1.0f);
         if ((lod_id == higher_lod + 1u && t_ratio == 0.0f) || (lod_id == higher_lod && t_ratio == 1.0f))
             return 0;
+    }
+    if (strict_mode) {
+        /* A6..A10 as the shader writes them (gswt.wgsl:152-258, 260-265, 402-419) */
+        const float *V = cam->view, *P = cam->projection;
+        float cv[4];                        /* cam = view * vec4(center, 1.0) */
+        for (int r = 0; r < 4; r++) cv[r] = ((V[r] * c[0] + V[4 + r] * c[1]) + V[8 + r] * c[2]) + V[12 + r] * 1.0f;
+        /* opengl_to_wgpu * projection (left-associative): rows 0, 1, 3 of P unchanged (x*1 + 0*.. exact), row 2 = 0.5 P2 + 0.5 P3 */
+        float GP[16];
+        for (int cc = 0; cc < 4; cc++) {
+            GP[4 * cc + 0] = P[4 * cc + 0];
+            GP[4 * cc + 1] = P[4 * cc + 1];
+            GP[4 * cc + 2] = 0.5f * P[4 * cc + 2] + 0.5f * P[4 * cc + 3];
+            GP[4 * cc + 3] = P[4 * cc + 3];
+        }
+        float q[4];
+        for (int r = 0; r < 4; r++)
+            q[r] = ((GP[r] * cv[0] + GP[4 + r] * cv[1]) + GP[8 + r] * cv[2]) + GP[12 + r] * cv[3];
+        float clip = 1.2f * q[3];
+        if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) return 0;
+        float a = orc_half_to_float(rec[4] & 0xFFFFu), b = orc_half_to_float(rec[4] >> 16);
+        float c2 = orc_half_to_float(rec[5] & 0xFFFFu), d = orc_half_to_float(rec[5] >> 16);
+        float e = orc_half_to_float(rec[6] & 0xFFFFu), f = orc_half_to_float(rec[6] >> 16);
+        float K[9] = { a, b, c2, b, d, e, c2, e, f };
+        if (s->point_cloud_radius > 0.0f) {
+            float pr = s->point_cloud_radius;
+            if (s->draw_mode > 0u) pr *= ldexpf(1.0f, (int)u->tile_id[0]);
+            K[0] = pr; K[1] = 0; K[2] = 0; K[3] = 0; K[4] = pr; K[5] = 0; K[6] = 0; K[7] = 0; K[8] = pr;
+        }
+        if (s->surface_type > 0u) {         /* Vrk = transform * Vrk * transpose(transform) */
+            float FK[9], R[9];
+            for (int cc = 0; cc < 3; cc++)
+                for (int r = 0; r < 3; r++)
+                    FK[3 * cc + r] = (F[r] * K[3 * cc] + F[3 + r] * K[3 * cc + 1]) + F[6 + r] * K[3 * cc + 2];
+            for (int cc = 0; cc < 3; cc++)
+                for (int r = 0; r < 3; r++)
+                    R[3 * cc + r] = (FK[r] * F[cc] + FK[3 + r] * F[3 + cc]) + FK[6 + r] * F[6 + cc];
+            memcpy(K, R, sizeof(K));
+        }
+        {                                   /* scene_scale_mat * Vrk * transpose(scene_scale_mat), full matrix products */
+            const float S[9] = { s->scene_scale[0], 0, 0, 0, s->scene_scale[1], 0, 0, 0, s->scene_scale[2] };
+            float SK[9], R[9];
+            for (int cc = 0; cc < 3; cc++)
+                for (int r = 0; r < 3; r++)
+                    SK[3 * cc + r] = (S[r] * K[3 * cc] + S[3 + r] * K[3 * cc + 1]) + S[6 + r] * K[3 * cc + 2];
+            for (int cc = 0; cc < 3; cc++)
+                for (int r = 0; r < 3; r++)
+                    R[3 * cc + r] = (SK[r] * S[cc] + SK[3 + r] * S[3 + cc]) + SK[6 + r] * S[6 + cc];
+            memcpy(K, R, sizeof(K));
+        }
+        float dd[3] = { c[0] - cam->cam_pos[0], c[1] - cam->cam_pos[1], c[2] - cam->cam_pos[2] };
+        float t[3];
+        for (int r = 0; r < 3; r++) t[r] = (V[r] * dd[0] + V[4 + r] * dd[1]) + V[8 + r] * dd[2];
+        float txtz = t[0] / t[2], tytz = t[1] / t[2];
+        float limx = 1.3f * cam->htan_fov[0], limy = 1.3f * cam->htan_fov[1];
+        t[0] = clampf(txtz, -limx, limx) * t[2];
+        t[1] = clampf(tytz, -limy, limy) * t[2];
+        float tz2 = t[2] * t[2];
+        /* J_T columns: (fx/tz, 0, -fx*tx/tz2), (0, fy/tz, -fy*ty/tz2), (0, 0, 0) */
+        float JT[9] = { cam->focal[0] / t[2], 0.0f, (-cam->focal[0] * t[0]) / tz2,
+                        0.0f, cam->focal[1] / t[2], (-cam->focal[1] * t[1]) / tz2,
+                        0.0f, 0.0f, 0.0f };
+        /* T = transpose(view3) * J_T: T[c][r] = sum_k view3T[k][r] * JT[c][k], view3T[k][r] = V[4 r + k] */
+        float Tm[9];
+        for (int cc = 0; cc < 3; cc++)
+            for (int r = 0; r < 3; r++)
+                Tm[3 * cc + r] = (V[4 * r + 0] * JT[3 * cc] + V[4 * r + 1] * JT[3 * cc + 1]) + V[4 * r + 2] * JT[3 * cc + 2];
+        /* cov2d = transpose(T) * Vrk * T: first A = transpose(T) * Vrk, A[c][r] = sum_k Tt[k][r] * K[c][k], Tt[k][r] = Tm[3 r + k] */
+        float Am[9], C2[9];
+        for (int cc = 0; cc < 3; cc++)
+            for (int r = 0; r < 3; r++)
+                Am[3 * cc + r] = (Tm[3 * r + 0] * K[3 * cc] + Tm[3 * r + 1] * K[3 * cc + 1]) + Tm[3 * r + 2] * K[3 * cc + 2];
+        for (int cc = 0; cc < 3; cc++)
+            for (int r = 0; r < 3; r++)
+                C2[3 * cc + r] = (Am[r] * Tm[3 * cc] + Am[3 + r] * Tm[3 * cc + 1]) + Am[6 + r] * Tm[3 * cc + 2];
+        float c00 = C2[0], c01 = C2[1], c11 = C2[4];       /* cov2d[0][0], cov2d[0][1], cov2d[1][1] */
+        float mid = 0.5f * (c00 + c11);
+        float hx = 0.5f * (c00 - c11);
+        float radius = sqrtf(hx * hx + c01 * c01);          /* length(vec2) */
+        float l1 = mid + radius, l2 = mid - radius;
+        if (l2 < 0.0f) return 0;
+        float vx = c01, vy = l1 - c00;
+        float vlen = sqrtf(vx * vx + vy * vy);
+        float ex = vx / vlen, ey = vy / vlen;               /* normalize(): 0/0 -> NaN -> nothing drawn */
+        float smaj = fminf(sqrtf(2.0f * l1), 1024.0f);
+        float smin = fminf(sqrtf(2.0f * l2), 1024.0f);
+        out->major[0] = smaj * ex; out->major[1] = smaj * ey;
+        out->minor[0] = smin * ey; out->minor[1] = smin * -ex;
+        uint32_t cw = rec[7];
+        out->rgba[0] = (float)(cw & 0xFFu) / 255.0f;
+        out->rgba[1] = (float)((cw >> 8) & 0xFFu) / 255.0f;
+        out->rgba[2] = (float)((cw >> 16) & 0xFFu) / 255.0f;
+        out->rgba[3] = (float)((cw >> 24) & 0xFFu) / 255.0f;
+        if (s->draw_mode != 0u) debug_draw_color(s, u, pos, lod_id, t_ratio, out->rgba);
+        if (u->changing == 1u) {
+            if (lod_id != higher_lod) out->rgba[3] = out->rgba[3] * t_ratio;
+            else out->rgba[3] = out->rgba[3] * (1.0f - t_ratio);
+        }
+        float fade = clampf(q[2] / q[3] + 1.0f, 0.0f, 1.0f);
+        for (int k = 0; k < 4; k++) out->rgba[k] = out->rgba[k] * fade;
+        out->ndc[0] = q[0] / q[3];
+        out->ndc[1] = q[1] / q[3];
+        out->depth = q[2] / q[3];
+        if (!(out->depth >= 0.0f && out->depth <= 1.0f)) return 0;
+        out->visible = 1;
+        return 1;
     }
     /* A6 :152-167.  pos2d = (opengl_to_wgpu * projection) * (view * center).
      * Canonical sequence v2 (round 2): dot products are fma chains (first product rounded, then one fma per further
@@ -684,6 +811,13 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
     return 1;
 }
 
+ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_tile *u,
+                        const uint32_t *tex, uint32_t gs_index, uint32_t map_id, uint32_t lod_id,
+                        const float *hmap, int hm_w, int hm_h, orc_splat *out)
+{
+    return project_impl(cam, s, u, tex, gs_index, map_id, lod_id, hmap, hm_w, hm_h, out, g_strict);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Fragment stage (fs_main gswt.wgsl:425-435 + blend renderer.rs:118-129 +     */
 /* depth state :179-185), restated analytically.   */
@@ -770,6 +904,46 @@ static void raster_over(const orc_splat *sp, const orc_frag_setup *fs, int W, in
                     dst[3] = Bv + dst[3] * om;
                 }
             }
+        }
+    }
+}
+
+/* STRICT mode fragment stage (see the mode's header above): per pixel centre the exact affine inverse of the +-2 quad in
+ * double precision, rounded to binary32 = v_position; fs_main as written; "over" blend as above. */
+static void raster_over_strict(const orc_splat *sp, float splat_scale, int W, int H, int y_lo, int y_hi,
+                               const float *bg_depth, float *img)
+{
+    const double s = (double)splat_scale;
+    const double Mx = sp->major[0], My = sp->major[1], Nx = sp->minor[0], Ny = sp->minor[1];
+    const double mm = Mx * Mx + My * My, nn = Nx * Nx + Ny * Ny;
+    if (!(mm > 0.0) || !(nn > 0.0) || !(mm < INFINITY) || !(nn < INFINITY)) return;
+    /* pixel-space centre and the pixel-space images of the quad axes (framebuffer y is down) */
+    const double cx = ((double)sp->ndc[0] * 0.5 + 0.5) * W, cy = (0.5 - (double)sp->ndc[1] * 0.5) * H;
+    const double ux = 0.5 * s * Mx, uy = -0.5 * s * My, vx = 0.5 * s * Nx, vy = -0.5 * s * Ny;
+    const double hx = 2.0 * sqrt(ux * ux + vx * vx) * 1.000001 + 1e-3, hy = 2.0 * sqrt(uy * uy + vy * vy) * 1.000001 + 1e-3;
+    double fx0 = ceil(cx - hx - 0.5), fx1 = floor(cx + hx - 0.5), fy0 = ceil(cy - hy - 0.5), fy1 = floor(cy + hy - 0.5);
+    if (!(fx1 >= fx0) || !(fy1 >= fy0) || !(fx1 >= 0.0) || !(fy1 >= 0.0) || !(fx0 <= W - 1) || !(fy0 <= H - 1)) return;
+    int x0 = fx0 < 0.0 ? 0 : (int)fx0, x1 = fx1 > W - 1 ? W - 1 : (int)fx1;
+    int y0 = fy0 < y_lo ? y_lo : (int)fy0, y1 = fy1 > y_hi - 1 ? y_hi - 1 : (int)fy1;
+    for (int y = y0; y <= y1; y++) {
+        /* ndc of the pixel centre; d = (ndc_px - vCenter.xy) * viewport / splat_scale = p.x major + p.y minor */
+        const double ny = 1.0 - (y + 0.5) / H * 2.0;
+        const double dy = (ny - (double)sp->ndc[1]) * H / s;
+        for (int x = x0; x <= x1; x++) {
+            const double nx = (x + 0.5) / W * 2.0 - 1.0;
+            const double dx = (nx - (double)sp->ndc[0]) * W / s;
+            const float px = (float)((dx * Mx + dy * My) / mm), py = (float)((dx * Nx + dy * Ny) / nn);
+            const float A = -(px * px + py * py);                 /* -dot(v_position, v_position) */
+            if (A < -4.0f || A != A) continue;                     /* discard (a NaN position draws nothing sensible either) */
+            float dbuf = bg_depth ? bg_depth[(size_t)y * W + x] : 1.0f;
+            if (!(sp->depth < dbuf)) continue;
+            float Bv = expf(A) * sp->rgba[3];
+            float om = 1.0f - Bv;
+            float *dst = img + 4 * ((size_t)y * W + x);
+            dst[0] = Bv * sp->rgba[0] + dst[0] * om;
+            dst[1] = Bv * sp->rgba[1] + dst[1] * om;
+            dst[2] = Bv * sp->rgba[2] + dst[2] * om;
+            dst[3] = Bv + dst[3] * om;
         }
     }
 }
@@ -905,7 +1079,8 @@ ORC_API int orc_render(const orc_camera *cam, const orc_scene *scene, const uint
                 int y_lo = band * 16, y_hi = y_lo + 16 > H ? H : y_lo + 16;
                 for (uint64_t i = band_off[band]; i < band_off[band + 1]; i++) {
                     uint64_t k = blist[i];
-                    raster_over(&sp[k], &fs[k], W, H, y_lo, y_hi, bg_depth, out_rgba);
+                    if (g_strict) raster_over_strict(&sp[k], scene->splat_scale, W, H, y_lo, y_hi, bg_depth, out_rgba);
+                    else raster_over(&sp[k], &fs[k], W, H, y_lo, y_hi, bg_depth, out_rgba);
                 }
             }
             free(fill); free(blist);
@@ -914,6 +1089,92 @@ ORC_API int orc_render(const orc_camera *cam, const orc_scene *scene, const uint
     free(band_off);
     if (stats) { stats->n_instanced = n_total; stats->n_visible = n_vis; stats->n_pairs16 = n_pairs; }
     free(order); free(sp); free(fs); free(prefix);
+    return 0;
+}
+
+/* v2 coverage decision of one pixel (F3 / F4 of raster_over, the sequence the HIP compositor evaluates) */
+static inline int cover_v2(const orc_frag_setup *fs, int x, int y)
+{
+    int bx = x & ~15, by = y & ~15;
+    float ox = fs->cxp - (float)bx, oy = fs->cyp - (float)by;
+    float nku = -fmaf(fs->iux, ox, fs->iuy * oy);
+    float nkv = -fmaf(fs->ivx, ox, fs->ivy * oy);
+    float ly = (float)(y - by) + 0.5f, lx = (float)(x - bx) + 0.5f;
+    float px = fmaf(fs->iux, lx, fmaf(fs->iuy, ly, nku));
+    float py = fmaf(fs->ivx, lx, fmaf(fs->ivy, ly, nkv));
+    float r2 = fmaf(py, py, px * px);
+    return r2 <= 4.0f;
+}
+
+/* strict coverage decision of one pixel (raster_over_strict) */
+static inline int cover_strict(const orc_splat *sp, float splat_scale, int W, int H, int x, int y)
+{
+    const double s = (double)splat_scale;
+    const double Mx = sp->major[0], My = sp->major[1], Nx = sp->minor[0], Ny = sp->minor[1];
+    const double mm = Mx * Mx + My * My, nn = Nx * Nx + Ny * Ny;
+    if (!(mm > 0.0) || !(nn > 0.0) || !(mm < INFINITY) || !(nn < INFINITY)) return 0;
+    const double ny = 1.0 - (y + 0.5) / H * 2.0, nx = (x + 0.5) / W * 2.0 - 1.0;
+    const double dy = (ny - (double)sp->ndc[1]) * H / s, dx = (nx - (double)sp->ndc[0]) * W / s;
+    const float px = (float)((dx * Mx + dy * My) / mm), py = (float)((dx * Nx + dy * Ny) / nn);
+    const float A = -(px * px + py * py);
+    return !(A < -4.0f) && A == A;
+}
+
+/* Where do the two evaluation modes DECIDE differently?  For every instance of every draw: vertex stage in both modes; a
+ * splat visible in only one of them marks every pixel it covers there; for a splat visible in both, every pixel (of the
+ * union of the two conservative boxes) whose coverage-and-depth decision differs is marked.  mask: W*H bytes (cleared here).
+ * counts[0] = splats visible in exactly one mode, [1] = (pixel, splat) decisions that differ, [2] = marked pixels,
+ * [3] = splats visible in both modes.  A marked pixel may differ by up to alpha * e^-4 per flipped splat; an unmarked pixel
+ * blends the same splats in both modes and differs only by the continuous part of the arithmetic. */
+ORC_API int orc_compare_modes(const orc_camera *cam, const orc_scene *scene, const uint32_t *tex,
+                              const orc_draw *draws, int n_draws, const float *hmap, int hm_w, int hm_h,
+                              int W, int H, const float *bg_depth, int n_threads, uint8_t *mask, uint64_t counts[4])
+{
+    if (W <= 0 || H <= 0) return -1;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+    memset(mask, 0, (size_t)W * (size_t)H);
+    uint64_t one_mode = 0, flips = 0, both = 0;
+    for (int d = 0; d < n_draws; d++) {
+        const orc_draw *dr = &draws[d];
+        long cnt = (long)dr->count;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : one_mode, flips, both)
+        for (long j = 0; j < cnt; j++) {
+            uint32_t mid = dr->map_id ? dr->map_id[j] : 0u;
+            uint32_t lid = dr->lod_id ? dr->lod_id[j] : 0u;
+            orc_splat a, b;
+            orc_frag_setup fa, fb;
+            project_impl(cam, scene, &dr->tile, tex, dr->gs_index[j], mid, lid, hmap, hm_w, hm_h, &a, 0);
+            project_impl(cam, scene, &dr->tile, tex, dr->gs_index[j], mid, lid, hmap, hm_w, hm_h, &b, 1);
+            fa.ok = fb.ok = 0;
+            if (a.visible) { frag_setup(&a, scene->splat_scale, (float)W, (float)H, &fa); if (!fa.ok) a.visible = 0; }
+            if (b.visible) { frag_setup(&b, scene->splat_scale, (float)W, (float)H, &fb); if (!fb.ok) b.visible = 0; }
+            if (!a.visible && !b.visible) continue;
+            if (a.visible != b.visible) one_mode++; else both++;
+            /* union of the two conservative boxes, one pixel of slack */
+            float x_lo = 3e38f, x_hi = -3e38f, y_lo = 3e38f, y_hi = -3e38f;
+            if (a.visible) { x_lo = fminf(x_lo, fa.cxp - fa.hx); x_hi = fmaxf(x_hi, fa.cxp + fa.hx); y_lo = fminf(y_lo, fa.cyp - fa.hy); y_hi = fmaxf(y_hi, fa.cyp + fa.hy); }
+            if (b.visible) { x_lo = fminf(x_lo, fb.cxp - fb.hx); x_hi = fmaxf(x_hi, fb.cxp + fb.hx); y_lo = fminf(y_lo, fb.cyp - fb.hy); y_hi = fmaxf(y_hi, fb.cyp + fb.hy); }
+            if (!(x_hi >= x_lo) || !(y_hi >= y_lo)) continue;
+            float fx0 = floorf(x_lo) - 1.0f, fx1 = ceilf(x_hi) + 1.0f, fy0 = floorf(y_lo) - 1.0f, fy1 = ceilf(y_hi) + 1.0f;
+            if (fx1 < 0.0f || fy1 < 0.0f || fx0 > (float)(W - 1) || fy0 > (float)(H - 1)) continue;
+            int x0 = fx0 < 0.0f ? 0 : (int)fx0, x1 = fx1 > (float)(W - 1) ? W - 1 : (int)fx1;
+            int y0 = fy0 < 0.0f ? 0 : (int)fy0, y1 = fy1 > (float)(H - 1) ? H - 1 : (int)fy1;
+            for (int y = y0; y <= y1; y++)
+                for (int x = x0; x <= x1; x++) {
+                    float dbuf = bg_depth ? bg_depth[(size_t)y * W + x] : 1.0f;
+                    int ca = a.visible && cover_v2(&fa, x, y) && a.depth < dbuf;
+                    int cb = b.visible && cover_strict(&b, scene->splat_scale, W, H, x, y) && b.depth < dbuf;
+                    if (ca != cb) { flips++; mask[(size_t)y * W + x] = 1; }
+                }
+        }
+    }
+    uint64_t marked = 0;
+    for (size_t i = 0; i < (size_t)W * (size_t)H; i++) marked += mask[i];
+    counts[0] = one_mode; counts[1] = flips; counts[2] = marked; counts[3] = both;
     return 0;
 }
 

@@ -131,7 +131,28 @@ def lib():
         _lib.orc_project_draws.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_set_strict.restype = None
+        _lib.orc_set_strict.argtypes = [C.c_int]
+        _lib.orc_get_strict.restype = C.c_int
+        _lib.orc_compare_modes.restype = C.c_int
+        _lib.orc_compare_modes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     return _lib
+
+
+class strict:
+    """Context manager: the oracle evaluates gswt.wgsl:152-258,402-435 operator by operator (IEEE `/`, no fused
+    multiply-add, exact quad interpolation) instead of the canonical sequence v2 the kernels reproduce (gswt_oracle.c,
+    "STRICT mode").  Process-wide switch."""
+
+    def __enter__(self):
+        self.prev = lib().orc_get_strict()
+        lib().orc_set_strict(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_strict(self.prev)
+        return False
 
 
 def _ptr(a):
@@ -546,6 +567,25 @@ def render(cam: Camera176, scene: Scene160, tex: np.ndarray, draws, width: int, 
     if rc != 0:
         raise RuntimeError(f"orc_render failed: {rc}")
     return out, {"n_instanced": st.n_instanced, "n_visible": st.n_visible, "n_pairs16": st.n_pairs16}
+
+
+def compare_modes(cam: Camera176, scene: Scene160, tex: np.ndarray, draws, width: int, height: int, *, height_map=None,
+                  bg_depth=None, n_threads: int = 0):
+    """Where the canonical sequence v2 and the strict (shader-text) evaluation DECIDE differently (orc_compare_modes):
+    returns (mask [H, W] bool of the pixels holding at least one flipped coverage / cull decision, counts dict)."""
+    tex = np.ascontiguousarray(tex, dtype=np.uint32)
+    arr, keep = _pack_draws(draws)
+    hm = np.ascontiguousarray(height_map, dtype=np.float32) if height_map is not None else None
+    bgd = np.ascontiguousarray(bg_depth, dtype=np.float32) if bg_depth is not None else None
+    mask = np.zeros((height, width), dtype=np.uint8)
+    counts = np.zeros(4, dtype=np.uint64)
+    rc = lib().orc_compare_modes(C.byref(cam), C.byref(scene), _ptr(tex), arr, len(draws), _ptr(hm),
+                                 hm.shape[1] if hm is not None else 0, hm.shape[0] if hm is not None else 0,
+                                 width, height, _ptr(bgd), n_threads, _ptr(mask), _ptr(counts))
+    if rc != 0:
+        raise RuntimeError(f"orc_compare_modes failed: {rc}")
+    return mask.astype(bool), {"visible_in_one_mode": int(counts[0]), "decision_flips": int(counts[1]),
+                               "marked_pixels": int(counts[2]), "visible_in_both": int(counts[3])}
 
 
 def project_draws(cam: Camera176, scene: Scene160, tex: np.ndarray, draws, *, height_map=None) -> np.ndarray:

@@ -82,6 +82,9 @@ def main():
         hm = ou.height_map.reshape(ou.height_map_wh[1], ou.height_map_wh[0]) if ou.surface_type == 1 else None
         img, st = orc.render(cam.uniforms(), su, pp.tex, draws, c["W"], c["H"], height_map=hm)
         var = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
+        with orc.strict():      # the shader text operator by operator (oracle/gswt_oracle.c, "STRICT mode")
+            img_s, st_s = orc.render(cam.uniforms(), su, pp.tex, draws, c["W"], c["H"], height_map=hm)
+            var_s = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
         classes = [2 if d.tile.single_draw else (1 if d.tile.changing else 0) for d in draws]
         np.savez_compressed(
             os.path.join(out_dir, name + ".npz"),
@@ -93,7 +96,8 @@ def main():
             views=np.array([t.view_id for t in osort["tile_instance_vec"]], dtype=np.int32),
             lods=np.array([t.tid[0] for t in osort["tile_instance_vec"]], dtype=np.int32),
             draw_classes=np.array(classes, dtype=np.int32),
-            image=img, varyings=var, stats=np.array([st["n_instanced"], st["n_visible"], st["n_pairs16"]], dtype=np.int64))
+            image=img, varyings=var, image_strict=img_s, varyings_strict=var_s, stats=np.array([st["n_instanced"], st["n_visible"], st["n_pairs16"]], dtype=np.int64))
+        print(name, "strict vs v2 image", float(np.abs(img - img_s).max()))
         print(name, "draws", len(draws), "classes", np.bincount(classes, minlength=3).tolist(), st, "img max", float(img.max()))
 
 

@@ -84,3 +84,44 @@ def test_peer_copy_group_three_ranks_on_one_device(mode):
         for r in rs:
             r.comm_destroy()
             r.close()
+
+
+def test_back_to_back_group_gathers_without_a_sync():
+    """Two gathers of DIFFERENT frames issued back to back (frames in flight, no synchronize between them): the second gather's
+    pushes into a peer's gather buffer must wait for that peer's re-assembly of the first (write-after-read across
+    streams).  Each gathered frame must be its own camera's unsharded render, bit for bit."""
+    import torch
+    pp = H.tileset()
+    n = 3
+    rs = [GSWTRenderer(0) for _ in range(n)]
+    try:
+        for r in rs:
+            _scene(r, pp)
+        W, Hh = 640, 360
+        cams = [orc.default_camera(W, Hh).uniforms(), orc.Camera(W, Hh, (0.5, -1.0, 4.0), (1.0, 3.0, 1.0), [0, 0, 1]).uniforms()]
+        su = orc.scene_uniforms(num_lod=pp.n_lod)
+        wants = [rs[0].render(c, su, W, Hh) for c in cams]
+        assert not np.array_equal(wants[0], wants[1])
+        GSWTRenderer.group_init(rs)
+        shard_shape = (Hh, rs[0].shard_cols_padded(W, n), 4)
+        for rep in range(3):
+            outs = [[torch.zeros(shard_shape, dtype=torch.float32, device="cuda") for _ in range(n)] for _ in cams]
+            frames = [[torch.zeros((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in range(n)] for _ in cams]
+            torch.cuda.synchronize()
+            tickets = []
+            for ci, cam in enumerate(cams):                         # both frames in flight on every rank before any gather
+                tickets.append([r.render_async(cam, su, W, Hh, o.data_ptr(), shard=(k, n, "cols")) for k, (r, o) in enumerate(zip(rs, outs[ci]))])
+            for ci in range(len(cams)):                             # ... and the gathers one behind the other, no host sync
+                GSWTRenderer.group_render_gather(rs, tickets[ci], [f.data_ptr() for f in frames[ci]])
+            for ci in range(len(cams)):
+                for r, t in zip(rs, tickets[ci]):
+                    r.render_wait(t)
+            for r in rs:
+                r.synchronize()
+            for ci in range(len(cams)):
+                for f in frames[ci]:
+                    assert np.array_equal(f.cpu().numpy(), wants[ci])
+    finally:
+        for r in rs:
+            r.comm_destroy()
+            r.close()

@@ -312,12 +312,25 @@ def test_column_band_shards_equal_unsharded(renderer, n):
         img, _, _, _ = _run_case(renderer, cfg, cam, 360, 200, lod0=900, shard=n, shard_cols=True, stats=vis, **kw)
         assert np.array_equal(img, full), (cam, n)
         assert sum(vis) > 0 and min(vis) < st["n_visible"]          # some rank projected fewer splats than the whole frame has
-    # surfaces other than the plane: column bands without the draw cull
-    cfgh = dict(tile_map_half_wh=(3, 4), surface_type=1, lod_max_dist=24.0, tile_sort_type=3, merge_type=2,
-                height_map_wh=(4, 4), height_map_scale=(1.0, 1.0, 0.3))
-    cam = ((0.5, 0.3, 5.0), (1.0, 1.0, 4.5))
-    full, ref, _, _ = _run_case(renderer, cfgh, cam, 320, 240)
-    img, _, _, _ = _run_case(renderer, cfgh, cam, 320, 240, shard=n, shard_cols=True)
+    # the HeightMap surface (the reference's default, structure.rs:75) with the band cull: a cell's splats are bounded through the height
+    # map's extremes and slopes; a steep map and a camera close to the ground make the bound work
+    for hscale, cam in (((1.0, 1.0, 0.3), ((0.5, 0.3, 5.0), (1.0, 1.0, 4.5))), ((0.7, 1.3, 1.5), ((-5.0, -3.0, 2.2), (2.0, 6.0, 0.4))),
+                        ((1.0, 1.0, -0.8), ((4.2, 1.0, 3.0), (5.0, 3.0, 2.5)))):
+        cfgh = dict(tile_map_half_wh=(4, 4), surface_type=1, lod_max_dist=24.0, tile_sort_type=3, merge_type=2,
+                    height_map_type=4, height_map_wh=(6, 6), height_map_scale=hscale)
+        full, ref, _, st = _run_case(renderer, cfgh, cam, 360, 200, lod0=900)
+        assert H.max_abs_diff(full, ref) <= TOL
+        vis = []
+        img, _, _, _ = _run_case(renderer, cfgh, cam, 360, 200, lod0=900, shard=n, shard_cols=True, stats=vis)
+        assert np.array_equal(img, full), (hscale, cam, n)
+        assert sum(vis) > 0
+        if n >= 3:                                                  # the inflated boxes still let some band drop something
+            assert min(vis) < st["n_visible"], (vis, st)
+    # the Sphere surface: column bands without the cull (its parametrisation has seams and poles: no cheap conservative bound)
+    cfgs = dict(tile_map_half_wh=(5, 2), surface_type=2, sphere_radius=6.5, lod_max_dist=60.0, tile_sort_type=3, merge_type=2)
+    cam = ((3.0, -19.0, 6.0), (0.0, 0.0, 0.0))
+    full, ref, _, _ = _run_case(renderer, cfgs, cam, 320, 240, lod0=700)
+    img, _, _, _ = _run_case(renderer, cfgs, cam, 320, 240, lod0=700, shard=n, shard_cols=True)
     assert np.array_equal(img, full)
 
 

@@ -1,0 +1,114 @@
+"""The oracle's STRICT mode (gswt.wgsl:152-258,402-435 operator by operator: IEEE `/`, no fused multiply-add, exact quad
+interpolation; oracle/gswt_oracle.c "STRICT mode") against the canonical sequence v2 that the HIP kernels reproduce bit for bit.
+
+Both are legal binary32 evaluations of the same shader text (WGSL allows fused multiply-add and 2.5-ULP division), so what these
+tests pin is HOW FAR APART two legal evaluations are, at the sizes of BASELINE.json's configurations:
+  * the cull decisions (frustum, lambda2 < 0, z clip) -- identical visible sets;
+  * the |p|^2 <= 4 coverage decisions -- a few hundred pixels per frame hold a flipped one, each worth up to alpha * e^-4 = 0.018;
+  * everywhere else the images differ by the continuous part of the arithmetic: a few 1e-4 at a handful of pixels (thin
+    ellipses: lambda2 = mid - radius cancels), below 1e-4 elsewhere.
+The 1e-4 contract of the product is against v2 (tests/test_baseline_configs_gpu.py); tests/test_strict_gpu.py repeats these
+bounds for the GPU image against the strict image.  Reference: /root/reference/src/gswt.wgsl:152-258,402-435."""
+import numpy as np
+import pytest
+
+import bench
+from oracle import gswt_oracle as orc
+
+E4 = float(np.exp(-4.0))        # a flipped coverage decision is worth at most alpha * e^-4 per splat
+
+
+def both_modes(name):
+    w, wang, cu, vp, sort = bench.build_workload(name)
+    W, H = w["width"], w["height"]
+    su = wang.scene_uniforms()
+    hm = wang.height_map() if int(wang.user.surface_type) == 1 else None
+    tex, draws = bench.oracle_draws(wang, sort, vp)
+    ocu = orc.Camera176.from_buffer_copy(bytes(cu))
+    osu = orc.Scene160.from_buffer_copy(bytes(su))
+    v2, st2 = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
+    with orc.strict():
+        assert orc.lib().orc_get_strict() == 1
+        st_img, sts = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
+        var_s = orc.project_draws(ocu, osu, tex, draws, height_map=hm)
+    assert orc.lib().orc_get_strict() == 0
+    var_2 = orc.project_draws(ocu, osu, tex, draws, height_map=hm)
+    mask, counts = orc.compare_modes(ocu, osu, tex, draws, W, H, height_map=hm)
+    return dict(W=W, H=H, v2=v2, strict=st_img, st2=st2, sts=sts, var2=var_2, vars=var_s, mask=mask, counts=counts)
+
+
+def check_bounds(d, img_a, img_b, *, flip_frac=1e-3, cont_max=1e-3, cont_over_frac=1e-4, extra=0.0):
+    """img_a vs img_b under the flip mask of d: marked pixels <= e^-4 per flipped decision, unmarked ones continuous."""
+    diff = np.abs(img_a.astype(np.float64) - img_b.astype(np.float64)).max(axis=2)
+    mask = d["mask"]
+    n = diff.size
+    assert d["counts"]["marked_pixels"] <= flip_frac * n, d["counts"]
+    out = diff[~mask]
+    assert out.max() <= cont_max + extra, out.max()
+    assert (out > 1e-4 + extra).sum() <= cont_over_frac * n, int((out > 1e-4 + extra).sum())
+    if mask.any():
+        # every flipped decision moves a pixel by at most alpha * e^-4 (alpha <= 1); two flips on one pixel are possible
+        assert diff[mask].max() <= 2 * E4 + cont_max + extra, diff[mask].max()
+    return dict(linf=float(diff.max()), linf_unmarked=float(out.max()), over_1e4_unmarked=int((out > 1e-4).sum()),
+                marked=int(mask.sum()))
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c3h"])
+def test_strict_vs_v2_at_config_size(name):
+    d = both_modes(name)
+    a, b = d["var2"], d["vars"]
+    # cull decisions: the visible sets of the two modes (a splat flipping would show up as a whole missing ellipse)
+    assert d["st2"]["n_visible"] > 10000
+    n_diff = int((a["visible"] != b["visible"]).sum())
+    assert n_diff <= 2 and d["counts"]["visible_in_one_mode"] == n_diff, (n_diff, d["counts"])
+    both = (a["visible"] == 1) & (b["visible"] == 1)
+    # per varying: the centre, the depth and the colour differ in the last bits ...
+    assert np.abs(a["ndc"][both].astype(np.float64) - b["ndc"][both]).max() <= 4e-7
+    assert np.abs(a["depth"][both].astype(np.float64) - b["depth"][both]).max() <= 2e-7
+    assert np.abs(a["rgba"][both].astype(np.float64) - b["rgba"][both]).max() <= 2e-7
+    # ... the axes of a THIN ellipse do not (lambda2 = mid - radius cancels; the direction of a nearly round one is
+    # ill-conditioned but then does not matter): relative to the major axis length they agree to 1e-3
+    la = np.linalg.norm(a["major"][both].astype(np.float64), axis=1)
+    lb = np.linalg.norm(b["major"][both].astype(np.float64), axis=1)
+    assert np.abs(la - lb).max() <= 1e-3 * max(1.0, la.max()) and np.median(np.abs(la - lb) / np.maximum(lb, 1e-30)) <= 1e-6
+    r = check_bounds(d, d["v2"], d["strict"])
+    print(f"{name}: strict vs v2 L-inf {r['linf']:.3e}; {r['marked']} of {d['W'] * d['H']} pixels hold a flipped coverage decision "
+          f"({d['counts']['decision_flips']} decisions); elsewhere L-inf {r['linf_unmarked']:.3e}, {r['over_1e4_unmarked']} pixels above 1e-4")
+
+
+GOLD_DIFF = {"case_plane": 1e-5, "case_hmap": 1.5e-5, "case_sphere": 5e-5, "case_plane_mode1": 1e-5}   # measured 6.1e-6, 8.4e-6, 3.3e-5, 6.1e-6
+
+
+def test_strict_goldens():
+    """The committed goldens carry the strict image and varyings next to the v2 ones (tests/golden/make_golden.py): the
+    strict restatement itself is pinned, and the two images of each small case are within the stated bound."""
+    import glob, json, os
+    from tests import test_golden as tg
+    from oracle import wangtile_oracle as wo
+    for path in tg.GOLD:
+        g, cfg, rows = tg._load(path)
+        rc = cfg.pop("__rc")
+        if "image_strict" not in g.files:
+            pytest.fail(f"{path} has no strict arrays: regenerate with tests/golden/make_golden.py")
+        W, H = [int(x) for x in g["size"]]
+        pos, tgt = g["camera"][0], g["camera"][1]
+        pp = orc.preprocess(rows)
+        ow = wo.WangTile(pp)
+        ou = ow.configure(wo.UserData(**cfg))
+        cam = orc.Camera(W, H, pos, tgt, [0, 0, 1])
+        with np.errstate(all="ignore"):
+            osd = ow.build_tiles(pos)
+            osort = ow.sort_tiles(pos, cam.view_proj())
+            draws = wo.renderer_draws(pp, osort, cam.view_proj())
+        hm = ou.height_map.reshape(ou.height_map_wh[1], ou.height_map_wh[0]) if ou.surface_type == 1 else None
+        su = wo.scene_uniforms_from_data(ou, osd["center_coord"], **rc)
+        with orc.strict():
+            img, st = orc.render(cam.uniforms(), su, pp.tex, draws, W, H, height_map=hm)
+            var = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
+        assert np.max(np.abs(img - g["image_strict"])) <= 1e-6      # expf may differ in the last ulp across libm builds
+        assert var.tobytes() == g["varyings_strict"].tobytes()
+        name = os.path.basename(path)[:-4]
+        mask, counts = orc.compare_modes(cam.uniforms(), su, pp.tex, draws, W, H, height_map=hm)
+        diff = np.abs(g["image"].astype(np.float64) - g["image_strict"]).max(axis=2)
+        assert counts["visible_in_one_mode"] == 0
+        assert diff[~mask].max() <= GOLD_DIFF[name], (name, diff[~mask].max())

@@ -15,6 +15,10 @@ W, H = w["width"], w["height"]
 su = wang.scene_uniforms()
 r = GSWTRenderer(0)
 r.set_option(L.GSWT_OPT_TIMING, 0)
+if os.environ.get("GSWT_SEGMENT"):                 # kernel-variant sweeps: pairs per compositor work item, ablation / variant bits
+    r.set_option(L.GSWT_OPT_SEGMENT, int(os.environ["GSWT_SEGMENT"], 0))
+if os.environ.get("GSWT_DBG_FLAGS"):
+    r.set_option(L.GSWT_OPT_DEBUG_FLAGS, int(os.environ["GSWT_DBG_FLAGS"], 0))
 wang.upload_to(r)
 r.configure(wang.height_map() if int(wang.user.surface_type) == 1 else None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
