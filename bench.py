@@ -670,12 +670,16 @@ def main():
         n_px = rows * band_w
         algo_bytes = 52.0 * P + (36.0 if use_passes else 16.0) * n_px   # (4 + 48) B per pair + 16 B per pixel (+ 20 B read with bg colour + depth)
         achieved = algo_bytes / comp / 1e9 if comp > 0 else 0.0
+        achieved_all = algo_bytes / comp_all / 1e9 if comp_all > 0 else 0.0
+        # what the compositing stage moves by this design: 32-B records + 4-B slot indices per pair and 16 B per output pixel (the tiles
+        # without pairs are written by k_combine, so k_composite's own share is smaller still); SURVEY 8(d)'s 52 B per pair assumed 48-B records
+        moved_bytes = 36.0 * P + 16.0 * n_px + (20.0 * n_px if use_passes else 0.0)
         last = st["last"]
         # HBM bytes per launch of k_composite and its VALU busy share from the committed PMC passes of the static-camera command
         # (rocprofv3 --pmc, separate passes; profiles/): raw counter bytes.  MI355X_MICROARCH's x2 rule is for wide coalesced
         # streams; these reads are scattered record gathers (uncalibrated), so the raw sum is reported and the x2 figure kept beside it.
         traffic, traffic_note, valu = None, "no PMC summary for this workload under profiles/", None
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json"), os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload}.json")) if os.path.exists(q)), None)
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r03_pmc_{args.workload}.json"), os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json"), os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload}.json")) if os.path.exists(q)), None)
         if world == 1 and pmc_path:
             try:
                 pmc = json.load(open(pmc_path))
@@ -690,7 +694,8 @@ def main():
                             "peak_cycles_per_valu_inst_per_simd": 2.0,
                             "lds_bank_conflict_cycle_share": (k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"]) if k.get("SQ_LDS_IDX_ACTIVE") else None,
                             "wave_cycles_waiting_share": (k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None,
-                            "note": "from the committed PMC passes (static camera); peak issue rate = tools/ubench/valu_issue2.hip: 2.0 cycles @2.4 GHz per wave64 "
+                            "source": f"profiles/{os.path.basename(pmc_path)} (committed rocprofv3 --pmc passes of the static-camera command: NOT measured in this run)",
+                            "note": "peak issue rate = tools/ubench/valu_issue2.hip: 2.0 cycles @2.4 GHz per wave64 "
                                     "instruction per SIMD with >= 4 waves issuing, ~7 cycles per instruction for one wave alone whatever its ILP"}
             except Exception as e:      # the summary is evidence, not a dependency
                 traffic_note = f"could not read {pmc_path}: {e}"
@@ -723,8 +728,14 @@ def main():
             "static_camera": static,
             "roofline": {"bound": "hbm", "kernel": "k_composite", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": comp * 1e3, "kernel_ms_samples": len(by_slot.get(best_slot, st["comp_ms"])), "timed_every": max(1, args.timing_every),
+                         "traffic_source": (f"profiles/{os.path.basename(pmc_path)} (committed PMC passes: NOT measured in this run)" if traffic is not None else None),
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "kernel_ms_min_slot": comp * 1e3, "kernel_ms": comp * 1e3, "kernel_ms_samples": len(by_slot.get(best_slot, st["comp_ms"])), "timed_every": max(1, args.timing_every),
                          "kernel_ms_by_slot": {str(k): round(v, 5) for k, v in slot_means.items()}, "kernel_ms_slot": best_slot, "kernel_ms_all_slots": comp_all * 1e3,
+                         "frac_all_slots": achieved_all / HBM_PEAK_GBS,
+                         "frac_note": "`achieved` / `frac` use kernel_ms_min_slot: the hipEvent bracket of the frame slot whose stream has a hardware queue of its own (the other "
+                                      "slots' brackets also time kernels of the frames that share their queue); frac_all_slots uses the mean over every sample",
+                         "bytes_moved_by_design": moved_bytes, "frac_bytes_moved": (moved_bytes / comp / 1e9) / HBM_PEAK_GBS if comp > 0 else None,
                          "kernel_ms_isolated": iso_ms, "frac_isolated": (algo_bytes / (iso_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if iso_ms > 0 else None,
                          "limiter": "instruction issue + latency, not HBM: BASELINE.json asks for the HBM fraction of the compositing kernel, so that is what `frac` is; "
                                     "what the kernel actually runs against is in `valu`",

@@ -677,8 +677,9 @@ try {
     hipSetDevice(c->device);
     HIP_TRY(c, collect_pending(c));
     if (!height_map || hm_w <= 0 || hm_h <= 0) { c->hm_w = c->hm_h = 0; return GSWT_OK; }
-    HIP_TRY(c, c->hmap.ensure((size_t)hm_w * hm_h));
+    HIP_TRY(c, c->hmap.ensure((size_t)hm_w * hm_h + 2));         // + padding: k_project reads a cell's two texels of a row as one 8-byte load
     HIP_TRY(c, hipMemcpy(c->hmap.p, height_map, (size_t)hm_w * hm_h * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->hmap.p + (size_t)hm_w * hm_h, 0, 8));
     {
         float mn = height_map[0], mx = height_map[0], du = 0.f, dv = 0.f;
         bool finite = true;

@@ -46,6 +46,9 @@ __device__ __forceinline__ int wrap_repeat(float fx, int w)
 {
     if (fabsf(fx) < 8388608.0f && w < 8388608) {
         const int x = (int)fx;
+        // a power-of-two map (the reference resizes its random maps to 1024 x 1024, wangtile.rs:405-412): two's-complement AND is the
+        // mathematical modulus; the branch is uniform
+        if ((w & (w - 1)) == 0) return x & (w - 1);
         int r = x - w * (int)floorf((float)x / (float)w);
         if (r < 0) r += w;
         if (r >= w) r -= w;
@@ -55,6 +58,9 @@ __device__ __forceinline__ int wrap_repeat(float fx, int w)
 }
 
 // WebGPU bilinear sample, R32Float, repeat addressing, level 0 (renderer.rs:376-388).
+// The two texels of a row are neighbours unless the cell straddles the map's seam: one 8-byte load per row (the buffer carries one
+// float of padding behind its last row), the seam case re-reads column 0.  Same texels, same arithmetic as four scalar loads:
+// a splat on the HeightMap surface issues 10 height loads instead of 20.
 __device__ __forceinline__ float sample_height(const float* __restrict__ hm, int w, int h, float u, float v)
 {
     float x = u * (float)w - 0.5f;
@@ -62,9 +68,15 @@ __device__ __forceinline__ float sample_height(const float* __restrict__ hm, int
     float fx0 = floorf(x), fy0 = floorf(y);
     float tx = x - fx0, ty = y - fy0;
     const int xa = wrap_repeat(fx0, w), ya = wrap_repeat(fy0, h);
-    const int xb = xa + 1 == w ? 0 : xa + 1, yb = ya + 1 == h ? 0 : ya + 1;
-    float i00 = hm[ya * w + xa], i10 = hm[ya * w + xb];
-    float i01 = hm[yb * w + xa], i11 = hm[yb * w + xb];
+    const int yb = ya + 1 == h ? 0 : ya + 1;
+    const float* r0 = hm + (size_t)ya * w + xa;
+    const float* r1 = hm + (size_t)yb * w + xa;
+    float2 p0, p1;
+    __builtin_memcpy(&p0, r0, 8);
+    __builtin_memcpy(&p1, r1, 8);
+    if (xa + 1 == w) { p0.y = hm[(size_t)ya * w]; p1.y = hm[(size_t)yb * w]; }
+    float i00 = p0.x, i10 = p0.y;
+    float i01 = p1.x, i11 = p1.y;
     float i0 = i00 * (1.0f - tx) + i10 * tx;
     float i1 = i01 * (1.0f - tx) + i11 * tx;
     return i0 * (1.0f - ty) + i1 * ty;
@@ -1655,7 +1667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
 #ifdef GSWT_TRACE
     const bool tr_on = threadIdx.x == 0 && item < kTraceItems;
     const uint32_t tr_item = item;
-    unsigned long long tr_walk = 0, tr_steps = 0;
+    unsigned long long tr_walk = 0;
     bool tr_first = true;
     GSWT_TR(0, GSWT_NOW())
 #endif
@@ -1814,291 +1826,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
 // 50 us walk), but hiding the gathers behind another item's walk inside a workgroup is not what makes them overlap: the
 // dispatcher's dynamic hand-out of ~16 k short workgroups does that better than a static stride over them.
 
-// ------------------------------------------------------------------------------------
-// k_composite_w (round 3): ONE WAVE per work item.  The wave owns the whole 16x16 tile -- a lane holds the pixel
-// (4 grp + (gi & 3), 4 s + (gi >> 2)) of each of the four 16x4 strips s -- and walks the strips one after the other, every
-// strip with the bin + walk of k_composite (four 4x4 sub-block lists, one splat per 16-lane group per step).  Same
-// canonical F3 / F4, same blend order per pixel, same partials layout: the image is bit-identical to k_composite's.
-// Why: in the four-wave workgroup a batch lasts as long as the slowest of its four strips (41 % of the wave-slots idle
-// at the two barriers per batch), and the four waves wait for ONE gather; a CU held 8 such chains.  Here nothing waits
-// for another wave (no s_barrier at all: a single-wave workgroup orders its LDS traffic by program order), a CU holds
-// up to 32 independent gather -> stage -> walk chains, and a chain carries four strips of walk per gather latency.
-// Batch = NB x 64 pairs (lane stages NB records).  The blend takes its colour as f16 (bytes 0..255 are exact) through
-// v_fma_mix_f32: fma(wgt, byte, acc) with the conversion folded in -- the same IEEE result as v_cvt_f32_ubyteN + v_fmac,
-// three VALU instructions per step less.  The staged record is q0 = (iu.x, iu.y, -ku, log2 alpha), q1 = (iv.x, iv.y, -kv,
-// red | green << 16 as halves) and a side word x = (pixel box bytes, blue as a half, depth bits); all three arrays are
-// addressed with the list entry (record index x 16) plus an immediate offset.
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ float half_lo_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu)); }
-__device__ __forceinline__ float half_hi_f32(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16)); }
-
-template <bool EARLY, bool DEPTH, bool COLF, int NB, bool MIX>
-__device__ __forceinline__ void wave_bin_walk(const Frame& f, const int r0, const float lx, const float ly, const uint32_t lane, const uint32_t grp,
-                                              const uint32_t n, const char* const q0b, const char* const q1b, const char* const xb,
-                                              const char* const q2b, uint16_t* const wlist, const uint32_t list_stride, const float dbuf,
-                                              const float t_eps, float& T, float& ar, float& ag, float& ab, bool& live)
-{
-    constexpr uint32_t PB = (uint32_t)NB * 64u;
-    uint16_t* const my_list = wlist + grp * list_stride;
-    uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
-#pragma unroll
-    for (int c = 0; c < NB; c++) {
-        const uint32_t idx = (uint32_t)c * 64u + lane;
-        bool h0 = false, h1 = false, h2 = false, h3 = false;
-        if (idx < n) {
-            const uint32_t bb = *reinterpret_cast<const uint32_t*>(xb + idx * 16u);
-            const int xa = __builtin_amdgcn_sbfe((int)bb, 0, 8), xb2 = __builtin_amdgcn_sbfe((int)bb, 8, 8);
-            const int ya = __builtin_amdgcn_sbfe((int)bb, 16, 8), yb = __builtin_amdgcn_sbfe((int)bb, 24, 8);
-            const bool hy = yb >= r0 && ya <= r0 + 3;
-            h0 = hy && xa <= 3 && xb2 >= 0;
-            h1 = hy && xb2 >= 4 && xa <= 7;
-            h2 = hy && xb2 >= 8 && xa <= 11;
-            h3 = hy && xb2 >= 12 && xa <= 15;
-        }
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-#define GSWT_APPEND(H, M, CNT, G)                                                                                         \
-        if (M) {                                                                                                            \
-            if (H) wlist[(G) * list_stride + (CNT) + __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))] = (uint16_t)(idx * 16u); \
-            CNT += (uint32_t)__popcll(M);                                                                                   \
-        }
-        GSWT_APPEND(h0, m0, cnt0, 0u) GSWT_APPEND(h1, m1, cnt1, 1u) GSWT_APPEND(h2, m2, cnt2, 2u) GSWT_APPEND(h3, m3, cnt3, 3u)
-#undef GSWT_APPEND
-    }
-    const uint32_t n_mine = grp == 0u ? cnt0 : grp == 1u ? cnt1 : grp == 2u ? cnt2 : cnt3;
-    const uint32_t n_max = max(max(cnt0, cnt1), max(cnt2, cnt3));
-    if ((f.dbg_flags & 1) || n_max == 0u) return;
-    const uint32_t n_steps = (n_max + 1u) & ~1u;
-    for (uint32_t p = n_mine + (lane & 15u); p < n_steps + 2u; p += 16u) my_list[p] = (uint16_t)(PB * 16u);      // the null record
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#define GSWT_WREC0(O) (*reinterpret_cast<const float4*>(q0b + (O)))
-#define GSWT_WREC1(O) (*reinterpret_cast<const float4*>(q1b + (O)))
-#define GSWT_WREC2(O) (*reinterpret_cast<const float4*>(q2b + (O)))
-#define GSWT_WRECC(O) (*reinterpret_cast<const uint32_t*>(xb + (O) + 4u))      /* blue as a half */
-#define GSWT_WRECD(O) (*reinterpret_cast<const float*>(xb + (O) + 8u))         /* depth */
-#define GSWT_WSTEP(Q0, Q1, Q2, XC, XD)                                                                \
-    {                                                                                               \
-        const float pu_y = fmaf(Q0.y, ly, Q0.z);                                                    \
-        const float pv_y = fmaf(Q1.y, ly, Q1.z);                                                    \
-        const float ppx = fmaf(Q0.x, lx, pu_y);                                                     \
-        const float ppy = fmaf(Q1.x, lx, pv_y);                                                     \
-        const float r2 = fmaf(ppy, ppy, ppx * ppx);                                                 \
-        bool cover = r2 <= 4.0f;                                                                    \
-        if (DEPTH) cover = cover && XD < dbuf;                                                      \
-        if (__ballot(cover) != 0ull) {                                                              \
-            const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q0.w));           \
-            const float Bv = cover ? e : 0.0f;                                                      \
-            const float wgt = T * Bv;                                                               \
-            const uint32_t cw = __float_as_uint(Q1.w);                                              \
-            ar = fmaf(wgt, COLF ? Q2.x : MIX ? half_lo_f32(cw) : (float)(cw & 0xFFu), ar);          \
-            ag = fmaf(wgt, COLF ? Q2.y : MIX ? half_hi_f32(cw) : (float)((cw >> 8) & 0xFFu), ag);   \
-            ab = fmaf(wgt, COLF ? Q2.z : MIX ? half_lo_f32(XC) : (float)((cw >> 16) & 0xFFu), ab);  \
-            T = T - wgt;                                                                            \
-        }                                                                                           \
-    }
-    {
-        uint32_t kA = my_list[0], kB = my_list[1];
-        asm("" : "+v"(kA)); asm("" : "+v"(kB));
-        float4 a0 = GSWT_WREC0(kA), a1 = GSWT_WREC1(kA);
-        float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), b2 = a2;
-        if (COLF) a2 = GSWT_WREC2(kA);
-        uint32_t ca = 0u, cb = 0u;
-        float da = 0.0f, db = 0.0f;
-        if (!COLF && MIX) ca = GSWT_WRECC(kA);
-        if (DEPTH) da = GSWT_WRECD(kA);
-        for (uint32_t i = 0; i < n_steps; i += 2u) {
-            const float4 b0 = GSWT_WREC0(kB), b1 = GSWT_WREC1(kB);
-            if (COLF) b2 = GSWT_WREC2(kB);
-            if (!COLF && MIX) cb = GSWT_WRECC(kB);
-            if (DEPTH) db = GSWT_WRECD(kB);
-            kA = my_list[i + 2u];
-            asm("" : "+v"(kA));
-            GSWT_WSTEP(a0, a1, a2, ca, da)
-            a0 = GSWT_WREC0(kA); a1 = GSWT_WREC1(kA);
-            if (COLF) a2 = GSWT_WREC2(kA);
-            if (!COLF && MIX) ca = GSWT_WRECC(kA);
-            if (DEPTH) da = GSWT_WRECD(kA);
-            kB = my_list[i + 3u];
-            asm("" : "+v"(kB));
-            GSWT_WSTEP(b0, b1, b2, cb, db)
-        }
-    }
-#undef GSWT_WSTEP
-#undef GSWT_WREC0
-#undef GSWT_WREC1
-#undef GSWT_WREC2
-#undef GSWT_WRECC
-#undef GSWT_WRECD
-    if (EARLY && __ballot(T >= t_eps) == 0ull) live = false;
-}
-
-template <bool EARLY, bool DEPTH, bool COLF, int NB, bool MIX>
-__global__ __launch_bounds__(64) void k_composite_w(const Frame f, const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
-                                                     const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
-                                                     const float* __restrict__ depths, const float4* __restrict__ col_f,
-                                                     const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
-                                                     float4* __restrict__ out, float4* __restrict__ partials, int n_tiles, int out_rows)
-{
-    constexpr uint32_t PB = (uint32_t)NB * 64u;          // pairs per batch
-    constexpr uint32_t kStride = PB + 8u;                // u16 entries per sub-block list (hits + even padding + 2 of prefetch overrun)
-    __shared__ float4 s_q0[PB + 1], s_q1[PB + 1];        // [PB] = the null record
-    __shared__ uint4 s_x[PB + 1];                        // (pixel box bytes, blue as a half, depth bits, -)
-    __shared__ float4 s_q2[COLF ? PB + 1 : 1];
-    __shared__ uint16_t s_list[4][kStride];
-    const uint32_t item = blockIdx.x;
-#ifdef GSWT_TRACE
-    const bool tr_on = threadIdx.x == 0 && item < kTraceItems;
-    const uint32_t tr_item = item;
-    unsigned long long tr_walk = 0;
-    bool tr_first = true;
-    GSWT_TR(0, GSWT_NOW())
+#ifdef GSWT_EXPERIMENTS
+#include "gswt_composite_exp.hip"      // compositor variants of round 3 (measured, not shipped)
 #endif
-    const uint32_t n_items = item_base[n_tiles];
-    const uint4 it = item_tab[item];
-    if (item >= n_items) return;
-    GSWT_TR(1, GSWT_NOW())
-    GSWT_TR(4, it.w - it.z)
-#ifdef GSWT_TRACE
-    { unsigned hwid, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); GSWT_TR(7, (unsigned long long)hwid | ((unsigned long long)xcc << 32)) }
-#endif
-    const int tile = (int)it.x;
-    const bool multi_seg = (it.y & 1u) != 0u;
-    const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
-    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
-    const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
-    const int bx = (tx + f.col0) * kTile, by = ty * kTile;
-    const uint32_t lane = threadIdx.x;
-    const uint32_t grp = lane >> 4, gi = lane & 15u;
-    const int lxi = (int)grp * 4 + (int)(gi & 3u), lyi0 = (int)(gi >> 2);
-    const float lx = (float)lxi + 0.5f, ly0 = (float)lyi0 + 0.5f;
-    const float fbx = (float)bx, fby = (float)by;
-    const uint2 rg = make_uint2(it.z, it.w);
-    float T[4], ar[4], ag[4], ab[4], dbuf[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const int px = bx + lxi, py = by + 4 * s + lyi0;
-        const bool inside = px < f.width && py < f.height;
-        T[s] = (EARLY && !inside) ? 0.0f : 1.0f; ar[s] = ag[s] = ab[s] = 0.0f;
-        dbuf[s] = 1.0f;
-        if (DEPTH && inside) dbuf[s] = bg_depth[(size_t)py * f.width + px];
-    }
-    const float t_eps = f.t_eps;
-    bool live0 = true, live1 = true, live2 = true, live3 = true;
-    if (lane == 0) {
-        s_q0[PB] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);       // r^2 = +inf for every pixel
-        s_q1[PB] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s_x[PB] = make_uint4(0u, 0u, 0u, 0u);
-        if (COLF) s_q2[PB] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float4 ra[NB], rb[NB], rd[NB];
-    float rbw[NB];
-    uint32_t slot_nxt[NB];
-    const uint32_t last_pair = rg.y - 1u;
-#pragma unroll
-    for (int k = 0; k < NB; k++) { ra[k] = rb[k] = rd[k] = make_float4(0.f, 0.f, 0.f, 0.f); rbw[k] = 0.f; slot_nxt[k] = 0u; }
-    if (rg.x < rg.y) {
-        uint32_t s0[NB];
-#pragma unroll
-        for (int k = 0; k < NB; k++) s0[k] = vals[min(rg.x + (uint32_t)k * 64u + lane, last_pair)];
-#pragma unroll
-        for (int k = 0; k < NB; k++) slot_nxt[k] = vals[min(rg.x + PB + (uint32_t)k * 64u + lane, last_pair)];
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const float4* rp = reinterpret_cast<const float4*>(recs + s0[k]);
-            ra[k] = rp[0]; rb[k] = rp[1];
-            if (DEPTH) rbw[k] = depths[s0[k]];
-            if (COLF) rd[k] = col_f[s0[k]];
-        }
-    }
-    const char* const q0b = reinterpret_cast<const char*>(s_q0);
-    const char* const q1b = reinterpret_cast<const char*>(s_q1);
-    const char* const xb = reinterpret_cast<const char*>(s_x);
-    const char* const q2b = reinterpret_cast<const char*>(s_q2);
-    for (uint32_t base = rg.x; base < rg.y; base += PB) {
-        const uint32_t n = min(PB, rg.y - base);
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const uint32_t idx = (uint32_t)k * 64u + lane;
-            if (idx < n) {
-                // F3 and the tile-local pixel-centre box: as in k_composite
-                const float ox = rb[k].x - fbx, oy = rb[k].y - fby;
-                const float nku = -fmaf(ra[k].x, ox, ra[k].y * oy);
-                const float nkv = -fmaf(ra[k].z, ox, ra[k].w * oy);
-                const uint32_t cw = __float_as_uint(rb[k].w);
-                const uint32_t rgh = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)(float)(cw & 0xFFu)) |
-                                     ((uint32_t)__builtin_bit_cast(unsigned short, (_Float16)(float)((cw >> 8) & 0xFFu)) << 16);
-                const uint32_t bh = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)(float)((cw >> 16) & 0xFFu));
-                s_q0[idx] = make_float4(ra[k].x, ra[k].y, nku, __builtin_amdgcn_logf(rb[k].z));
-                s_q1[idx] = make_float4(ra[k].z, ra[k].w, nkv, MIX ? __uint_as_float(rgh) : rb[k].w);
-                const float ria = __builtin_amdgcn_rcpf(fmaf(ra[k].y, ra[k].y, ra[k].x * ra[k].x)), rib = __builtin_amdgcn_rcpf(fmaf(ra[k].w, ra[k].w, ra[k].z * ra[k].z));
-                const float qux = ra[k].x * ria, quy = ra[k].y * ria, qwx = ra[k].z * rib, qwy = ra[k].w * rib;
-                const float bhx = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwx, qwx, qux * qux)), 1.0001f, 0.002f);
-                const float bhy = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwy, qwy, quy * quy)), 1.0001f, 0.002f);
-                const int xa = min(max((int)ceilf((ox - bhx) - 0.5f), -2), 17), xb2 = min(max((int)floorf((ox + bhx) - 0.5f), -2), 17);
-                const int ya = min(max((int)ceilf((oy - bhy) - 0.5f), -2), 17), yb = min(max((int)floorf((oy + bhy) - 0.5f), -2), 17);
-                const uint32_t bb = (uint32_t)(xa & 0xFF) | ((uint32_t)(xb2 & 0xFF) << 8) | ((uint32_t)(ya & 0xFF) << 16) | ((uint32_t)(yb & 0xFF) << 24);
-                s_x[idx] = make_uint4(bb, bh, __float_as_uint(rbw[k]), 0u);
-                if (COLF) s_q2[idx] = rd[k];
-            }
-        }
-        // one wave: LDS operations complete in program order, the fences only keep the compiler from moving them
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef GSWT_TRACE
-        if (tr_first) { GSWT_TR(2, GSWT_NOW()) tr_first = false; }
-        const unsigned long long tr_t0 = GSWT_NOW();
-#endif
-        // the next batch's records and the one-after-next's slot indices are in flight during the walk
-#pragma unroll
-        for (int k = 0; k < NB; k++) {
-            const float4* rp = reinterpret_cast<const float4*>(recs + slot_nxt[k]);
-            ra[k] = rp[0]; rb[k] = rp[1];
-            if (DEPTH) rbw[k] = depths[slot_nxt[k]];
-            if (COLF) rd[k] = col_f[slot_nxt[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < NB; k++) slot_nxt[k] = vals[min(base + 2u * PB + (uint32_t)k * 64u + lane, last_pair)];
-        if (!(f.dbg_flags & 2)) {
-            if (live0) wave_bin_walk<EARLY, DEPTH, COLF, NB, MIX>(f, 0, lx, ly0, lane, grp, n, q0b, q1b, xb, q2b, &s_list[0][0], kStride, dbuf[0], t_eps, T[0], ar[0], ag[0], ab[0], live0);
-            if (live1) wave_bin_walk<EARLY, DEPTH, COLF, NB, MIX>(f, 4, lx, ly0 + 4.0f, lane, grp, n, q0b, q1b, xb, q2b, &s_list[0][0], kStride, dbuf[1], t_eps, T[1], ar[1], ag[1], ab[1], live1);
-            if (live2) wave_bin_walk<EARLY, DEPTH, COLF, NB, MIX>(f, 8, lx, ly0 + 8.0f, lane, grp, n, q0b, q1b, xb, q2b, &s_list[0][0], kStride, dbuf[2], t_eps, T[2], ar[2], ag[2], ab[2], live2);
-            if (live3) wave_bin_walk<EARLY, DEPTH, COLF, NB, MIX>(f, 12, lx, ly0 + 12.0f, lane, grp, n, q0b, q1b, xb, q2b, &s_list[0][0], kStride, dbuf[3], t_eps, T[3], ar[3], ag[3], ab[3], live3);
-        }
-#ifdef GSWT_TRACE
-        tr_walk += GSWT_NOW() - tr_t0;
-#endif
-        if (EARLY && !(live0 || live1 || live2 || live3)) break;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    GSWT_TR(3, GSWT_NOW())
-    GSWT_TR(6, tr_walk)
-    const float k255 = 1.0f / 255.0f;
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        float cr = ar[s], cg = ag[s], cb = ab[s];
-        if (!COLF) { cr *= k255; cg *= k255; cb *= k255; }
-        if (multi_seg) {
-            partials[(size_t)item * 256u + (uint32_t)s * 64u + lane] = make_float4(cr, cg, cb, T[s]);
-            continue;
-        }
-        const int px = bx + lxi, lyi = 4 * s + lyi0, py = by + lyi;
-        if (px < f.width && py < f.height) {
-            float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (bg_rgba) bg = bg_rgba[(size_t)py * f.width + px];
-            float4 o;
-            o.x = fmaf(T[s], bg.x, cr);
-            o.y = fmaf(T[s], bg.y, cg);
-            o.z = fmaf(T[s], bg.z, cb);
-            o.w = fmaf(T[s], bg.w, 1.0f - T[s]);
-            const int orow = tyl * kTile + lyi;
-            if (orow < out_rows) out[(size_t)orow * f.out_w + (px - f.out_x0)] = o;
-        }
-    }
-}
 
 // Folds the per-segment partials of multi-segment tiles: (C1,T1) o (C2,T2) = (C1 + T1*C2, T1*T2).
 // One workgroup per tile, same lane -> pixel mapping as k_composite.
@@ -2351,32 +2081,68 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
-    if (f.dbg_flags & 0x1000) {          // experiment: the one-wave-per-item compositor (0x2000: 64-pair batches instead of 128)
-#define GSWT_LAUNCH_COMPOSITE_W(E, D, C, NB, MIX)                                                                               \
-        GSWT_LAUNCH((k_composite_w<E, D, C, NB, MIX>), dim3(max_items), dim3(64), s, f, item_base, item_tab, vals, recs, depths, col_f, \
+#ifdef GSWT_EXPERIMENTS
+    if (f.dbg_flags & 0x20000) {         // experiment: two packed waves per item with shared staging (0x2000: 256-pair batches instead of 128)
+#define GSWT_LAUNCH_COMPOSITE_P2(E, D, C, NB2, OCC)                                                                             \
+        GSWT_LAUNCH((k_composite_p2<E, D, C, NB2, OCC>), dim3(max_items), dim3(128), s, f, item_base, item_tab, vals, recs, depths, col_f, \
                     bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
-        // 0x2000: 64-pair batches instead of 128; 0x4000: byte colours (v_cvt_f32_ubyteN) instead of halves (v_fma_mix_f32)
-#define GSWT_LAUNCH_COMPOSITE_WN(E, D, C) { GSWT_LAUNCH_COMPOSITE_W(E, D, C, 2, true); }
+        // 0x40000: the register allocator is told to fit 8 waves per SIMD (64 VGPRs) instead of taking what it likes
+#define GSWT_LAUNCH_COMPOSITE_P2N(E, D, C) { if (f.dbg_flags & 0x2000) GSWT_LAUNCH_COMPOSITE_P2(E, D, C, 2, 4); else if ((f.dbg_flags & 0x40000) && !D && !C) GSWT_LAUNCH_COMPOSITE_P2(E, false, false, 1, 8); else GSWT_LAUNCH_COMPOSITE_P2(E, D, C, 1, 4); }
         if (colf) {
-            if (depth) GSWT_LAUNCH_COMPOSITE_WN(false, true, true)
-            else GSWT_LAUNCH_COMPOSITE_WN(false, false, true)
+            if (depth) GSWT_LAUNCH_COMPOSITE_P2N(false, true, true)
+            else GSWT_LAUNCH_COMPOSITE_P2N(false, false, true)
         }
-        else if (early && depth) GSWT_LAUNCH_COMPOSITE_WN(true, true, false)
-        else if (depth) GSWT_LAUNCH_COMPOSITE_WN(false, true, false)
-        else if (early) {
-            const int v = (f.dbg_flags >> 13) & 3;
-            if (v == 0) GSWT_LAUNCH_COMPOSITE_W(true, false, false, 2, true);
-            else if (v == 1) GSWT_LAUNCH_COMPOSITE_W(true, false, false, 1, true);
-            else if (v == 2) GSWT_LAUNCH_COMPOSITE_W(true, false, false, 2, false);
-            else GSWT_LAUNCH_COMPOSITE_W(true, false, false, 1, false);
-        }
-        else GSWT_LAUNCH_COMPOSITE_WN(false, false, false)
-#undef GSWT_LAUNCH_COMPOSITE_WN
-#undef GSWT_LAUNCH_COMPOSITE_W
+        else if (early && depth) GSWT_LAUNCH_COMPOSITE_P2N(true, true, false)
+        else if (early) GSWT_LAUNCH_COMPOSITE_P2N(true, false, false)
+        else if (depth) GSWT_LAUNCH_COMPOSITE_P2N(false, true, false)
+        else GSWT_LAUNCH_COMPOSITE_P2N(false, false, false)
+#undef GSWT_LAUNCH_COMPOSITE_P2N
+#undef GSWT_LAUNCH_COMPOSITE_P2
         if (ev_end) hipEventRecord(ev_end, s);
         GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
         return;
     }
+    if (f.dbg_flags & 0x4000) {          // experiment: independent strip waves (0x8000: two strips per wave, 0x10000: four; 0x2000: 128-pair batches)
+        const uint32_t items8 = (max_items + 7u) & ~7u;
+#define GSWT_LAUNCH_COMPOSITE_S(E, D, C, NB, SPW)                                                                                  \
+        GSWT_LAUNCH((k_composite_s<E, D, C, NB, SPW>), dim3(items8 * (4u / SPW)), dim3(64), s, f, item_base, item_tab, vals, recs, depths, col_f, \
+                    bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
+#define GSWT_LAUNCH_COMPOSITE_SN(E, D, C)                                                                                          \
+        {                                                                                                                          \
+            const int spw = (f.dbg_flags & 0x10000) ? 4 : (f.dbg_flags & 0x8000) ? 2 : 1;                                          \
+            if (f.dbg_flags & 0x2000) { if (spw == 4) GSWT_LAUNCH_COMPOSITE_S(E, D, C, 2, 4); else if (spw == 2) GSWT_LAUNCH_COMPOSITE_S(E, D, C, 2, 2); else GSWT_LAUNCH_COMPOSITE_S(E, D, C, 2, 1); } \
+            else { if (spw == 4) GSWT_LAUNCH_COMPOSITE_S(E, D, C, 1, 4); else if (spw == 2) GSWT_LAUNCH_COMPOSITE_S(E, D, C, 1, 2); else GSWT_LAUNCH_COMPOSITE_S(E, D, C, 1, 1); } \
+        }
+        if (early && !depth && !colf) GSWT_LAUNCH_COMPOSITE_SN(true, false, false)
+        else if (!early && !depth && !colf) GSWT_LAUNCH_COMPOSITE_SN(false, false, false)
+        else if (depth && !colf) { if (early) GSWT_LAUNCH_COMPOSITE_S(true, true, false, 1, 1); else GSWT_LAUNCH_COMPOSITE_S(false, true, false, 1, 1); }
+        else { if (depth) GSWT_LAUNCH_COMPOSITE_S(false, true, true, 1, 1); else GSWT_LAUNCH_COMPOSITE_S(false, false, true, 1, 1); }
+#undef GSWT_LAUNCH_COMPOSITE_SN
+#undef GSWT_LAUNCH_COMPOSITE_S
+        if (ev_end) hipEventRecord(ev_end, s);
+        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+        return;
+    }
+    if (f.dbg_flags & 0x1000) {          // experiment: the one-wave-per-item packed compositor (0x2000: 64-pair batches instead of 128)
+#define GSWT_LAUNCH_COMPOSITE_P(E, D, C, NB)                                                                                    \
+        GSWT_LAUNCH((k_composite_p<E, D, C, NB>), dim3(max_items), dim3(64), s, f, item_base, item_tab, vals, recs, depths, col_f, \
+                    bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
+#define GSWT_LAUNCH_COMPOSITE_PN(E, D, C) { if (f.dbg_flags & 0x2000) GSWT_LAUNCH_COMPOSITE_P(E, D, C, 1); else GSWT_LAUNCH_COMPOSITE_P(E, D, C, 2); }
+        if (colf) {
+            if (depth) GSWT_LAUNCH_COMPOSITE_PN(false, true, true)
+            else GSWT_LAUNCH_COMPOSITE_PN(false, false, true)
+        }
+        else if (early && depth) GSWT_LAUNCH_COMPOSITE_PN(true, true, false)
+        else if (early) GSWT_LAUNCH_COMPOSITE_PN(true, false, false)
+        else if (depth) GSWT_LAUNCH_COMPOSITE_PN(false, true, false)
+        else GSWT_LAUNCH_COMPOSITE_PN(false, false, false)
+#undef GSWT_LAUNCH_COMPOSITE_PN
+#undef GSWT_LAUNCH_COMPOSITE_P
+        if (ev_end) hipEventRecord(ev_end, s);
+        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+        return;
+    }
+#endif
 #define GSWT_LAUNCH_COMPOSITE(E, D, C)                                                                                         \
     GSWT_LAUNCH((k_composite<E, D, C>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)

@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 for V in "$@"; do
   NAME=${V%%:*}; REST=${V#*:}; SEG=${REST%%:*}; FL=${REST#*:}
   export GSWT_SEGMENT=$SEG GSWT_DBG_FLAGS=$FL
+  mkdir -p $OUT/$NAME
   for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA"; do
     D=$OUT/$NAME/$(echo $C | tr ' ' '_')
