@@ -568,6 +568,7 @@ def main():
             print(f"trace {kind:6s} {idx:4d} start {1e6 * (a - tb):9.1f} us  dur {1e6 * (b - a):8.1f} us  swaps {sw}", file=sys.stderr)
         trace = None
     mg_built, mg_reused = r.merge_stats()
+    mg_deep = r.merge_stats_deep()
     swaps, swap_ms = state["swaps"], list(state["swap_ms"])
     w_build, w_sort = (list(worker.build_ms), list(worker.sort_ms)) if worker is not None else ([], [])
     # A short timed region (the driver's --steps 20) is mostly pipeline fill and drain: the bracket starts on an idle GPU and ends
@@ -717,7 +718,8 @@ def main():
             "frames_in_flight": slots,
             "segment": segment,
             "sort_events": {"swapped_in": swaps, "swap_in_ms_mean": float(np.mean(swap_ms)) if swap_ms else None,
-                            "merged_groups_sorted": mg_built, "merged_groups_copied_from_previous_event": mg_reused,
+                            "merged_groups_sorted": mg_built, "merged_groups_copied": mg_reused, "merged_groups_copied_from_older_than_previous_event": mg_deep,
+                            "merged_groups_sorted_share": (mg_built / float(mg_built + mg_reused)) if (mg_built + mg_reused) else None,
                             "takes_effect": "first frame submitted after the event's device-side list build has finished (GSWT_OPT_DEFER_SWAP = 1)" if defer_swap else ("third frame submitted after the swap-in, on every rank (GSWT_OPT_DEFER_SWAP = 3)" if (world > 1 and args.mode == "flypath" and not args.no_defer_swap) else "next frame (which waits for the build on the device)"),
                             "note": "SortData swap-ins inside the timed region (gswt_set_draws_merge_groups: draw-list upload into the spare draw set + merged lists built on the device, on a stream of their own)"},
             "worker_ms": worker_ms,

@@ -196,6 +196,7 @@ SYMBOLS = {
     "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gswt_debug_read_ranges": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gswt_debug_merge_stats": (C.c_int, [_P, _P]),
+    "gswt_debug_merge_stats_deep": (C.c_int, [_P, _P]),
     "gswt_debug_totals": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "gswt_debug_sort": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
     "gswt_debug_graph_stats": (C.c_int, [_P, _P]),

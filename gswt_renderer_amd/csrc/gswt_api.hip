@@ -30,7 +30,7 @@
 namespace gswt {
 void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t,
                  uint32_t*, uint4*);
-void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*);
+void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const MergeSources&, uint32_t*, uint32_t*);
 void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
 size_t radix_ws_zero_words(uint32_t, int);
@@ -140,7 +140,10 @@ constexpr const char* kStreamLayout = "c012p34s";
 // The per-sort-event state (GSWTRenderer's swap-in of a SortData, state.rs:361-376): draw descriptors, chunk tables, merged
 // lists, band-cull bounds.  Double-buffered: gswt_set_draws* fills the set that is NOT current while the frames in flight
 // keep reading the one they were submitted with, so a sort event does not drain the frame pipeline.
-constexpr int kDrawSets = kFrameSlots + 1;     // frames in flight + 1: the set being refilled is never one a frame in flight still reads
+// frames in flight + 1 (the set being refilled is never one a frame in flight still reads) + 4 more, so that with the sets refilled
+// round robin the merged lists of the last kDrawSets - 1 = 9 sort events stay addressable for gswt_set_draws_merge_groups
+constexpr int kDrawSets = kFrameSlots + 5;
+static_assert(kDrawSets <= kMergeSources, "MergeSources holds one pointer pair per draw set");
 template <typename T>
 struct Ref { T* p = nullptr; };
 
@@ -308,7 +311,7 @@ struct gswt_ctx {
     std::vector<uint32_t> raw_cnt, raw_merge_offset;   // [lod*n_tile + tile]
 
     int opt_no_merge_reuse = 0;            // GSWT_OPT_NO_MERGE_REUSE: every merged group is re-sorted at every sort event
-    unsigned long long stat_groups_built = 0, stat_groups_reused = 0;
+    unsigned long long stat_groups_built = 0, stat_groups_reused = 0, stat_groups_reused_deep = 0;
     DevBuf<uint32_t> mg_ws;
     bool draws_ready = false;
     // frame (the per-frame buffers live in the slots)
@@ -863,11 +866,16 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
         bool used = k == c->cur_set || k == c->pending_set || k == c->latest_set || o.ev_up_pending;
         for (const FrameSlot& fs : c->slots) used = used || (fs.pending && fs.set == k);
         if (used && !empty) continue;
+        if (o.g_valid) continue;      // it holds the group lists of an earlier sort event that later events may still copy from
         if (o.h_blob.cap >= D.h_blob.cap && o.d_blob.cap >= D.d_blob.cap && o.chunk_tab.cap >= D.chunk_tab.cap &&
             o.chunk_tab_xcd.cap >= D.chunk_tab_xcd.cap && o.merged_list.cap >= D.merged_list.cap && o.merged_map.cap >= D.merged_map.cap) continue;
         HIP_TRY(c, o.h_blob.ensure(D.h_blob.cap)); HIP_TRY(c, o.d_blob.ensure(D.d_blob.cap));
         HIP_TRY(c, o.chunk_tab.ensure(D.chunk_tab.cap)); HIP_TRY(c, o.chunk_tab_xcd.ensure(D.chunk_tab_xcd.cap));
-        HIP_TRY(c, o.merged_list.ensure(D.merged_list.cap)); HIP_TRY(c, o.merged_map.ensure(D.merged_map.cap));
+        {
+            const uint32_t* const l0 = o.merged_list.p; const uint32_t* const m0 = o.merged_map.p;
+            HIP_TRY(c, o.merged_list.ensure(D.merged_list.cap)); HIP_TRY(c, o.merged_map.ensure(D.merged_map.cap));
+            if (o.merged_list.p != l0 || o.merged_map.p != m0) o.g_valid = false;      // its lists are gone: no later event may copy from them
+        }
     }
     if (!device_merge) { publish_set(c, target); c->draws_ready = true; }      // (gswt_set_draws_merge_groups publishes behind its builds)
     return GSWT_OK;
@@ -920,7 +928,13 @@ try {
     c->merge_target = target;
     collect_set(c, target);
     DrawSet& D = c->sets[target];
-    const DrawSet* prev = (c->draws_ready && target != c->latest_set && c->sets[c->latest_set].g_valid && !c->opt_no_merge_reuse) ? &c->sets[c->latest_set] : nullptr;
+    // every other set that still holds the group lists of an earlier sort event, newest first (the sets are refilled round robin)
+    std::vector<int> sources;
+    if (c->draws_ready && !c->opt_no_merge_reuse)
+        for (int j = 0; j < kDrawSets - 1; j++) {
+            const int k = ((c->latest_set - j) % kDrawSets + kDrawSets) % kDrawSets;
+            if (k != target && c->sets[k].g_valid && c->sets[k].merged_list.p) sources.push_back(k);
+        }
     if (D.ev_up_pending) { HIP_TRY(c, hipEventSynchronize(D.ev_up)); D.ev_up_pending = false; }
     {   // upper bound of the merged entries (sizes the block tables of the upload block)
         size_t total_upper = 0;
@@ -935,8 +949,9 @@ try {
     MergeGroup* const grp = D.hp<MergeGroup>(D.off_groups);       // build space: only the groups that are sorted
     MergeCopy* const jobs = D.hp<MergeCopy>(D.off_jobs);
     uint2* const h_remap = D.hp<uint2>(D.off_remap);
-    std::unordered_multimap<uint64_t, uint32_t> prev_by_hash;
-    if (prev) for (uint32_t q = 0; q < prev->g_desc.size(); q++) prev_by_hash.emplace(prev->g_desc[q].hash, q);
+    // hash -> (set, group) of every retained event; a set listed earlier (newer) wins on equal keys
+    std::unordered_multimap<uint64_t, std::pair<int, uint32_t>> prev_by_hash;
+    for (int k : sources) for (uint32_t q = 0; q < c->sets[k].g_desc.size(); q++) prev_by_hash.emplace(c->sets[k].g_desc[q].hash, std::make_pair(k, q));
     std::vector<DrawSet::GroupDesc> desc((size_t)n_groups);
     size_t n_segs = 0, n_build = 0, n_jobs = 0, n_remap = 0;
     uint64_t total = 0, build_total = 0;
@@ -958,33 +973,40 @@ try {
         }
         DrawSet::GroupDesc& d = desc[g];
         d.view = G.view_id; d.base = (uint32_t)total; d.len = (uint32_t)len; d.first = G.first_member; d.n = G.n_members; d.hash = h;
-        int match = -1;
-        if (prev && len) {
+        int match = -1, match_set = -1, match_rank = 1 << 30;
+        if (!sources.empty() && len) {
             auto range = prev_by_hash.equal_range(h);
-            for (auto it = range.first; it != range.second && match < 0; ++it) {
-                const DrawSet::GroupDesc& p = prev->g_desc[it->second];
-                if (p.view != G.view_id || p.n != G.n_members || p.len != (uint32_t)len) continue;
+            for (auto it = range.first; it != range.second; ++it) {
+                const DrawSet& ps = c->sets[it->second.first];
+                const DrawSet::GroupDesc& p = ps.g_desc[it->second.second];
+                if (p.view != G.view_id || p.n != G.n_members || p.len != (uint32_t)len || G.n_members > 256u) continue;
                 bool same = true;
                 for (uint32_t m = 0; m < G.n_members && same; m++) {
                     const gswt_merge_member& a = members[G.first_member + m];
-                    const gswt_merge_member& b = prev->g_members[p.first + m];
+                    const gswt_merge_member& b = ps.g_members[p.first + m];
                     same = a.lod == b.lod && a.tile == b.tile && a.other_lod == b.other_lod;
                 }
-                if (same && G.n_members <= 256u) match = (int)it->second;
+                if (!same) continue;
+                // the newest holder (fewest map ids to rewrite, and its buffers are the warmest)
+                int rank = 0;
+                while (rank < (int)sources.size() && sources[rank] != it->second.first) rank++;
+                if (rank < match_rank) { match_rank = rank; match = (int)it->second.second; match_set = it->second.first; }
             }
         }
         if (match >= 0) {
-            const DrawSet::GroupDesc& p = prev->g_desc[match];
+            const DrawSet& ps = c->sets[match_set];
+            const DrawSet::GroupDesc& p = ps.g_desc[match];
             MergeCopy jb;
-            jb.src = p.base; jb.dst = (uint32_t)total; jb.len = (uint32_t)len; jb.first_pair = (uint32_t)n_remap; jb.n_pairs = 0; jb._pad[0] = jb._pad[1] = jb._pad[2] = 0;
+            jb.src = p.base; jb.dst = (uint32_t)total; jb.len = (uint32_t)len; jb.first_pair = (uint32_t)n_remap; jb.n_pairs = 0; jb.src_set = (uint32_t)match_set; jb._pad[0] = jb._pad[1] = 0;
             bool moved = false;
-            for (uint32_t m = 0; m < G.n_members; m++) moved = moved || members[G.first_member + m].map_index != prev->g_members[p.first + m].map_index;
+            for (uint32_t m = 0; m < G.n_members; m++) moved = moved || members[G.first_member + m].map_index != ps.g_members[p.first + m].map_index;
             if (moved) {
                 for (uint32_t m = 0; m < G.n_members; m++)
-                    h_remap[n_remap++] = make_uint2(prev->g_members[p.first + m].map_index, members[G.first_member + m].map_index);
+                    h_remap[n_remap++] = make_uint2(ps.g_members[p.first + m].map_index, members[G.first_member + m].map_index);
                 jb.n_pairs = G.n_members;
             }
             jobs[n_jobs++] = jb;
+            if (match_rank > 0) c->stat_groups_reused_deep++;
         } else if (len) {
             MergeGroup& B = grp[n_build];
             B.base = (uint32_t)build_total; B.len = (uint32_t)len; B.mn = 0; B.mx = 0; B.out_base = (uint32_t)total; B._pad[0] = B._pad[1] = B._pad[2] = 0;
@@ -1013,10 +1035,16 @@ try {
                 return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws_merge_groups: draw %d does not match group %u (offset %u/%u count %u/%u)", i, g,
                             draws[i].merged_offset, (int)g < n_groups ? desc[g].base : 0u, draws[i].merged_count, (int)g < n_groups ? desc[g].len : 0u);
         }
-    const uint32_t* const prev_list = prev ? prev->merged_list.p : nullptr;      // (set_draws_impl below may grow the target's arrays, not these)
-    const uint32_t* const prev_map = prev ? prev->merged_map.p : nullptr;
     int rc = set_draws_impl(c, draws, n_draws, nullptr, nullptr, nullptr, (size_t)total, true);       // fills the same target set
     if (rc != GSWT_OK) return rc;
+    // (set_draws_impl grows the target's arrays and those of sets nothing reads; a source whose arrays it re-allocated lost g_valid:
+    // that cannot be one of `sources` -- they are kept from growing below -- but it is checked all the same)
+    MergeSources msrc;
+    for (int k = 0; k < kMergeSources; k++) { msrc.list[k] = nullptr; msrc.map[k] = nullptr; }
+    for (int k : sources) {
+        if (!c->sets[k].g_valid) return fail(c, GSWT_ERR_STATE, "gswt_set_draws_merge_groups: a source set lost its lists");
+        msrc.list[k] = c->sets[k].merged_list.p; msrc.map[k] = c->sets[k].merged_map.p;
+    }
     D.g_desc.swap(desc);
     D.g_members.assign(members, members + n_members);
     D.g_valid = true;
@@ -1039,7 +1067,7 @@ try {
     HIP_TRY(c, hipMemcpyAsync(D.d_blob.p, D.h_blob.p, D.blob_bytes, hipMemcpyHostToDevice, s));
     launch_chunk_tabs(s, D.draws.p, D.xcd_first.p, D.n_draws, D.chunk_tab.p, D.chunk_tab_xcd.p, D.per_xcd, D.longest);
     if (n_jobs)
-        launch_merge_copy(s, D.dp<MergeCopy>(D.off_jobs), D.dp<uint2>(D.off_cblocks), (uint32_t)n_cb, D.dp<uint2>(D.off_remap), prev_list, prev_map,
+        launch_merge_copy(s, D.dp<MergeCopy>(D.off_jobs), D.dp<uint2>(D.off_cblocks), (uint32_t)n_cb, D.dp<uint2>(D.off_remap), msrc,
                           D.merged_list.p, D.merged_map.p);
     if (n_build) {
         int gbits = 1;
@@ -1848,6 +1876,13 @@ int gswt_debug_merge_stats(const gswt_ctx* c, unsigned long long out[2])
 {
     if (!c || !out) return GSWT_ERR_BAD_ARG;
     out[0] = c->stat_groups_built; out[1] = c->stat_groups_reused;
+    return GSWT_OK;
+}
+
+int gswt_debug_merge_stats_deep(const gswt_ctx* c, unsigned long long* out)
+{
+    if (!c || !out) return GSWT_ERR_BAD_ARG;
+    *out = c->stat_groups_reused_deep;
     return GSWT_OK;
 }
 

@@ -26,9 +26,6 @@
 // and four strips walked in turn (k_composite_w: 111-114 us against 96 for k_composite -- the same walk, four times the
 // serial chain per item), with v_fma_mix_f32 colours from halves (three VALU less, one ds_read_b32 more per step: +-0).
 // ------------------------------------------------------------------------------------
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f pk_splat(float s) { v2f r; r.x = s; r.y = s; return r; }
 
 // bin + walk of one staged batch for one 16x8 half tile (rows r0 .. r0 + 7).
 template <bool EARLY, bool DEPTH, bool COLF, int NB>

@@ -96,9 +96,17 @@ struct MergeGroup {
 // A group whose (view, ordered member tids) equal a group of the previous sort event: its list is copied from the previous
 // draw set, map ids rewritten member by member (the reference's LRU hit, wangtile.rs:575-593).
 struct MergeCopy {
-    uint32_t src, dst, len;   // ranges in the previous / new merged arrays
+    uint32_t src, dst, len;   // ranges in the source / new merged arrays
     uint32_t first_pair, n_pairs;   // (old map index, new map index) pairs of its members in the remap table; n_pairs = 0: map ids unchanged
-    uint32_t _pad[3];
+    uint32_t src_set;         // which retained draw set holds the source list (MergeSources)
+    uint32_t _pad[2];
+};
+// The merged arrays of the retained draw sets a copy job may read from: the lists of the last kMergeSources - 1 sort events stay
+// addressable, keyed by (view, ordered member tile ids, transition states) -- the reference's LRU of merged lists (wangtile.rs:427,575-593).
+constexpr int kMergeSources = 12;
+struct MergeSources {
+    const uint32_t* list[kMergeSources];
+    const uint32_t* map[kMergeSources];
 };
 
 // vs_main varyings for the debug/parity hook (48 B, same layout as the oracle's orc_splat)

@@ -1349,14 +1349,15 @@ __global__ __launch_bounds__(256) void k_mg_final(const MergeSeg* __restrict__ s
     merged_map[out] = sg.map_index;
 }
 
-// Groups unchanged since the previous sort event: one workgroup per 1024 entries of a copy job (block table as above).
+// Groups whose list one of the retained sort events already holds: one workgroup per 1024 entries of a copy job (block table as above).
 __global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ jobs, const uint2* __restrict__ blocks, const uint2* __restrict__ remap,
-                                                 const uint32_t* __restrict__ old_list, const uint32_t* __restrict__ old_map,
-                                                 uint32_t* __restrict__ new_list, uint32_t* __restrict__ new_map)
+                                                 const MergeSources src, uint32_t* __restrict__ new_list, uint32_t* __restrict__ new_map)
 {
     __shared__ uint2 s_pairs[256];
     const uint2 b = blocks[blockIdx.x];
     const MergeCopy jb = jobs[b.x];
+    const uint32_t* __restrict__ old_list = src.list[jb.src_set < (uint32_t)kMergeSources ? jb.src_set : 0u];
+    const uint32_t* __restrict__ old_map = src.map[jb.src_set < (uint32_t)kMergeSources ? jb.src_set : 0u];
     const uint32_t np = min(jb.n_pairs, 256u);
     if (threadIdx.x < np) s_pairs[threadIdx.x] = remap[jb.first_pair + threadIdx.x];
     __syncthreads();
@@ -1506,6 +1507,10 @@ struct CompLane {
     uint32_t lane, grp;
 };
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_splat(float s) { v2f r; r.x = s; r.y = s; return r; }
+
 constexpr uint32_t kListStride = 264u;     // u16 entries per sub-block list: 256 hits + padding to an even count + 2 of prefetch overrun
 constexpr uint32_t kNullRec = 256u;        // LDS record no pixel is ever inside (list padding)
 
@@ -1515,7 +1520,7 @@ constexpr uint32_t kNullRec = 256u;        // LDS record no pixel is ever inside
 // longest one -- which paces the wave -- is close to their mean: 1.98 M wave-steps against 2.28 M on the c3 frame).
 // List entries are LDS byte offsets of the records (u16), padded to an even length with the offset of a null record
 // whose r^2 is +inf: the walk needs neither a shift nor an `i < n` test nor a mid-pair exit.
-template <bool EARLY, bool DEPTH, bool COLF>
+template <bool EARLY, bool DEPTH, bool COLF, bool PK>
 __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLane& g, uint32_t n, const float4* s_q0, const float4* s_q1,
                                                    const float4* s_q2, const uint32_t* s_bb, const float* s_dep, uint16_t* wlist,
                                                    float dbuf, float t_eps, float& T, float& ar, float& ag, float& ab, bool& wave_live)
@@ -1566,7 +1571,34 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 #define GSWT_REC1(O) (*reinterpret_cast<const float4*>(q1b + (O)))
 #define GSWT_REC2(O) (*reinterpret_cast<const float4*>(q2b + (O)))
 #define GSWT_RECD(O) (*reinterpret_cast<const float*>(dpb + ((O) >> 2)))
+// PK (measurement variant, -DGSWT_EXPERIMENTS only): the staged record is q0 = (iu.x, iv.x, iu.y, iv.y), q1 = (-ku, -kv, log2 alpha, rgba8),
+// so that F4's two coordinates are the two halves of packed operations -- (pu_y, pv_y) = v_pk_fma_f32((iu.y, iv.y), ly, (-ku, -kv)),
+// (p.x, p.y) = v_pk_fma_f32((iu.x, iv.x), lx, (pu_y, pv_y)) -- and the blend pairs (red, green) and (T, blue): (T, ab) += wgt * (-1, cb).
+// IEEE per component: the same image bit for bit, 15 VALU instructions per step instead of 19 -- and 5-7 % SLOWER (c3 104.6 against
+// 98.9 us, c3d 259.8 against 243.8): four v_pk_fma_f32 cost more than the eight scalar instructions they replace.
 #define GSWT_STEP(Q0, Q1, Q2, DV)                                                                   \
+    if (PK) {                                                                                       \
+        v2f iy_, k_, ix_;                                                                           \
+        iy_.x = Q0.z; iy_.y = Q0.w; k_.x = Q1.x; k_.y = Q1.y; ix_.x = Q0.x; ix_.y = Q0.y;           \
+        const v2f pyv = pk_fma(iy_, pk_splat(ly), k_);                                              \
+        const v2f pp = pk_fma(ix_, pk_splat(lx), pyv);                                              \
+        const float r2 = fmaf(pp.y, pp.y, pp.x * pp.x);                                             \
+        bool cover = r2 <= 4.0f;                                                                    \
+        if (DEPTH) cover = cover && DV < dbuf;                                                      \
+        if (__ballot(cover) != 0ull) {                                                              \
+            const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q1.z));           \
+            const float Bv = cover ? e : 0.0f;                                                      \
+            const float wgt = T * Bv;                                                               \
+            const uint32_t cw = __float_as_uint(Q1.w);                                              \
+            v2f c01, acc01, acc23;                                                                  \
+            c01.x = COLF ? Q2.x : (float)(cw & 0xFFu); c01.y = COLF ? Q2.y : (float)((cw >> 8) & 0xFFu); \
+            mtb.y = COLF ? Q2.z : (float)((cw >> 16) & 0xFFu);                                      \
+            acc01.x = ar; acc01.y = ag; acc23.x = T; acc23.y = ab;                                  \
+            acc01 = pk_fma(pk_splat(wgt), c01, acc01);                                              \
+            acc23 = pk_fma(pk_splat(wgt), mtb, acc23);                                              \
+            ar = acc01.x; ag = acc01.y; T = acc23.x; ab = acc23.y;                                  \
+        }                                                                                           \
+    } else                                                                                          \
     {                                                                                               \
         const float pu_y = fmaf(Q0.y, ly, Q0.z);                                                    \
         const float pv_y = fmaf(Q1.y, ly, Q1.z);                                                    \
@@ -1587,6 +1619,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
             T = T - wgt;                                                                            \
         }                                                                                           \
     }
+    v2f mtb; mtb.x = -1.0f; mtb.y = 0.0f;        // (-1, blue): T - wgt = fma(wgt, -1, T) exactly
     {
         // (every list entry goes through an empty asm as soon as it is loaded: carried around the loop as a 16-bit value, the compiler
         // masks each one again before using it as an LDS address -- one VALU instruction per step; a 32-bit register it cannot look
@@ -1647,7 +1680,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 // the gather latency was already covered by the other workgroups of the CU.  "stage-only 58 us" in the ablation is
 // what staging costs with nothing to hide behind, not a serial share of the full kernel.
 
-template <bool EARLY, bool DEPTH, bool COLF>
+template <bool EARLY, bool DEPTH, bool COLF, bool PK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || COLF) ? 7 : 8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
                                                    uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
@@ -1708,10 +1741,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     bool wave_live = true;
     // the null record: p.x = +inf for every pixel (0 * l + inf), so r^2 = +inf and no pixel is ever inside
     if (tid == 0) {
-        s_q0[kNullRec] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
-        s_q1[kNullRec] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (DEPTH) s_dep[kNullRec] = 0.0f;
-        if (COLF) s_q2[kNullRec] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s_q0[kNullRec] = PK ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, __builtin_inff(), 0.f);
+        s_q1[kNullRec] = PK ? make_float4(__builtin_inff(), 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DEPTH) s_dep[DEPTH ? kNullRec : 0u] = 0.0f;
+        if (COLF) s_q2[COLF ? kNullRec : 0u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // Software-pipelined gather: the records of batch b+1 and the slot indices of batch b+2 are in flight
     // while batch b is binned and walked (two dependent HBM latencies per batch otherwise sit between barriers).
@@ -1749,8 +1782,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
             const float ox = rb.x - fbx, oy = rb.y - fby;
             const float nku = -fmaf(ra.x, ox, ra.y * oy);
             const float nkv = -fmaf(ra.z, ox, ra.w * oy);
-            s_q0[tid] = make_float4(ra.x, ra.y, nku, __builtin_amdgcn_logf(rb.z));   // v_log_f32 = log2; log2(0) = -inf -> B = 0
-            s_q1[tid] = make_float4(ra.z, ra.w, nkv, rb.w);
+            const float l2a = __builtin_amdgcn_logf(rb.z);                           // v_log_f32 = log2; log2(0) = -inf -> B = 0
+            s_q0[tid] = PK ? make_float4(ra.x, ra.z, ra.y, ra.w) : make_float4(ra.x, ra.y, nku, l2a);
+            s_q1[tid] = PK ? make_float4(nku, nkv, l2a, rb.w) : make_float4(ra.z, ra.w, nkv, rb.w);
             // Pixel half extents of |p| <= 2 from the inverse map: the quad axes are u = iu / |iu|^2, w = iv / |iv|^2 and the
             // box is 2 sqrt(u.x^2 + w.x^2) by 2 sqrt(u.y^2 + w.y^2).  Approximate reciprocals / roots (1 ulp) under a 1e-4
             // relative + 2e-3 px margin: the box only has to CONTAIN every pixel centre with r^2 <= 4 (it decides which
@@ -1781,7 +1815,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
             slot_nxt = GSWT_VAL(min(base + 512u + tid, last_pair));
         }
         if (wave_live && !(f.dbg_flags & 2))               // ablation bit 2: stage only
-            composite_bin_walk<EARLY, DEPTH, COLF>(f, cl, n, s_q0, s_q1, s_q2, s_bb, s_dep, wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
+            composite_bin_walk<EARLY, DEPTH, COLF, PK>(f, cl, n, s_q0, s_q1, s_q2, s_bb, s_dep, wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
 #ifdef GSWT_TRACE
         tr_walk += GSWT_NOW() - tr_t0;
 #endif
@@ -2057,10 +2091,10 @@ void launch_merge_build(hipStream_t s, const MergeSeg* segs, uint32_t n_segs, co
                        n_total, merged_list, merged_map);
 }
 
-void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks, uint32_t n_blocks, const uint2* remap, const uint32_t* old_list,
-                       const uint32_t* old_map, uint32_t* new_list, uint32_t* new_map)
+void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks, uint32_t n_blocks, const uint2* remap, const MergeSources& src,
+                       uint32_t* new_list, uint32_t* new_map)
 {
-    if (n_blocks) hipLaunchKernelGGL(k_mg_copy, dim3(n_blocks), dim3(256), 0, s, jobs, blocks, remap, old_list, old_map, new_list, new_map);
+    if (n_blocks) hipLaunchKernelGGL(k_mg_copy, dim3(n_blocks), dim3(256), 0, s, jobs, blocks, remap, src, new_list, new_map);
 }
 
 // `ranges` must be zero on entry (k_cull clears it each frame)
@@ -2143,9 +2177,14 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         return;
     }
 #endif
-#define GSWT_LAUNCH_COMPOSITE(E, D, C)                                                                                         \
-    GSWT_LAUNCH((k_composite<E, D, C>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
+#define GSWT_LAUNCH_COMPOSITE_K(E, D, C, PK)                                                                                   \
+    GSWT_LAUNCH((k_composite<E, D, C, PK>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
+#ifdef GSWT_EXPERIMENTS      // 0x80000: the packed-coordinate step (15 VALU instead of 19): measured 5-7 % SLOWER (profiles/r03_composite_variants.txt)
+#define GSWT_LAUNCH_COMPOSITE(E, D, C) do { if (f.dbg_flags & 0x80000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true); else GSWT_LAUNCH_COMPOSITE_K(E, D, C, false); } while (0)
+#else
+#define GSWT_LAUNCH_COMPOSITE(E, D, C) GSWT_LAUNCH_COMPOSITE_K(E, D, C, false)
+#endif
         if (colf) {                       // debug draw modes: float colours from the side buffer
         if (depth) GSWT_LAUNCH_COMPOSITE(false, true, true);
         else GSWT_LAUNCH_COMPOSITE(false, false, true);
@@ -2155,6 +2194,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     else if (depth) GSWT_LAUNCH_COMPOSITE(false, true, false);
     else GSWT_LAUNCH_COMPOSITE(false, false, false);
 #undef GSWT_LAUNCH_COMPOSITE
+#undef GSWT_LAUNCH_COMPOSITE_K
     if (ev_end) hipEventRecord(ev_end, s);
     GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
 }

@@ -141,6 +141,12 @@ class GSWTRenderer:
         self._check(self._lib.gswt_debug_merge_stats(self._h, out))
         return int(out[0]), int(out[1])
 
+    def merge_stats_deep(self):
+        """Of the copied groups, how many came from a sort event older than the previous one (the lists of the last 9 events are kept)."""
+        out = C.c_ulonglong(0)
+        self._check(self._lib.gswt_debug_merge_stats_deep(self._h, C.byref(out)))
+        return int(out.value)
+
     def read_merged(self):
         n = C.c_size_t(0)
         self._check(self._lib.gswt_debug_read_merged(self._h, None, None, 0, C.byref(n)))

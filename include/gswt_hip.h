@@ -484,8 +484,11 @@ GSWT_API int gswt_debug_sort(gswt_ctx *ctx, uint32_t *keys, uint32_t *vals, size
 /* GSWT_OPT_GRAPH bookkeeping since gswt_create: {frames replayed through hipGraphLaunch, graphs (re)built, kernel nodes updated}. */
 GSWT_API int gswt_debug_graph_stats(const gswt_ctx *ctx, unsigned long long out[3]);
 
-/* Merged groups sorted / copied from the previous sort event by gswt_set_draws_merge_groups since gswt_create. */
+/* Merged groups sorted / copied from a retained earlier sort event by gswt_set_draws_merge_groups since gswt_create. */
 GSWT_API int gswt_debug_merge_stats(const gswt_ctx *ctx, unsigned long long out[2]);
+/* ... and how many of the copied ones came from an event OLDER than the previous one (the lists of the last 9 events stay addressable by
+ * (view, ordered member tile ids, transition states): the reference's 1 024-entry LRU of merged lists, wangtile.rs:427,575-593). */
+GSWT_API int gswt_debug_merge_stats_deep(const gswt_ctx *ctx, unsigned long long *out);
 
 /* Test / profiling hook: [start, end) of every screen tile in the sorted pair list of the last
  * gswt_render (2 u32 per tile, shard-local tile order). Host pointer. */

@@ -394,6 +394,47 @@ def test_merged_group_reuse_across_sort_events(renderer):
         assert np.array_equal(img_a, img_b)
 
 
+def test_merged_group_reuse_reaches_back_several_events(renderer):
+    """the lists of the last 9 sort events stay addressable by (view, member tile ids, transition states), so a camera
+    that oscillates between three places re-sorts nothing once each place has been seen -- the reference's 1 024-entry LRU of merged
+    lists (wangtile.rs:427,575-593); with the previous event alone every return trip sorted again.  Lists and images equal the ones
+    built with every group re-sorted."""
+    from gswt_renderer_amd import _lib as L
+    cfg = dict(tile_map_half_wh=(4, 4), surface_type=0, lod_max_dist=22.0, tile_sort_type=3, merge_type=2, merge_topk=40)
+    verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=900)
+    W, Hh = 320, 200
+    # one place, three viewing directions: the tile map (and with it the tile ids of the groups' members) stays, the merged groups and their
+    # presort views change with the direction
+    places = [((4.2, 1.0, 1.5), (5.0, 4.0, 1.0)), ((4.3, 1.1, 1.5), (8.0, 0.5, 1.0)), ((4.1, 0.9, 1.5), (1.0, 3.5, 1.0))]
+    path = [places[k % 3] for k in range(12)]
+    results = {}
+    for reuse in (False, True):
+        renderer.set_option(L.GSWT_OPT_NO_MERGE_REUSE, 0 if reuse else 1)
+        pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer, device_merge=True)
+        built0, reused0 = renderer.merge_stats()
+        deep0 = renderer.merge_stats_deep()
+        out, built_after_first_lap = [], None
+        for k, (pos, tgt) in enumerate(path):
+            cu, vp = host.camera_uniforms(pos, tgt, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
+            pipe.update(pos, vp, force_sort=True)
+            img = pipe.render(cu, W, Hh)
+            lst, mp = renderer.read_merged()
+            out.append((img, lst.copy(), mp.copy()))
+            if k == 2:
+                built_after_first_lap = renderer.merge_stats()[0] - built0
+        built, reused = renderer.merge_stats()
+        results[reuse] = (out, built - built0, reused - reused0, renderer.merge_stats_deep() - deep0, built_after_first_lap)
+    renderer.set_option(L.GSWT_OPT_NO_MERGE_REUSE, 0)
+    out_a, built_a, reused_a, deep_a, _ = results[False]
+    out_b, built_b, reused_b, deep_b, first_lap_b = results[True]
+    assert reused_a == 0 and deep_a == 0
+    assert first_lap_b > 0 and built_b == first_lap_b            # after the first lap nothing is sorted any more
+    assert deep_b > 0 and built_b + reused_b == built_a          # ... the return trips copy from events two and three back
+    for (img_a, l_a, m_a), (img_b, l_b, m_b) in zip(out_a, out_b):
+        assert np.array_equal(l_a, l_b) and np.array_equal(m_a, m_b)
+        assert np.array_equal(img_a, img_b)
+
+
 def test_deferred_swap_in_takes_effect_once_built(renderer):
     """GSWT_OPT_DEFER_SWAP: a sort event is read by the first frame submitted after its device-side build has finished; until then
     frames keep the previous draw list, and the next event makes a still-pending one current.  After gswt_synchronize (which
