@@ -1511,7 +1511,11 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f pk_splat(float s) { v2f r; r.x = s; r.y = s; return r; }
 
+#ifdef GSWT_EXPERIMENTS
+constexpr uint32_t kListStride = 288u;     // (the register-broadcast walk pads a list to whole rounds of 16 + one round of prefetch overrun)
+#else
 constexpr uint32_t kListStride = 264u;     // u16 entries per sub-block list: 256 hits + padding to an even count + 2 of prefetch overrun
+#endif
 constexpr uint32_t kNullRec = 256u;        // LDS record no pixel is ever inside (list padding)
 
 // bin + walk of one staged batch (n pairs in LDS) for one wave; updates the lane's (T, colour) state.
@@ -1520,7 +1524,7 @@ constexpr uint32_t kNullRec = 256u;        // LDS record no pixel is ever inside
 // longest one -- which paces the wave -- is close to their mean: 1.98 M wave-steps against 2.28 M on the c3 frame).
 // List entries are LDS byte offsets of the records (u16), padded to an even length with the offset of a null record
 // whose r^2 is +inf: the walk needs neither a shift nor an `i < n` test nor a mid-pair exit.
-template <bool EARLY, bool DEPTH, bool COLF, bool PK>
+template <bool EARLY, bool DEPTH, bool COLF, bool PK, bool DPPW>
 __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLane& g, uint32_t n, const float4* s_q0, const float4* s_q1,
                                                    const float4* s_q2, const uint32_t* s_bb, const float* s_dep, uint16_t* wlist,
                                                    float dbuf, float t_eps, float& T, float& ar, float& ag, float& ab, bool& wave_live)
@@ -1558,6 +1562,73 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
     const uint32_t n_max = max(max(cnt0, cnt1), max(cnt2, cnt3));
     GSWT_STAT_BATCH(n_max, cnt0, cnt1, cnt2, cnt3)
     if ((f.dbg_flags & 1) || n_max == 0u) return;
+    if (DPPW && !DEPTH && !COLF && !PK) {
+        // ---- register-broadcast walk (measurement variant, -DGSWT_EXPERIMENTS only: 123-128 us against 95 us at c3, 312 against 242 at c3d) ----
+        // In rounds of 16 steps: lane j of a 16-lane group loads the record of its list's entry 16 r + j ONCE (one list read + two
+        // ds_read_b128 per lane and round, the next round's in flight during this one), and step j takes the record's dwords from lane j
+        // through DPP row_newbcast:j, folded into the consuming instructions (v_fmac_f32_dpp, v_cvt_f32_ubyteN_dpp; three v_mov_b32_dpp
+        // for the addends).  No LDS access and no LDS latency inside the steps: with the records fetched per step (a list entry, then two
+        // ds_read_b128 that depend on it) a step lasted as long as that round trip under load, ~200 cycles for ~19 VALU instructions.
+        // Same F4 sequence (v_fmac is the fused multiply-add of the scalar code), same blend order: the image is bit-identical.
+        const uint32_t gi = lane & 15u;
+        const uint32_t n_steps = (n_max + 1u) & ~1u;
+        const uint32_t n_pad = ((n_max + 15u) & ~15u) + 16u;                 // whole rounds + the prefetched one
+        for (uint32_t p = n_mine + gi; p < n_pad; p += 16u) my_list[p] = (uint16_t)(kNullRec * 16u);
+        const char* const q0b = reinterpret_cast<const char*>(s_q0);
+        const char* const q1b = reinterpret_cast<const char*>(s_q1);
+        uint32_t e = my_list[gi];
+        float4 c0 = *reinterpret_cast<const float4*>(q0b + e), c1 = *reinterpret_cast<const float4*>(q1b + e);
+        const float nl2e = -1.4426950408889634f;
+        float t0, t1, t2, t3;
+#define GSWT_DSTEP(J)                                                                                          \
+        asm volatile(                                                                                          \
+            "v_mov_b32_dpp %[t0], %[r2] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"                       \
+            "v_mov_b32_dpp %[t1], %[r6] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"                       \
+            "v_fmac_f32_dpp %[t0], %[r1], %[ly] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"               \
+            "v_fmac_f32_dpp %[t1], %[r5], %[ly] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"               \
+            "v_fmac_f32_dpp %[t0], %[r0], %[lx] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"               \
+            "v_fmac_f32_dpp %[t1], %[r4], %[lx] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"               \
+            "v_mul_f32 %[t2], %[t0], %[t0]\n"                                                                  \
+            "v_fmac_f32 %[t2], %[t1], %[t1]\n"                                                                 \
+            "v_cmp_ge_f32 vcc, 4.0, %[t2]\n"                                                                   \
+            "s_cbranch_vccz 1f\n"                                                                              \
+            "v_mov_b32_dpp %[t3], %[r3] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"                       \
+            "v_fmac_f32 %[t3], %[k], %[t2]\n"                                                                  \
+            "v_exp_f32 %[t3], %[t3]\n"                                                                         \
+            "v_cvt_f32_ubyte0_dpp %[t0], %[r7] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"                \
+            "v_cvt_f32_ubyte1_dpp %[t1], %[r7] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"                \
+            "v_cvt_f32_ubyte2_dpp %[t2], %[r7] row_newbcast:" #J " row_mask:0xf bank_mask:0xf\n"                \
+            "v_cndmask_b32 %[t3], 0, %[t3], vcc\n"                                                             \
+            "v_mul_f32 %[t3], %[T], %[t3]\n"                                                                   \
+            "v_fmac_f32 %[ar], %[t3], %[t0]\n"                                                                 \
+            "v_fmac_f32 %[ag], %[t3], %[t1]\n"                                                                 \
+            "v_fmac_f32 %[ab], %[t3], %[t2]\n"                                                                 \
+            "v_sub_f32 %[T], %[T], %[t3]\n"                                                                    \
+            "1:\n"                                                                                             \
+            : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [T] "+v"(T), [ar] "+v"(ar), [ag] "+v"(ag), [ab] "+v"(ab) \
+            : [r0] "v"(c0.x), [r1] "v"(c0.y), [r2] "v"(c0.z), [r3] "v"(c0.w), [r4] "v"(c1.x), [r5] "v"(c1.y), [r6] "v"(c1.z), [r7] "v"(c1.w), \
+              [lx] "v"(lx), [ly] "v"(ly), [k] "s"(nl2e)                                                        \
+            : "vcc");
+        for (uint32_t base = 0; base < n_steps; base += 16u) {
+            e = my_list[base + 16u + gi];                                   // the next round's entry and record
+            const float4 n0 = *reinterpret_cast<const float4*>(q0b + e), n1 = *reinterpret_cast<const float4*>(q1b + e);
+            const uint32_t left = n_steps - base;                           // even, >= 2
+            do {
+                GSWT_DSTEP(0) GSWT_DSTEP(1) if (left <= 2u) break;
+                GSWT_DSTEP(2) GSWT_DSTEP(3) if (left <= 4u) break;
+                GSWT_DSTEP(4) GSWT_DSTEP(5) if (left <= 6u) break;
+                GSWT_DSTEP(6) GSWT_DSTEP(7) if (left <= 8u) break;
+                GSWT_DSTEP(8) GSWT_DSTEP(9) if (left <= 10u) break;
+                GSWT_DSTEP(10) GSWT_DSTEP(11) if (left <= 12u) break;
+                GSWT_DSTEP(12) GSWT_DSTEP(13) if (left <= 14u) break;
+                GSWT_DSTEP(14) GSWT_DSTEP(15)
+            } while (0);
+            c0 = n0; c1 = n1;
+        }
+#undef GSWT_DSTEP
+        if (EARLY && __ballot(T >= t_eps) == 0ull) wave_live = false;
+        return;
+    }
     // pad this group's list with the null record up to the wave's even step count (+2: the walk reads two entries ahead)
     const uint32_t n_steps = (n_max + 1u) & ~1u;
     for (uint32_t p = n_mine + (lane & 15u); p < n_steps + 2u; p += 16u) my_list[p] = (uint16_t)(kNullRec * 16u);
@@ -1680,7 +1751,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 // the gather latency was already covered by the other workgroups of the CU.  "stage-only 58 us" in the ablation is
 // what staging costs with nothing to hide behind, not a serial share of the full kernel.
 
-template <bool EARLY, bool DEPTH, bool COLF, bool PK>
+template <bool EARLY, bool DEPTH, bool COLF, bool PK, bool DPPW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || COLF) ? 7 : 8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
                                                    uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
@@ -1815,7 +1886,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
             slot_nxt = GSWT_VAL(min(base + 512u + tid, last_pair));
         }
         if (wave_live && !(f.dbg_flags & 2))               // ablation bit 2: stage only
-            composite_bin_walk<EARLY, DEPTH, COLF, PK>(f, cl, n, s_q0, s_q1, s_q2, s_bb, s_dep, wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
+            composite_bin_walk<EARLY, DEPTH, COLF, PK, DPPW>(f, cl, n, s_q0, s_q1, s_q2, s_bb, s_dep, wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
 #ifdef GSWT_TRACE
         tr_walk += GSWT_NOW() - tr_t0;
 #endif
@@ -2177,13 +2248,13 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         return;
     }
 #endif
-#define GSWT_LAUNCH_COMPOSITE_K(E, D, C, PK)                                                                                   \
-    GSWT_LAUNCH((k_composite<E, D, C, PK>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
+#define GSWT_LAUNCH_COMPOSITE_K(E, D, C, PK, DW)                                                                               \
+    GSWT_LAUNCH((k_composite<E, D, C, PK, DW>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
-#ifdef GSWT_EXPERIMENTS      // 0x80000: the packed-coordinate step (15 VALU instead of 19): measured 5-7 % SLOWER (profiles/r03_composite_variants.txt)
-#define GSWT_LAUNCH_COMPOSITE(E, D, C) do { if (f.dbg_flags & 0x80000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true); else GSWT_LAUNCH_COMPOSITE_K(E, D, C, false); } while (0)
+#ifdef GSWT_EXPERIMENTS      // measured and slower (profiles/r03_composite_variants.txt): 0x80000 the packed-coordinate step (15 VALU instead of 19), 0x100000 the register-broadcast (DPP) walk
+#define GSWT_LAUNCH_COMPOSITE(E, D, C) do { if (f.dbg_flags & 0x80000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true, false); else if (f.dbg_flags & 0x100000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, true); else GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, false); } while (0)
 #else
-#define GSWT_LAUNCH_COMPOSITE(E, D, C) GSWT_LAUNCH_COMPOSITE_K(E, D, C, false)
+#define GSWT_LAUNCH_COMPOSITE(E, D, C) GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, false)
 #endif
         if (colf) {                       // debug draw modes: float colours from the side buffer
         if (depth) GSWT_LAUNCH_COMPOSITE(false, true, true);
