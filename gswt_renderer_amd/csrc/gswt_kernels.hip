@@ -928,6 +928,18 @@ __device__ __forceinline__ uint32_t clamped_count(const unsigned long long* n_pt
     return (uint32_t)n;
 }
 
+// -DGSWT_TRACE (tools/composite_trace.py): per work item, 100 MHz wall-clock stamps of the compositor's phases, left by lane 0 of wave 0:
+// [0] entry, [1] item known, [2] first batch staged (gathers have arrived), [3] last walk done, [4] pairs of the item,
+// [5] walk steps of wave 0 / of the wave, [6] ticks wave 0 spent in bin + walk, [7] hardware id (HW_ID | XCC_ID << 32)
+#ifdef GSWT_TRACE
+constexpr uint32_t kTraceItems = 1u << 17;
+__device__ unsigned long long g_trace[kTraceItems * 8];
+#define GSWT_TR(K, V) { if (tr_on) g_trace[(size_t)tr_item * 8u + (K)] = (unsigned long long)(V); }
+#define GSWT_NOW() wall_clock64()
+#else
+#define GSWT_TR(K, V)
+#define GSWT_NOW() 0ull
+#endif
 // A sort workgroup takes 4096 consecutive items whatever its width: THREADS x (4096 / THREADS) per thread, each wave ranking
 // its share 64 at a time.  Sweeps, frames/s with two frames in flight (bench.py, 300 steps): c3 (2.66 M pairs) 256 threads
 // 3733, 512 3925, 1024 3899; c3h 3105 / 3578 / 3589; c5 (21 M pairs) 537.5 / 531.6 / 506.2.  The sort stage alone at c3:
@@ -1047,6 +1059,12 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     constexpr int kSortItems = kSortBlock / kSortThreads, kSortWaves = kSortThreads / 64;
     const uint32_t n = clamped_count(n_ptr, n_cap);
     if (blockIdx.x * kSortBlock >= n) return;
+#ifdef GSWT_TRACE
+    // phase stamps of the scatter pass (tools/sort_trace.py): rows kTraceItems / 2 + (shift ? 4096 : 0) + block
+    const bool tr_on = threadIdx.x == 0 && blockIdx.x < 4096u;
+    const uint32_t tr_item = kTraceItems / 2u + (shift ? 4096u : 0u) + blockIdx.x;
+    GSWT_TR(0, GSWT_NOW())
+#endif
     __shared__ uint32_t s_h[kSortWaves][256];
     __shared__ uint32_t s_g[256];                       // digit -> (global base of this block's run) - (its start inside the block)
     __shared__ uint32_t s_w[4], s_w2[4];
@@ -1101,6 +1119,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         for (uint32_t u = 0; u < kSupDirect; u++) { if (u < nsup) ga += g[u]; if (u < sb) ge += g[u]; }
         s_gs[0][d] = ge; s_gs[1][d] = ga;                                        // read by thread d after the next barrier
     }
+#ifdef GSWT_TRACE
+    { unsigned long long sink = key[0] + val[0] + pre; asm volatile("" :: "v"(sink)); }     // the loads have arrived
+    GSWT_TR(1, GSWT_NOW())
+#endif
     // per-wave digit counts: one LDS add per distinct digit of a 64-item round (see k_radix_hist); the peer masks are kept for
     // the ranking below
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1114,6 +1136,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         if (kCachePeers) pm[k] = peers;
         if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
     }
+    GSWT_TR(2, GSWT_NOW())
     {
         // exclusive scans over the first 256 threads (the other waves only take part in the barriers): of the digit totals
         // (global bases) and of this block's digit counts (positions inside the block)
@@ -1144,6 +1167,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         }
     }
     __syncthreads();
+    GSWT_TR(3, GSWT_NOW())
     // Ranking, 64 items per round: match-any on the digit bits gives every lane its peers; the lowest peer takes the run's
     // position with ONE returning LDS add and hands it to the others through a lane shuffle.  (Round 1 read the counter,
     // fenced the wave, wrote it back and fenced again: two dependent LDS round trips per round that no other round could
@@ -1162,6 +1186,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         if (valid) s_kv[pos + rank] = make_uint2(key[k], val[k]);
     }
     __syncthreads();
+    GSWT_TR(4, GSWT_NOW())
     const uint32_t n_blk = min((uint32_t)kSortBlock, n - blk0);
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
@@ -1183,6 +1208,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
             }
         }
     }
+    GSWT_TR(5, GSWT_NOW())
 }
 
 // ------------------------------------------------------------------------------------
@@ -1472,18 +1498,6 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
     if (threadIdx.x == 0 && base + 1024 * kPer >= n_tiles) item_base[n_tiles] = carry + s_tot;      // the last workgroup
 }
 
-// -DGSWT_TRACE (tools/composite_trace.py): per work item, 100 MHz wall-clock stamps of the compositor's phases, left by lane 0 of wave 0:
-// [0] entry, [1] item known, [2] first batch staged (gathers have arrived), [3] last walk done, [4] pairs of the item,
-// [5] walk steps of wave 0 / of the wave, [6] ticks wave 0 spent in bin + walk, [7] hardware id (HW_ID | XCC_ID << 32)
-#ifdef GSWT_TRACE
-constexpr uint32_t kTraceItems = 1u << 17;
-__device__ unsigned long long g_trace[kTraceItems * 8];
-#define GSWT_TR(K, V) { if (tr_on) g_trace[(size_t)tr_item * 8u + (K)] = (unsigned long long)(V); }
-#define GSWT_NOW() wall_clock64()
-#else
-#define GSWT_TR(K, V)
-#define GSWT_NOW() 0ull
-#endif
 #ifdef GSWT_STATS
 __device__ unsigned long long g_stats[8];
 #define GSWT_STAT_STEP(C) { unsigned long long cm_ = __ballot(C); if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[0], 1ull); \
