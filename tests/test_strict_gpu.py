@@ -19,11 +19,11 @@ from tests.test_strict_oracle import both_modes, check_bounds
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["c3", "c3h"])
+@pytest.mark.parametrize("name", ["c3", "c3h", "c5"])
 def test_gpu_vs_strict_full_error_stack(renderer, name):
     import bench
     import torch
-    d = both_modes(name)
+    d = both_modes(name, varyings=False)
     w, wang, cu, vp, sort = bench.build_workload(name)
     W, H = w["width"], w["height"]
     su = wang.scene_uniforms()
@@ -33,6 +33,8 @@ def test_gpu_vs_strict_full_error_stack(renderer, name):
     out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
     renderer.render_wait(renderer.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
     img = out.cpu().numpy()
+    del out
+    torch.cuda.empty_cache()
     t = renderer.timings()
     assert t["n_visible"] == d["st2"]["n_visible"] == d["sts"]["n_visible"]
     # against v2: the product's contract

@@ -18,7 +18,7 @@ from oracle import gswt_oracle as orc
 E4 = float(np.exp(-4.0))        # a flipped coverage decision is worth at most alpha * e^-4 per splat
 
 
-def both_modes(name):
+def both_modes(name, varyings=True):
     w, wang, cu, vp, sort = bench.build_workload(name)
     W, H = w["width"], w["height"]
     su = wang.scene_uniforms()
@@ -30,9 +30,9 @@ def both_modes(name):
     with orc.strict():
         assert orc.lib().orc_get_strict() == 1
         st_img, sts = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
-        var_s = orc.project_draws(ocu, osu, tex, draws, height_map=hm)
+        var_s = orc.project_draws(ocu, osu, tex, draws, height_map=hm) if varyings else None
     assert orc.lib().orc_get_strict() == 0
-    var_2 = orc.project_draws(ocu, osu, tex, draws, height_map=hm)
+    var_2 = orc.project_draws(ocu, osu, tex, draws, height_map=hm) if varyings else None
     mask, counts = orc.compare_modes(ocu, osu, tex, draws, W, H, height_map=hm)
     return dict(W=W, H=H, v2=v2, strict=st_img, st2=st2, sts=sts, var2=var_2, vars=var_s, mask=mask, counts=counts)
 

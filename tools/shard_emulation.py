@@ -20,7 +20,7 @@ r.set_option(L.GSWT_OPT_TIMING, 0)
 r.set_option(L.GSWT_OPT_GRAPH, int(os.environ.get("GSWT_GRAPH", "0")))      # GSWT_GRAPH=1: one hipGraphLaunch per frame
 print(f"workload {name}, GSWT_OPT_GRAPH = {os.environ.get('GSWT_GRAPH', '0')}", flush=True)
 wang.upload_to(r)
-r.configure(None)
+r.configure(wang.height_map() if int(wang.user.surface_type) == 1 else None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
 configs = [("rows", 1), ("rows", 2), ("rows", 4), ("rows", 8), ("cols", 2), ("cols", 4), ("cols", 8)]
 if name == "c5":
