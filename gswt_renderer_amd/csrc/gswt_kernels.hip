@@ -71,9 +71,10 @@ __device__ __forceinline__ float sample_height(const float* __restrict__ hm, int
     const int yb = ya + 1 == h ? 0 : ya + 1;
     const float* r0 = hm + (size_t)ya * w + xa;
     const float* r1 = hm + (size_t)yb * w + xa;
-    float2 p0, p1;
-    __builtin_memcpy(&p0, r0, 8);
-    __builtin_memcpy(&p1, r1, 8);
+    // (a two-float vector type with 4-byte alignment: global memory takes a dword-aligned 8-byte load as ONE global_load_dwordx2;
+    // a memcpy of 8 bytes at alignment 4 is lowered to two dword loads)
+    typedef float hm_pair __attribute__((ext_vector_type(2), aligned(4)));
+    hm_pair p0 = *reinterpret_cast<const hm_pair*>(r0), p1 = *reinterpret_cast<const hm_pair*>(r1);
     if (xa + 1 == w) { p0.y = hm[(size_t)ya * w]; p1.y = hm[(size_t)yb * w]; }
     float i00 = p0.x, i10 = p0.y;
     float i01 = p1.x, i11 = p1.y;
