@@ -569,8 +569,11 @@ __global__ __launch_bounds__(256) void k_project(
                         R[3 * cc + rr] = fmaf(FK[6 + rr], F[6 + cc], fmaf(FK[3 + rr], F[3 + cc], FK[rr] * F[cc]));
                 for (int k = 0; k < 9; k++) K[k] = R[k];
             }
-            for (int cc = 0; cc < 3; cc++)
-                for (int rr = 0; rr < 3; rr++) K[3 * cc + rr] = (f.scene_scale[rr] * K[3 * cc + rr]) * f.scene_scale[cc];
+            // scene_scale_mat * Vrk * transpose(scene_scale_mat): a product with 1.0 is exact, so the usual unit scale skips 18 multiplications
+            // (uniform branch; same bits)
+            if (f.scene_scale[0] != 1.0f || f.scene_scale[1] != 1.0f || f.scene_scale[2] != 1.0f)
+                for (int cc = 0; cc < 3; cc++)
+                    for (int rr = 0; rr < 3; rr++) K[3 * cc + rr] = (f.scene_scale[rr] * K[3 * cc + rr]) * f.scene_scale[cc];
             // A8 :207-258
             float d0 = c0 - f.cam_pos[0], d1 = c1 - f.cam_pos[1], d2 = c2 - f.cam_pos[2];
             float t[3];
@@ -1663,7 +1666,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 // IEEE per component: the same image bit for bit, 15 VALU instructions per step instead of 19 -- and 5-7 % SLOWER (c3 104.6 against
 // 98.9 us, c3d 259.8 against 243.8): four v_pk_fma_f32 cost more than the eight scalar instructions they replace.
 #define GSWT_STEP(Q0, Q1, Q2, DV)                                                                   \
-    if (PK) {                                                                                       \
+    if (PK && !DPPW) {                                                                              \
         v2f iy_, k_, ix_;                                                                           \
         iy_.x = Q0.z; iy_.y = Q0.w; k_.x = Q1.x; k_.y = Q1.y; ix_.x = Q0.x; ix_.y = Q0.y;           \
         const v2f pyv = pk_fma(iy_, pk_splat(ly), k_);                                              \
@@ -1694,9 +1697,12 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
         bool cover = r2 <= 4.0f;                                                                    \
         if (DEPTH) cover = cover && DV < dbuf;                                                      \
         GSWT_STAT_STEP(cover)                                                                       \
-        if (__ballot(cover) != 0ull) { /* wave-uniform skip; lanes are predicated, not masked */    \
+        /* the blend runs under EXEC masking (s_and_saveexec on the coverage mask, skipped when no lane is covered): round 2 predicated it   \
+           with a v_cndmask behind a wave-uniform ballot test; one VALU instruction less per step, 95.8 -> 93.0 us at c3 (round 3).           \
+           (DPPW && PK: that older form, kept as a measurement variant of the -DGSWT_EXPERIMENTS build) */                                   \
+        if ((DPPW && PK) ? __ballot(cover) != 0ull : cover) {                                       \
             const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q0.w));           \
-            const float Bv = cover ? e : 0.0f;                                                      \
+            const float Bv = (DPPW && PK) ? (cover ? e : 0.0f) : e;                                 \
             const float wgt = T * Bv;                                                               \
             const uint32_t cw = __float_as_uint(Q1.w);                                              \
             ar = fmaf(wgt, COLF ? Q2.x : (float)(cw & 0xFFu), ar);                                  \
@@ -1717,16 +1723,16 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
         if (COLF) a2 = GSWT_REC2(kA);
         float da = DEPTH ? GSWT_RECD(kA) : 0.0f, db = 0.0f;
         for (uint32_t i = 0; i < n_steps; i += 2u) {
-            const float4 b0 = GSWT_REC0(kB), b1 = GSWT_REC1(kB);           // record of step i+1
+            kA = my_list[i + 2u];                                          // entry of step i+2: issued BEFORE the record reads, so that pinning it
+            const float4 b0 = GSWT_REC0(kB), b1 = GSWT_REC1(kB);           // (below) waits for the oldest LDS read only, not for the records behind it
             if (COLF) b2 = GSWT_REC2(kB);
             if (DEPTH) db = GSWT_RECD(kB);
-            kA = my_list[i + 2u];                                          // entry of step i+2
             asm("" : "+v"(kA));
             GSWT_STEP(a0, a1, a2, da)
+            kB = my_list[i + 3u];                                          // entry of step i+3
             a0 = GSWT_REC0(kA); a1 = GSWT_REC1(kA);                        // record of step i+2
             if (COLF) a2 = GSWT_REC2(kA);
             if (DEPTH) da = GSWT_RECD(kA);
-            kB = my_list[i + 3u];                                          // entry of step i+3
             asm("" : "+v"(kB));
             GSWT_STEP(b0, b1, b2, db)
         }
@@ -1827,8 +1833,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     bool wave_live = true;
     // the null record: p.x = +inf for every pixel (0 * l + inf), so r^2 = +inf and no pixel is ever inside
     if (tid == 0) {
-        s_q0[kNullRec] = PK ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, __builtin_inff(), 0.f);
-        s_q1[kNullRec] = PK ? make_float4(__builtin_inff(), 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_q0[kNullRec] = (PK && !DPPW) ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, __builtin_inff(), 0.f);
+        s_q1[kNullRec] = (PK && !DPPW) ? make_float4(__builtin_inff(), 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (DEPTH) s_dep[DEPTH ? kNullRec : 0u] = 0.0f;
         if (COLF) s_q2[COLF ? kNullRec : 0u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -1869,8 +1875,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
             const float nku = -fmaf(ra.x, ox, ra.y * oy);
             const float nkv = -fmaf(ra.z, ox, ra.w * oy);
             const float l2a = __builtin_amdgcn_logf(rb.z);                           // v_log_f32 = log2; log2(0) = -inf -> B = 0
-            s_q0[tid] = PK ? make_float4(ra.x, ra.z, ra.y, ra.w) : make_float4(ra.x, ra.y, nku, l2a);
-            s_q1[tid] = PK ? make_float4(nku, nkv, l2a, rb.w) : make_float4(ra.z, ra.w, nkv, rb.w);
+            s_q0[tid] = (PK && !DPPW) ? make_float4(ra.x, ra.z, ra.y, ra.w) : make_float4(ra.x, ra.y, nku, l2a);
+            s_q1[tid] = (PK && !DPPW) ? make_float4(nku, nkv, l2a, rb.w) : make_float4(ra.z, ra.w, nkv, rb.w);
             // Pixel half extents of |p| <= 2 from the inverse map: the quad axes are u = iu / |iu|^2, w = iv / |iv|^2 and the
             // box is 2 sqrt(u.x^2 + w.x^2) by 2 sqrt(u.y^2 + w.y^2).  Approximate reciprocals / roots (1 ulp) under a 1e-4
             // relative + 2e-3 px margin: the box only has to CONTAIN every pixel centre with r^2 <= 4 (it decides which
@@ -2267,7 +2273,8 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     GSWT_LAUNCH((k_composite<E, D, C, PK, DW>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
 #ifdef GSWT_EXPERIMENTS      // measured and slower (profiles/r03_composite_variants.txt): 0x80000 the packed-coordinate step (15 VALU instead of 19), 0x100000 the register-broadcast (DPP) walk
-#define GSWT_LAUNCH_COMPOSITE(E, D, C) do { if (f.dbg_flags & 0x80000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true, false); else if (f.dbg_flags & 0x100000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, true); else GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, false); } while (0)
+#define GSWT_LAUNCH_COMPOSITE(E, D, C) do { if ((f.dbg_flags & 0x180000) == 0x180000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true, true); /* 0x180000: the scalar step with the blend predicated by v_cndmask behind a ballot test (round 2's form) instead of EXEC masking */ \
+        else if (f.dbg_flags & 0x80000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true, false); else if (f.dbg_flags & 0x100000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, true); else GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, false); } while (0)
 #else
 #define GSWT_LAUNCH_COMPOSITE(E, D, C) GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, false)
 #endif
