@@ -141,7 +141,8 @@ typedef struct {
 
 enum { GSWT_SHARD_ROWS = 0, GSWT_SHARD_COLUMNS = 1 };
 
-/* Per-stage device times of the last gswt_render (hipEvent, ms) and workload sizes. */
+/* Per-stage device times of the last gswt_render (hipEvent, ms) and workload sizes.  ms_ranges is ~0 since the per-tile
+ * [start, end) table is left by the last pass of the pair sort (its time is inside ms_sort); ms_scan is unused (no scan launch). */
 typedef struct {
     float ms_project, ms_scan, ms_emit, ms_sort, ms_ranges, ms_composite, ms_total;
     uint32_t n_draws;
