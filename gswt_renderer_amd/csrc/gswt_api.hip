@@ -187,6 +187,7 @@ struct DrawSet {
     std::vector<GroupDesc> g_desc;
     std::vector<gswt_merge_member> g_members;
     bool g_valid = false;
+    uint32_t src_mask = 0;                 // draw sets the device-side build of THIS set copies merged lists from (bit per set)
     hipEvent_t ev_up = nullptr;            // behind the upload: the pinned block may be refilled once it has fired
     bool ev_up_pending = false;
     bool built = false;                    // ev_up has been seen complete: frames on this set need not wait for it any more
@@ -480,6 +481,13 @@ static void collect_set(gswt_ctx* c, int set)
             sl.collected_timings = c->timings;
             sl.collected = true;
         }
+    // ... and no device-side list build still in flight may be COPYING from this set's merged arrays (the lists of the last sort events
+    // stay addressable as copy sources): everything that refills the set on the build stream is ordered behind such a copy anyway, a
+    // host-side upload (gswt_set_draws with host lists) is not
+    for (int k = 0; k < kDrawSets; k++) {
+        DrawSet& o = c->sets[k];
+        if (k != set && o.ev_up_pending && ((o.src_mask >> set) & 1u)) { (void)hipEventSynchronize(o.ev_up); o.ev_up_pending = false; }
+    }
 }
 
 namespace gswt {
@@ -853,6 +861,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     D.n_draws = (uint32_t)n_draws;
     D.n_chunks = (uint32_t)n_chunks;
     D.g_valid = false;
+    D.src_mask = 0;
     D.n_entries = entries;
     // The first draw list of a scene sizes the other draw sets too: every set's first fill used to allocate its own buffers (a
     // pinned upload block, its device mirror, chunk tables, merged arrays) inside the sort event that reached it -- the first five
@@ -1041,10 +1050,12 @@ try {
     // that cannot be one of `sources` -- they are kept from growing below -- but it is checked all the same)
     MergeSources msrc;
     for (int k = 0; k < kMergeSources; k++) { msrc.list[k] = nullptr; msrc.map[k] = nullptr; }
+    D.src_mask = 0;
     for (int k : sources) {
         if (!c->sets[k].g_valid) return fail(c, GSWT_ERR_STATE, "gswt_set_draws_merge_groups: a source set lost its lists");
         msrc.list[k] = c->sets[k].merged_list.p; msrc.map[k] = c->sets[k].merged_map.p;
     }
+    for (size_t q = 0; q < n_jobs; q++) D.src_mask |= 1u << jobs[q].src_set;
     D.g_desc.swap(desc);
     D.g_members.assign(members, members + n_members);
     D.g_valid = true;
