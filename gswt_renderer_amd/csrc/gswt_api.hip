@@ -1277,9 +1277,10 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         f.out_w = band_tiles * kTile; f.out_x0 = cfg->shard_index * band_tiles * kTile;
         // band culling bounds where a cell's splats can land: the plain surface (positions are the list positions) and the
         // HeightMap surface (the reference's default, structure.rs:75: the mapped centre is (x, y, h(x, y) hz) + n z with |n| = 1 and h
-        // between the map's extremes; the covariance becomes F Vrk F^T with |F|_F^2 <= 3 + slope_x^2 + slope_y^2).  Not the Sphere
-        // surface (its parametrisation has seams and poles: no cheap conservative bound) and not the point-cloud covariance.
-        f.band_cull = (su->surface_type <= 1u && !(su->point_cloud_radius > 0.0f)) ? 1 : 0;
+        // between the map's extremes; the covariance becomes F Vrk F^T with |F|_F^2 <= 3 + slope_x^2 + slope_y^2) and the
+        // Sphere surface (cells whose footprint stays inside one block of the strip parametrisation: sphere_cell_box in gswt_kernels.hip;
+        // the columns of F are finite differences of lz R, |.| <= 2.5 R / block_w, and lz itself).  Not the point-cloud covariance.
+        f.band_cull = (su->surface_type <= 2u && !(su->point_cloud_radius > 0.0f)) ? 1 : 0;
     }
     for (int k = 0; k < 3; k++) { f.loc_lo[k] = c->loc_lo[k]; f.loc_hi[k] = c->loc_hi[k]; }
     f.loc_max_trace = c->loc_max_trace;
@@ -1293,6 +1294,12 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         const float sx = c->hm_du * std::fabs(hz) / std::fabs(xr), sy = c->hm_dv * std::fabs(hz) / std::fabs(yr);
         f.surf_f2 = (3.0f + sx * sx + sy * sy) * 1.01f;
         if (!(f.surf_f2 == f.surf_f2) || !(f.surf_zlo == f.surf_zlo) || !(f.surf_zhi == f.surf_zhi)) f.band_cull = 0;
+    }
+    if (su->surface_type == 2u) {
+        const float block_w = ((float)su->map_half_wh[0] * 2.0f) * su->tile_width / 5.0f;
+        const float g = 2.5f * std::fabs(su->sphere_radius) / block_w;
+        f.surf_f2 = (2.0f * g * g + 1.0f) * 1.01f;
+        if (!(block_w > 0.0f) || !(f.surf_f2 == f.surf_f2) || su->map_half_wh[0] == 0u || su->map_half_wh[1] == 0u) f.band_cull = 0;
     }
     f.hm_w = c->hm_w; f.hm_h = c->hm_h;
     f.map_wh_y = 2u * su->map_half_wh[1] + (su->surface_type != 2u ? 1u : 0u);

@@ -239,7 +239,38 @@ __global__ __launch_bounds__(256) void k_chunk_tabs(const DrawDev* __restrict__ 
 // lo / hi: bounds of the splat centres BEFORE scene_scale and surface mapping (cell origin + the scene's tile-local bounds).
 // HeightMap surface (gswt.wgsl:565-599): the mapped centre is (x, y, h(x, y) hz) + n z with |n| = 1, so x and y move by at most
 // |z| and the height lies in [surf_zlo - |z|, surf_zhi + |z|]; the covariance is F Vrk F^T, lambda1 <= |F|_F^2 trace(Vrk).
-__device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], const float hi[3])
+// Sphere surface: sphere_cell_box above (bidx, bidy: the block of the draw's cell; unused elsewhere).
+// Sphere surface (gswt.wgsl:515-564, 600-623): a splat centre is lz (R + z), lz = the unit vector of the strip parametrisation at the
+// centre's block coordinates (bx, by).  Inside one block, 0 <= bx, by <= block_w, that map is continuous (also across the block's
+// diagonal and at the pole) and |d lz| <= K (|d bx| + |d by|) / block_w with K = max(0.2 pi + pi / 3, 2 pi^2 / 15 + pi / 3) = 2.363
+// (equatorial triangles: u, v linear; polar triangles: cos v <= pi (block_w - t) / (3 block_w) against |du| <= 2 pi / (5 (block_w - t))):
+// the centres of a cell lie within rho = R K (w + h) / (2 n block_w) + max |z| of the lz R of n x n sample points of its footprint.
+// K = 2.5 and 2 % on rho are the slack for the +-0.001 y_max taps of F and the rounding of the evaluation.  A footprint that leaves
+// its block (cells astride a block seam) is not bounded: such cells are kept.  lo / hi: scaled flat bounds; out: bounds of the centres.
+__device__ __forceinline__ bool sphere_cell_box(const Frame& f, float bidx, float bidy, const float lo[3], const float hi[3], float blo[3], float bhi[3])
+{
+    const float xmax = ((float)f.map_half_wh[0] * 2.0f) * f.tile_width;
+    const float block_w = xmax / 5.0f;
+    const float ox = (float)(f.center_coord[0] - (int32_t)f.map_half_wh[0]) * f.tile_width + bidx * block_w;
+    const float oy = (float)(f.center_coord[1] - (int32_t)f.map_half_wh[1]) * f.tile_width + bidy * block_w;
+    const float bx0 = lo[0] - ox, bx1 = hi[0] - ox, by0 = lo[1] - oy, by1 = hi[1] - oy;
+    if (!(block_w > 0.0f && bx0 >= 0.0f && bx1 <= block_w && by0 >= 0.0f && by1 <= block_w)) return false;
+    constexpr int n = 3;
+    const float R = fabsf(f.sphere_radius);
+    const float zmax = fmaxf(fabsf(lo[2]), fabsf(hi[2]));
+    const float rho = (R * 2.5f * ((bx1 - bx0) + (by1 - by0)) / (2.0f * (float)n * block_w) + zmax) * 1.02f + 1e-4f * R;
+    if (!(rho == rho)) return false;
+    for (int k = 0; k < 3; k++) { blo[k] = 3.402823466e+38f; bhi[k] = -3.402823466e+38f; }
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) {
+            float p[3];
+            sphere_point(block_w, bidx, bidy, bx0 + (bx1 - bx0) * (((float)i + 0.5f) / (float)n), by0 + (by1 - by0) * (((float)j + 0.5f) / (float)n), p);
+            for (int k = 0; k < 3; k++) { blo[k] = fminf(blo[k], p[k] * f.sphere_radius - rho); bhi[k] = fmaxf(bhi[k], p[k] * f.sphere_radius + rho); }
+        }
+    return blo[0] == blo[0] && bhi[0] == bhi[0] && blo[1] == blo[1] && bhi[1] == bhi[1] && blo[2] == blo[2] && bhi[2] == bhi[2];
+}
+
+__device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], const float hi[3], float bidx, float bidy)
 {
     float blo[3], bhi[3];
     for (int k = 0; k < 3; k++) {
@@ -250,6 +281,10 @@ __device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], c
         const float zp = fmaxf(fabsf(blo[2]), fabsf(bhi[2])) * 1.0001f;
         blo[0] -= zp; bhi[0] += zp; blo[1] -= zp; bhi[1] += zp;
         blo[2] = f.surf_zlo - zp; bhi[2] = f.surf_zhi + zp;
+    } else if (f.surface_type == 2u) {
+        float slo[3], shi[3];
+        if (!sphere_cell_box(f, bidx, bidy, blo, bhi, slo, shi)) return false;
+        for (int k = 0; k < 3; k++) { blo[k] = slo[k]; bhi[k] = shi[k]; }
     }
     float xmin = 3.402823466e+38f, xmax = -3.402823466e+38f, wmin = 3.402823466e+38f;
     for (int k = 0; k < 8; k++) {
@@ -293,13 +328,19 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
     for (uint32_t j = gtid; j < n_zero_b; j += gridDim.x * 256u) zero_b[j] = 0u;
     for (uint32_t j = gtid; j < n_zero_c; j += gridDim.x * 256u) zero_c[j] = 0u;       // per-chunk pair counts: culled chunks never run
     if (f.band_cull) {
-        uint32_t map_wh_y = 2u * f.map_half_wh[1] + 1u;                      // plain / HeightMap surface (band_cull is off on the Sphere)
+        const uint32_t map_wh_y = f.map_wh_y;                                // 2 h + 1; 2 h on the Sphere (gswt.wgsl:52-63, 606-610)
         for (uint32_t j = gtid; j < n_cells; j += gridDim.x * 256u) {
             // the merged-member offset of gswt.wgsl:52-63, same expression as k_project
-            const float ox = (float)((int32_t)(j / map_wh_y - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
-            const float oy = (float)((int32_t)(j % map_wh_y - f.map_half_wh[1]) + f.center_coord[1]) * f.tile_width;
+            const uint32_t mq = j / map_wh_y, mr = j % map_wh_y;
+            const float ox = (float)((int32_t)(mq - f.map_half_wh[0]) + f.center_coord[0]) * f.tile_width;
+            const float oy = (float)((int32_t)(mr - f.map_half_wh[1]) + f.center_coord[1]) * f.tile_width;
             const float lo[3] = {f.loc_lo[0] + ox, f.loc_lo[1] + oy, f.loc_lo[2]}, hi[3] = {f.loc_hi[0] + ox, f.loc_hi[1] + oy, f.loc_hi[2]};
-            cell_culled[j] = band_misses(f, lo, hi) ? 1u : 0u;
+            float bidx = 0.0f, bidy = 0.0f;
+            if (f.surface_type == 2u) {                                      // a merged member's block, as k_project derives it from the map id
+                bidx = (float)(5u * mq / (f.map_half_wh[0] * 2u));
+                bidy = (float)(2u * mr / (f.map_half_wh[1] * 2u));
+            }
+            cell_culled[j] = band_misses(f, lo, hi, bidx, bidy) ? 1u : 0u;
         }
     }
     const bool have = i < n_draws;
@@ -327,7 +368,12 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
     if (!culled && f.band_cull && d.count && d.single_draw != 1u) {
         const float lo[3] = {f.loc_lo[0] + d.off[0], f.loc_lo[1] + d.off[1], f.loc_lo[2] + d.off[2]};
         const float hi[3] = {f.loc_hi[0] + d.off[0], f.loc_hi[1] + d.off[1], f.loc_hi[2] + d.off[2]};
-        if (band_misses(f, lo, hi)) culled = 1;
+        float bidx = 0.0f, bidy = 0.0f;
+        if (f.surface_type == 2u) {
+            bidx = (float)(5u * d.map_coord[0] / (f.map_half_wh[0] * 2u));
+            bidy = (float)(2u * d.map_coord[1] / (f.map_half_wh[1] * 2u));
+        }
+        if (band_misses(f, lo, hi, bidx, bidy)) culled = 1;
     }
     if (have && sub == 0u) draw_culled[i] = culled;
     // Launch table of k_project for THIS frame: only the chunks of surviving draws, in the per-XCD layout of chunk_tab_xcd

@@ -44,6 +44,14 @@ WORKLOADS = {
                 user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
                           lod_blending=True, lod_transition_width_ratio=0.05, merge_topk=100, merge_dot_threshold=0.2,
                           lod_max_dist=64.0 * 4.0)),
+    # c3-sized frame on the Sphere surface (gswt.wgsl:600-623; maps are 5 : 2 there): 60 x 24 cells wrapped onto a sphere whose
+    # circumference is the map's width, seen whole from outside (sphere mapping per splat = k_project<FULL>; band cull through sphere_cell_box)
+    "c3s": dict(desc="60x24 map on the Sphere surface (R = 38.2), ~13M instanced Gaussians, 1920x1080, LOD blending + Edge merging",
+                half=(30, 12), lod0=9800, n_lod=3, width=1920, height=1080,
+                camera=dict(pos=(20.0, -95.0, 35.0), target=(0.0, 0.0, 0.0), up=(0.0, 0.0, 1.0), fovy=45.0, near=0.1, far=2400.0),
+                user=dict(surface_type=host.SURFACE_SPHERE, sphere_radius=38.2, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,
+                          lod_blending=True, lod_transition_width_ratio=0.05, merge_topk=100, merge_dot_threshold=0.2,
+                          lod_max_dist=64.0 * 4.0)),
     "c5": dict(desc="129x129 map (128x128 grid nearest valid), ~100M instanced Gaussians, 3840x2160, full LOD",
                half=(64, 64), lod0=6100, n_lod=3, width=3840, height=2160,
                user=dict(surface_type=host.SURFACE_NONE, tile_sort_type=host.SORT_GRAPH, merge_type=host.MERGE_EDGE,

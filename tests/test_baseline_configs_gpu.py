@@ -1,7 +1,7 @@
 """BASELINE.json's configurations through the C ABI, each against the CPU oracle at full size.
 
 c1 (1x1 map, ~50 k splats, 640x480), c2 (5x5 map, ~1 M instanced, 1280x720, LOD off), c3 (33x33 map, ~10 M instanced,
-1920x1080, LOD blending + Edge merging; `c3h` = the same on the GUI's default HeightMap surface) and c5 (129x129 map,
+1920x1080, LOD blending + Edge merging; `c3h` = the same on the GUI's default HeightMap surface, `c3s` = a 60x24 map on the Sphere surface) and c5 (129x129 map,
 ~94 M instanced, 3840x2160, skybox + proxy passes in front of the splats).  c4 (c3 sharded over 2/4/8 GPUs) needs more than
 the one GPU of the test box: its shard layout is covered here by the bitwise union of the 8 column bands rendered one
 after the other on one device.  The workloads are built exactly as bench.py builds them (gswt_renderer_amd/workloads.py);
@@ -43,7 +43,7 @@ def _both_sides(renderer, name, device_merge=False):
     return dict(w=w, W=W, H=Hh, pipe=pipe, cu=cu, vp=vp, pp=pp, ocam=ocam, odraws=odraws, osu=osu, hm=hm, osort=osort)
 
 
-@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c3h"])
+@pytest.mark.parametrize("name", ["c1", "c2", "c3", "c3h", "c3s"])
 def test_baseline_config_matches_oracle(renderer, name):
     s = _both_sides(renderer, name)
     W, Hh, pipe = s["W"], s["H"], s["pipe"]
@@ -57,16 +57,20 @@ def test_baseline_config_matches_oracle(renderer, name):
     # what bench.py times: front-to-back early termination at 1e-5
     img_e = pipe.render(s["cu"], W, Hh, transmittance_eps=1e-5)
     assert H.max_abs_diff(img_e, ref) <= TOL
-    if name == "c3":
+    if name in ("c3", "c3s"):
         # c4's shard layout on one device: 8 column bands, each with its own draw cull; their union is the frame, bit for bit
+        # (c3s: the same on the Sphere surface, whose cells are bounded by sphere_cell_box)
         n = 8
         bw = renderer.shard_cols_padded(W, n)
         uni = np.zeros_like(img)
+        vis = []
         for r in range(n):
             part = pipe.render(s["cu"], W, Hh, shard=(r, n, "cols"))
+            vis.append(renderer.timings()["n_visible"])
             x0, x1 = r * bw, min(W, (r + 1) * bw)
             uni[:, x0:x1] = part[:, :x1 - x0]
         assert np.array_equal(uni, img)
+        assert max(vis) < st["n_visible"], (vis, st)            # every band drops cells that cannot reach it
 
 
 def test_c3_device_built_merged_lists(renderer):

@@ -326,12 +326,23 @@ def test_column_band_shards_equal_unsharded(renderer, n):
         assert sum(vis) > 0
         if n >= 3:                                                  # the inflated boxes still let some band drop something
             assert min(vis) < st["n_visible"], (vis, st)
-    # the Sphere surface: column bands without the cull (its parametrisation has seams and poles: no cheap conservative bound)
-    cfgs = dict(tile_map_half_wh=(5, 2), surface_type=2, sphere_radius=6.5, lod_max_dist=60.0, tile_sort_type=3, merge_type=2)
-    cam = ((3.0, -19.0, 6.0), (0.0, 0.0, 0.0))
-    full, ref, _, _ = _run_case(renderer, cfgs, cam, 320, 240, lod0=700)
-    img, _, _, _ = _run_case(renderer, cfgs, cam, 320, 240, lod0=700, shard=n, shard_cols=True)
-    assert np.array_equal(img, full)
+    # the Sphere surface: a cell's centres are bounded through the Lipschitz constant of the strip parametrisation (sphere_cell_box);
+    # whole sphere in view, the north pole under the camera, the south pole from close by.  (The splat-radius bound carries |F|^2 <=
+    # 2 (2.5 R / block_w)^2 + 1 and the coarsest LOD's covariance: at 320 px it only lets go of cells with splat_scale < 1.)
+    # (splat_scale, camera, smallest number of bands at which some band must project less than the whole frame; None: union only)
+    for ss, cam, cull_from in ((0.3, ((3.0, -19.0, 6.0), (0.0, 0.0, 0.0)), 3), (0.3, ((9.0, -30.0, 8.0), (0.0, 0.0, 0.0)), 3),
+                               (0.2, ((0.6, 0.4, 16.0), (0.0, 0.0, 0.0)), 8), (0.3, ((0.6, 0.4, 11.0), (0.0, 0.0, 0.0)), None),
+                               (0.25, ((2.0, -3.0, -9.5), (0.0, 0.0, -6.5)), None), (1.0, ((3.0, -19.0, 6.0), (0.0, 0.0, 0.0)), None)):
+        cfgs = dict(tile_map_half_wh=(5, 2), surface_type=2, sphere_radius=6.5, lod_max_dist=60.0, tile_sort_type=3, merge_type=2)
+        rc = dict(splat_scale=ss)
+        full, ref, _, st = _run_case(renderer, cfgs, cam, 320, 240, lod0=700, render_config=rc)
+        assert H.max_abs_diff(full, ref) <= TOL
+        vis = []
+        img, _, _, _ = _run_case(renderer, cfgs, cam, 320, 240, lod0=700, shard=n, shard_cols=True, stats=vis, render_config=rc)
+        assert np.array_equal(img, full), (ss, cam, n)
+        assert sum(vis) > 0
+        if cull_from is not None and n >= cull_from:
+            assert min(vis) < st["n_visible"], (ss, cam, vis, st)
 
 
 def test_column_bands_follow_a_moving_camera(renderer):

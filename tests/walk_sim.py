@@ -151,3 +151,41 @@ decouple(256,1536)
 decouple(128,1536,lead=2)
 decouple(128,1536,lead=4)
 decouple(256,1536,lead=1)
+
+# ---- how much shorter would the lists be if the staging lane tested the ELLIPSE (r2 <= 4) against each 4x4 sub-block instead of its box?
+def exact_cover(batch=256, seg=1536, chunk=200000):
+    sidp = sid[o]                                   # splat of each pair, composite order within tile
+    cxm, cym, uxm, uym, wxm, wym = [a_[m].astype(np.float64) for a_ in (cx, cy, ux, uy, wx, wy)]
+    det = uxm*wym - uym*wxm
+    ia, ib, ic, idd = wym/det, -wxm/det, -uym/det, uxm/det   # [s t]^T = [[ia ib],[ic idd]] (pixel - c)
+    px = np.arange(16, dtype=np.float64) + 0.5
+    box_mask = np.zeros(P, dtype=np.uint16); ell_mask = np.zeros(P, dtype=np.uint16); covered = np.zeros(P, dtype=np.int32)
+    tx = (tile % tiles_x) * 16; ty = (tile // tiles_x) * 16
+    for a in range(0, P, chunk):
+        b = min(P, a + chunk); s_ = sidp[a:b]
+        dx = (tx[a:b, None] + px[None, :]) - cxm[s_, None]      # n x 16
+        dy = (ty[a:b, None] + px[None, :]) - cym[s_, None]
+        s = ia[s_, None, None] * dx[:, None, :] + ib[s_, None, None] * dy[:, :, None]   # n x 16(y) x 16(x)
+        t = ic[s_, None, None] * dx[:, None, :] + idd[s_, None, None] * dy[:, :, None]
+        cov = (s * s + t * t) <= 4.0
+        inbox = ((np.arange(16)[None, None, :] >= lx0[a:b, None, None]) & (np.arange(16)[None, None, :] <= lx1[a:b, None, None]) &
+                 (np.arange(16)[None, :, None] >= ly0[a:b, None, None]) & (np.arange(16)[None, :, None] <= ly1[a:b, None, None]))
+        cov &= inbox
+        covered[a:b] = cov.sum(axis=(1, 2))
+        sb = cov.reshape(-1, 4, 4, 4, 4).any(axis=(2, 4))                         # n x 4(by) x 4(bx)
+        bb = inbox.reshape(-1, 4, 4, 4, 4).any(axis=(2, 4))
+        wts = (1 << np.arange(16)).reshape(4, 4)
+        ell_mask[a:b] = (sb * wts).sum(axis=(1, 2)); box_mask[a:b] = (bb * wts).sum(axis=(1, 2))
+    nbat = (seg + batch - 1) // batch
+    bid_local = (pos % seg) // batch + (pos // seg) * nbat
+    key = tile * 100000 + bid_local
+    bfirst = np.r_[0, np.flatnonzero(np.diff(key)) + 1]
+    def steps(mask):
+        counts = np.stack([np.add.reduceat(((mask >> k) & 1).astype(np.int64), bfirst) for k in range(16)], axis=1).reshape(-1, 4, 4)
+        return int(counts.sum()), int(counts.max(axis=2).sum()), int(counts.max(axis=2).max(axis=1).sum())
+    eb, sb_, cb = steps(box_mask); ee, se, ce = steps(ell_mask)
+    print(f"box lists: entries {eb}, wave-steps {sb_}, workgroup critical path {cb}")
+    print(f"ellipse-exact lists: entries {ee} ({ee/eb:.3f}), wave-steps {se} ({se/sb_:.3f}), critical path {ce} ({ce/cb:.3f})")
+    print(f"pairs with no covered pixel at all: {(covered == 0).mean():.3f}; covered pixels per pair {covered.mean():.1f}; lane utilisation box {covered.sum()/(sb_*64):.3f} -> exact {covered.sum()/(se*64):.3f}")
+if os.environ.get("WALK_SIM_EXACT", "1") != "0":
+    exact_cover()
