@@ -1,0 +1,13 @@
+#!/bin/bash
+# k_project one frame at a time with each ablation flag (see pmc_project_ablation.sh): where its time goes.  GPU box: bash tools/project_ablation_times.sh
+mkdir -p gpurun_out/abl_t
+export TMPDIR=/tmp
+for FL in 0 8 16 128 256; do
+  export GSWT_DBG_FLAGS=$FL
+  D=gpurun_out/abl_t/f$FL
+  rocprofv3 --kernel-trace --stats --output-format csv -d $D -- python3 tools/serial_frames.py c3 20 > $D.log 2>&1
+  F=$(find $D -name "*kernel_stats.csv" | head -1)
+  python3 tools/pmc_summary.py stats $F $D.csv
+  echo "flags $FL: $(grep k_project $D.csv)"
+  rm -rf $D
+done
