@@ -959,14 +959,25 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
             return;
         }
         if (count == 0) continue;
-        int ty = ty0;
-        if (sc > 1) ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc;
-        for (; ty <= ty1; ty += sc) {
-            const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
-            for (int tx = tx0; tx <= tx1; tx++) {
-                keys[off] = row + (uint32_t)(tx - f.col0);
-                vals[off] = slot;
-                off++;
+        if (sc > 1) {                                                // row shards: this rank's rows of the rect, numbered locally
+            for (int ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc; ty <= ty1; ty += sc) {
+                const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
+                for (int tx = tx0; tx <= tx1; tx++) {
+                    keys[off] = row + (uint32_t)(tx - f.col0);
+                    vals[off] = slot;
+                    off++;
+                }
+            }
+        } else {
+            // the usual frame: a loop of its own, so that the ~25-instruction integer division by the shard count is not part of every row of
+            // every splat (as `ty / sc` with sc == 1 it was: the compiler cannot know the uniform's value)
+            for (int ty = ty0; ty <= ty1; ty++) {
+                const uint32_t row = (uint32_t)ty * (uint32_t)f.tiles_x;
+                for (int tx = tx0; tx <= tx1; tx++) {
+                    keys[off] = row + (uint32_t)(tx - f.col0);
+                    vals[off] = slot;
+                    off++;
+                }
             }
         }
     }
@@ -1333,14 +1344,23 @@ __global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* _
     }
     if (count == 0) return;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
-    int ty = ty0;
-    if (sc > 1) ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc;
-    for (; ty <= ty1; ty += sc) {
-        const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
-        for (int tx = tx0; tx <= tx1; tx++) {
-            keys[off] = row + (uint32_t)(tx - f.col0);
-            vals[off] = slot;
-            off++;
+    if (sc > 1) {
+        for (int ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc; ty <= ty1; ty += sc) {
+            const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
+            for (int tx = tx0; tx <= tx1; tx++) {
+                keys[off] = row + (uint32_t)(tx - f.col0);
+                vals[off] = slot;
+                off++;
+            }
+        }
+    } else {
+        for (int ty = ty0; ty <= ty1; ty++) {                        // (see k_emit: no division by the shard count in the usual frame)
+            const uint32_t row = (uint32_t)ty * (uint32_t)f.tiles_x;
+            for (int tx = tx0; tx <= tx1; tx++) {
+                keys[off] = row + (uint32_t)(tx - f.col0);
+                vals[off] = slot;
+                off++;
+            }
         }
     }
 }
