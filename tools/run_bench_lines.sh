@@ -1,11 +1,12 @@
 #!/bin/bash
-# The bench lines kept under profiles/ (one GPU): default c3 line (with the CPU baseline), dense / HeightMap / c5 variants,
+# The bench lines kept under profiles/ (one GPU): default c3 line (with the CPU baseline), dense / HeightMap / Sphere / c5 variants,
 # graph mode, the device-side worker, the PCIe-inclusive rate and the GPU tests' skip reasons.  Usage: bash tools/run_bench_lines.sh <outdir>
 O=${1:-gpurun_out/lines}; mkdir -p $O
 python bench.py > $O/bench_c3.json 2> $O/bench_c3.err
 python bench.py --graph --no-cpu-baseline > $O/bench_c3_graph.json 2>> $O/bench_c3.err
 python bench.py --workload c3d > $O/bench_c3d.json 2> $O/bench_c3d.err
 python bench.py --workload c3h --no-cpu-baseline > $O/bench_c3h.json 2> $O/bench_c3h.err
+python bench.py --workload c3s > $O/bench_c3s.json 2> $O/bench_c3s.err
 python bench.py --workload c5 > $O/bench_c5_passes.json 2> $O/bench_c5.err
 python bench.py --device-worker --no-cpu-baseline > $O/bench_c3_device_worker.json 2> $O/bench_dw.err
 python tools/pcie_rate.py c3 100 > $O/pcie_rate_c3.txt 2> $O/pcie.err
