@@ -1304,6 +1304,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     f.hm_w = c->hm_w; f.hm_h = c->hm_h;
     f.map_wh_y = 2u * su->map_half_wh[1] + (su->surface_type != 2u ? 1u : 0u);
     f.map_wh_y_magic = f.map_wh_y ? 0xFFFFFFFFu / f.map_wh_y + 1u : 0u;
+    f.tiles_x_magic = f.tiles_x > 0 && f.tiles_x < 65536 ? 0xFFFFFFFFu / (uint32_t)f.tiles_x + 1u : 0u;
     f.dbg_flags = c->opt_dbg_flags;
 
     const int rsc = f.shard_count;                                  // row-shard count (1 in column mode)

@@ -70,6 +70,7 @@ struct Frame {
     float surf_zlo, surf_zhi;              // HeightMap surface: range of the mapped height h(x, y) * height_map_scale.z (0, 0 on the plain surface)
     float surf_f2;                         // bound of |F|^2 of the surface frame F (1 on the plain surface): Vrk -> F Vrk F^T
     int32_t hm_w, hm_h;
+    uint32_t tiles_x_magic;                // floor(2^32 / tiles_x) + 1: tile -> (column, row) by multiply-high for tile ids below 2^16 (tile_xy)
     uint32_t map_wh_y, map_wh_y_magic;     // height of the tile map in cells (gswt.wgsl:53-56) and floor(2^32 / it) + 1 (quotients of 16-bit map ids by multiply-high)
     int32_t dbg_flags;       // profiling ablations (GSWT_OPT_DEBUG_FLAGS); 0 in normal operation
 };

@@ -196,6 +196,17 @@ __device__ __forceinline__ void debug_draw_color(const Frame& f, const DrawDev& 
     }
 }
 
+// Screen tile id -> (column, row) of this ctx's tile grid.  The id is uniform per workgroup: for ids and widths below 2^16 the quotient is
+// the high word of id * (floor(2^32 / tiles_x) + 1) -- one scalar multiply instead of the ~25 vector instructions of a 32-bit division
+// that every wave of k_composite / k_combine used to spend on it (exact: the error of the product stays below 2^-16 <= 1 / tiles_x).
+__device__ __forceinline__ void tile_xy(const Frame& f, uint32_t tile, int& tx, int& ty)
+{
+    uint32_t q;
+    if (f.tiles_x_magic != 0u && tile < 65536u) q = __umulhi(tile, f.tiles_x_magic);
+    else q = tile / (uint32_t)f.tiles_x;
+    tx = (int)(tile - q * (uint32_t)f.tiles_x); ty = (int)q;
+}
+
 // Number of 16-px tile rows in [ty0, ty1] owned by this shard (row % count == index).
 __device__ __forceinline__ int owned_rows(int ty0, int ty1, int index, int count)
 {
@@ -1875,7 +1886,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
 #endif
     const int tile = (int)it.x;
     const bool multi_seg = (it.y & 1u) != 0u;
-    const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
+    int tx, tyl;
+    tile_xy(f, (uint32_t)tile, tx, tyl);
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
     const int bx = (tx + f.col0) * kTile, by = ty * kTile;
@@ -2048,7 +2060,8 @@ __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* 
     if (tile == 0 && threadIdx.x < 4u && host_counters) host_counters[threadIdx.x] = counters[threadIdx.x];
     const uint32_t i0 = item_base[tile], n_seg = item_base[tile + 1] - i0;
     if (n_seg == 1u) return;                      // the tile's only work item wrote the pixels itself; n_seg == 0: no pairs, background only
-    const int tx = tile % f.tiles_x, tyl = tile / f.tiles_x;
+    int tx, tyl;
+    tile_xy(f, (uint32_t)tile, tx, tyl);
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
     const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
