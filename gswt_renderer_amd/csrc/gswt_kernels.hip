@@ -431,6 +431,15 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
 // outgrew its grid and the host re-runs it) instead of from the whole table: the dispatcher hands out ~4.6 k workgroups per us
 // (flag 256: c5's 366 k workgroups that only read the launch table and leave take ~80 us), but the workgroups of culled chunks
 // overlap with the live ones: project stage 461 -> 433 us at c5, 87 -> 87 us at c3, frame rates unchanged.
+// The quotients and roots of the projection are IEEE operations (correctly rounded: what the CPU checker reproduces).  -DGSWT_AB_FASTMATH
+// (measurement only, WRONG bits) swaps them for the 1-ulp hardware approximations: the upper bound of what a cheaper exact sequence could gain.
+#ifdef GSWT_AB_FASTMATH
+#define GSWT_RCP(X) __builtin_amdgcn_rcpf(X)
+#define GSWT_SQRT(X) __builtin_amdgcn_sqrtf(X)
+#else
+#define GSWT_RCP(X) (1.0f / (X))
+#define GSWT_SQRT(X) sqrtf(X)
+#endif
 template <bool DEBUG, bool FULL>
 __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
@@ -644,7 +653,7 @@ __global__ __launch_bounds__(256) void k_project(
             float d0 = c0 - f.cam_pos[0], d1 = c1 - f.cam_pos[1], d2 = c2 - f.cam_pos[2];
             float t[3];
             for (int rr = 0; rr < 3; rr++) t[rr] = fmaf(f.V[8 + rr], d2, fmaf(f.V[4 + rr], d1, f.V[rr] * d0));
-            const float rz = 1.0f / t[2];
+            const float rz = GSWT_RCP(t[2]);
             float txtz = t[0] * rz, tytz = t[1] * rz;
             float limx = 1.3f * f.htan[0], limy = 1.3f * f.htan[1];
             t[0] = clampf(txtz, -limx, limx) * t[2];
@@ -667,15 +676,15 @@ __global__ __launch_bounds__(256) void k_project(
             float c11 = fmaf(A1[2], T1[2], fmaf(A1[1], T1[1], A1[0] * T1[0]));
             float mid = 0.5f * (c00 + c11);
             float hxx = 0.5f * (c00 - c11);
-            float radius = sqrtf(fmaf(hxx, hxx, c01 * c01));
+            float radius = GSWT_SQRT(fmaf(hxx, hxx, c01 * c01));
             float l1 = mid + radius, l2 = mid - radius;
             if (l2 < 0.0f) break;
             float vx = c01, vy = l1 - c00;
-            float vlen = sqrtf(fmaf(vx, vx, vy * vy));
-            const float rv = 1.0f / vlen;
+            float vlen = GSWT_SQRT(fmaf(vx, vx, vy * vy));
+            const float rv = GSWT_RCP(vlen);
             float ex = vx * rv, ey = vy * rv;
-            float smaj = fminf(sqrtf(2.0f * l1), 1024.0f);
-            float smin = fminf(sqrtf(2.0f * l2), 1024.0f);
+            float smaj = fminf(GSWT_SQRT(2.0f * l1), 1024.0f);
+            float smin = fminf(GSWT_SQRT(2.0f * l2), 1024.0f);
             float majx = smaj * ex, majy = smaj * ey;
             float minx = smin * ey, miny = smin * -ex;
             // A9 :260-265, 402-410 (byte / 255 as byte * fl(1 / 255))
@@ -691,7 +700,7 @@ __global__ __launch_bounds__(256) void k_project(
             }
             // rgba *= clamp(z/w + 1, 0, 1): identically 1 for 0 <= z/w, kept for the debug output only
             // A10 :415-419
-            const float rq = 1.0f / q[3];
+            const float rq = GSWT_RCP(q[3]);
             float ndcx = q[0] * rq, ndcy = q[1] * rq, depth = q[2] * rq;
             if (DEBUG) {
                 float fade = clampf(fmaf(q[2], rq, 1.0f), 0.0f, 1.0f);
@@ -713,11 +722,11 @@ __global__ __launch_bounds__(256) void k_project(
             visible = true;
             // depth_compare Less against the 1.0 clear when no proxy depth is bound (renderer.rs:182,436)
             if (!f.has_depth && !(depth < 1.0f)) { visible = false; break; }
-            const float ruu = 1.0f / uu, rww = 1.0f / ww;
+            const float ruu = GSWT_RCP(uu), rww = GSWT_RCP(ww);
             const float r_iux = ux * ruu, r_iuy = uy * ruu, r_ivx = wx * rww, r_ivy = wy * rww;
             // half extents of |p| <= 2, inflated by 1e-5 relative + 1e-3 px (conservative under f32 rounding)
-            float hx = fmaf(2.0f * sqrtf(fmaf(wx, wx, ux * ux)), 1.00001f, 0.001f);
-            float hy = fmaf(2.0f * sqrtf(fmaf(wy, wy, uy * uy)), 1.00001f, 0.001f);
+            float hx = fmaf(2.0f * GSWT_SQRT(fmaf(wx, wx, ux * ux)), 1.00001f, 0.001f);
+            float hy = fmaf(2.0f * GSWT_SQRT(fmaf(wy, wy, uy * uy)), 1.00001f, 0.001f);
             // pixels whose CENTRE lies inside the box: x in [ceil(c - h - 0.5), floor(c + h - 0.5)]
             float fx0 = ceilf(cxp - hx - 0.5f), fx1 = floorf(cxp + hx - 0.5f);
             float fy0 = ceilf(cyp - hy - 0.5f), fy1 = floorf(cyp + hy - 0.5f);
