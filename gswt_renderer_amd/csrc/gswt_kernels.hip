@@ -427,10 +427,32 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
 // splats a rank of 8 carries through the whole projection fell from 471-619 k to 217-266 k (union of the bands still bitwise the
 // unsharded image), and the kernel's time did not move (49-66 us per rank before and after; c5 441 -> 451 us per frame): in band
 // mode, too, the kernel is paced by its workgroups' load chains, not by the projection's instructions.
+// (9) round 3, with per-workgroup phase stamps (-DGSWT_TRACE, tools/project_trace.py): c3's 13.7 k live workgroups live 5.1 us each (launch
+// table 0.4, list word 1.0, record 1.0, projection 1.7, barrier 0.5, sums 0.4) and start at ~260 per us, so that ~1 300 of the 2 048 slots are
+// filled on average (each CU peaks at 7-8): lifetimes sum to 34 us x 2 048.  Two / four chunks per workgroup (half / a quarter of the
+// workgroups for the dispatcher): 87 -> 101 -> 113 us.  A PERSISTENT grid taking launch positions from per-XCD queue heads (one returning
+// atomic per chunk, issued a chunk ahead; the frame constants through device memory so that the loop does not hoist 150 scalar loads):
+// 240 us with the eight heads in one cache line (~65 returning atomics per us and line), 114 us with the heads 256 bytes apart -- the loop
+// costs 83 VGPRs (5 workgroups per CU, all of them busy: 1 150 resident, a chunk lives 5.8 us, 199 chunks per us against 264).
 // (8) the grid sized from the previous frame's table of live chunks (+ 50 % + 64 per XCD list; k_totals flags a frame whose table
 // outgrew its grid and the host re-runs it) instead of from the whole table: the dispatcher hands out ~4.6 k workgroups per us
 // (flag 256: c5's 366 k workgroups that only read the launch table and leave take ~80 us), but the workgroups of culled chunks
 // overlap with the live ones: project stage 461 -> 433 us at c5, 87 -> 87 us at c3, frame rates unchanged.
+// -DGSWT_TRACE (tools/composite_trace.py): per work item, 100 MHz wall-clock stamps of the compositor's phases, left by lane 0 of wave 0:
+// [0] entry, [1] item known, [2] first batch staged (gathers have arrived), [3] last walk done, [4] pairs of the item,
+// [5] walk steps of wave 0 / of the wave, [6] ticks wave 0 spent in bin + walk, [7] hardware id (HW_ID | XCC_ID << 32)
+#ifdef GSWT_TRACE
+constexpr uint32_t kTraceItems = 1u << 17;
+__device__ unsigned long long g_trace[kTraceItems * 8];
+#define GSWT_TR(K, V) { if (tr_on) g_trace[(size_t)tr_item * 8u + (K)] = (unsigned long long)(V); }
+#define GSWT_NOW() wall_clock64()
+#else
+#define GSWT_TR(K, V)
+#define GSWT_NOW() 0ull
+#endif
+// k_project's stamps (tools/project_trace.py), rows 8192 + launch position: [0] entry, [1] launch-table entry known, [2] list word arrived (lane 0),
+// [3] record arrived (lane 0, when it gets that far), [4] wave 0 through the projection, [5] behind the workgroup barrier, [6] end,
+// [7] hardware id (HW_ID | XCC_ID << 32) | chunk has pairs << 63
 // The quotients and roots of the projection are IEEE operations (correctly rounded: what the CPU checker reproduces).  -DGSWT_AB_FASTMATH
 // (measurement only, WRONG bits) swaps them for the 1-ulp hardware approximations: the upper bound of what a cheaper exact sequence could gain.
 #ifdef GSWT_AB_FASTMATH
@@ -458,6 +480,11 @@ __global__ __launch_bounds__(256) void k_project(
     // live count exit after one cached scalar load); the debug-varyings build visits every chunk through the static table.
     uint2 ct;
     uint32_t list_top = 0, list_cnt = 0;      // non-DEBUG: list index of this chunk's lane 0, list length | merged << 31 (from k_cull)
+#ifdef GSWT_TRACE
+    const bool tr_on = threadIdx.x == 0 && blockIdx.x < 49152u;
+    const uint32_t tr_item = 8192u + blockIdx.x;
+    GSWT_TR(0, GSWT_NOW())
+#endif
     if (DEBUG) {
         ct = chunk_tab[blockIdx.x];
         if (ct.y == 0xFFFFFFFFu) return;    // padding of a short per-XCD list
@@ -467,6 +494,10 @@ __global__ __launch_bounds__(256) void k_project(
         ct = make_uint2(lt.x, lt.y);
         list_top = lt.z; list_cnt = lt.w;
         if (f.dbg_flags & 256) return;      // ablation: nothing behind the launch-table entry
+#ifdef GSWT_TRACE
+        { unsigned long long sink = lt.x + lt.w; asm volatile("" :: "s"(sink)); }
+        GSWT_TR(1, GSWT_NOW())
+#endif
     }
     const DrawDev& d = draws[ct.x];
     const uint32_t tid = threadIdx.x;
@@ -493,6 +524,10 @@ __global__ __launch_bounds__(256) void k_project(
         const uint32_t map_id_m = mrg ? merged_map[li] : 0u;
         const uint32_t gs_index = entry & kIdxMask;
         const uint32_t lod_id = entry >> kLodShift;
+#ifdef GSWT_TRACE
+        { unsigned long long sink = entry; asm volatile("" :: "v"(sink)); }
+        GSWT_TR(2, GSWT_NOW())
+#endif
         do {
             // column-band shard: the member tile this entry belongs to cannot reach the band (k_cull's cell table)
             if (f.band_cull && d.single_draw == 1u && cell_culled[map_id_m] != 0u) break;
@@ -502,6 +537,10 @@ __global__ __launch_bounds__(256) void k_project(
             // A2 :45-49
             const uint4 w0 = tex[2 * (size_t)gs_index];
             const uint4 w1 = tex[2 * (size_t)gs_index + 1];
+#ifdef GSWT_TRACE
+            { unsigned long long sink = w0.x + w1.w; asm volatile("" :: "v"(sink)); }
+            GSWT_TR(3, GSWT_NOW())
+#endif
             // A3 :52-65
             float ox = d.off[0], oy = d.off[1], oz = d.off[2];
             if (d.single_draw == 1u) {
@@ -753,6 +792,7 @@ __global__ __launch_bounds__(256) void k_project(
         } while (0);
     }
     if (DEBUG && in_list) dbg[d.entry_base + (d.count - 1u - r)] = vout;
+    GSWT_TR(4, GSWT_NOW())
 
     // workgroup sums: pairs and visible splats
     uint32_t wsum = count, wvis = visible ? 1u : 0u;
@@ -762,7 +802,12 @@ __global__ __launch_bounds__(256) void k_project(
     }
     if ((tid & 63u) == 0) { s_wsum[tid >> 6] = wsum; s_wvis[tid >> 6] = wvis; }
     __syncthreads();
+    GSWT_TR(5, GSWT_NOW())
     const uint32_t bsum = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+#ifdef GSWT_TRACE
+    { unsigned hwid, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      GSWT_TR(7, (unsigned long long)hwid | ((unsigned long long)(xcc & 0xFFu) << 32) | ((unsigned long long)(bsum ? 1u : 0u) << 63)) }
+#endif
     // k_emit reads the rects of a chunk only when the chunk has pairs
     if (bsum) rects[slot] = my_rect;
     if (tid == 0) {
@@ -773,6 +818,7 @@ __global__ __launch_bounds__(256) void k_project(
         uint32_t v = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
         if (v) atomicAdd(&super_sums[n_super + (cid >> 8)], v);
     }
+    GSWT_TR(6, GSWT_NOW())
 }
 
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total);
@@ -1018,18 +1064,6 @@ __device__ __forceinline__ uint32_t clamped_count(const unsigned long long* n_pt
     return (uint32_t)n;
 }
 
-// -DGSWT_TRACE (tools/composite_trace.py): per work item, 100 MHz wall-clock stamps of the compositor's phases, left by lane 0 of wave 0:
-// [0] entry, [1] item known, [2] first batch staged (gathers have arrived), [3] last walk done, [4] pairs of the item,
-// [5] walk steps of wave 0 / of the wave, [6] ticks wave 0 spent in bin + walk, [7] hardware id (HW_ID | XCC_ID << 32)
-#ifdef GSWT_TRACE
-constexpr uint32_t kTraceItems = 1u << 17;
-__device__ unsigned long long g_trace[kTraceItems * 8];
-#define GSWT_TR(K, V) { if (tr_on) g_trace[(size_t)tr_item * 8u + (K)] = (unsigned long long)(V); }
-#define GSWT_NOW() wall_clock64()
-#else
-#define GSWT_TR(K, V)
-#define GSWT_NOW() 0ull
-#endif
 // A sort workgroup takes 4096 consecutive items whatever its width: THREADS x (4096 / THREADS) per thread, each wave ranking
 // its share 64 at a time.  Sweeps, frames/s with two frames in flight (bench.py, 300 steps): c3 (2.66 M pairs) 256 threads
 // 3733, 512 3925, 1024 3899; c3h 3105 / 3578 / 3589; c5 (21 M pairs) 537.5 / 531.6 / 506.2.  The sort stage alone at c3:
