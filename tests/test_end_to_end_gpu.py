@@ -100,6 +100,17 @@ def test_more_than_8192_screen_tiles(renderer):
     assert H.max_abs_diff(img, ref) <= TOL
 
 
+def test_more_than_65536_screen_tiles(renderer):
+    """5120x3472 = 320 x 217 = 69 440 screen tiles: 17 tile bits = three passes of the tile-bit sort, and tile ids above 2^16 take the plain
+    division in tile_xy (k_composite / k_combine map ids below 2^16 to (column, row) by multiply-high)."""
+    cfg = dict(tile_map_half_wh=(2, 2), surface_type=0, lod_max_dist=40.0, tile_sort_type=3, merge_type=2)
+    cam = ((2.0, -9.0, 7.0), (2.0, 2.0, 0.0))
+    img, ref, _, st = _run_case(renderer, cfg, cam, 5120, 3472, lod0=500)
+    assert st["n_visible"] > 500
+    assert img[3280:, :, 3].max() > 0.05                  # splats in the rows whose tiles have ids >= 65 600
+    assert H.max_abs_diff(img, ref) <= TOL
+
+
 def test_heightmap_surface_with_background_and_depth(renderer):
     cfg = dict(tile_map_half_wh=(3, 4), surface_type=1, lod_max_dist=24.0, tile_sort_type=3, merge_type=2,
                height_map_wh=(4, 4), height_map_scale=(1.0, 1.0, 0.3))
