@@ -81,7 +81,7 @@ def oracle_draws(wang, sort, vp, culling_dist=1.0):
     return tex, draws
 
 
-def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, height_map=None):
+def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, height_map=None, order_mode=0):
     """Times the CPU oracle (oracle/gswt_oracle.c, OpenMP) on ONE frame of the same workload."""
     from oracle import gswt_oracle as orc
     tex, draws = oracle_draws(wang, sort, vp, culling_dist)
@@ -98,7 +98,7 @@ def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, he
         bg = orc.skybox_render(cam, faces, W, H)
         bgd = np.ones((H, W), np.float32)
         orc.proxy_render(orc.Proxy224.from_buffer_copy(bytes(pu)), W, H, bg, bgd, mips)
-    img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads, bg_rgba=bg, bg_depth=bgd, height_map=height_map)
+    img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads, bg_rgba=bg, bg_depth=bgd, height_map=height_map, order_mode=order_mode)
     dt = time.perf_counter() - t0
     return img, st, dt, n_threads
 
@@ -277,6 +277,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="never use GSWT_OPT_GRAPH")
     ap.add_argument("--segment", type=int, default=0, help="GSWT_OPT_SEGMENT, pairs per compositor work item (multiple of 256); 0 = from the first frame's pairs per screen tile: 4 x that, between the library's default and 4096 (dense scenes with the early-out on gain from long segments)")
     ap.add_argument("--static-steps", type=int, default=100, help="flypath mode: frames of the static-camera comparison run (0: skip)")
+    ap.add_argument("--order", default="reference", choices=["reference", "depth"], help="reference: tiles back to front, presorted lists (wangtile.rs:489-499, "
+                    "scene.rs:685-695); depth: GSWT_ORDER_DEPTH, every visible splat of the frame in true depth order (the global radix depth sort)")
+    ap.add_argument("--strict-vs", action="store_true", help="GSWT_OPT_STRICT_VS: the vertex stage operator by operator as gswt.wgsl:152-258 writes it")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU baseline: fly-path frames are rendered by the oracle until this much time has gone (at most 24 frames)")
     args = ap.parse_args()
     if args.timing_every <= 0:
         args.timing_every = 2 if args.steps < 64 else 3       # 0 = auto: short runs time every other frame (10 samples in the driver's 20 steps; the frames between them can go through GSWT_OPT_GRAPH); 3 is coprime with the 4 frame slots, so every slot is sampled
@@ -321,6 +325,9 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     r.set_stream(stream.cuda_stream)                    # ctx stream: fences, all-gather and unshard are ordered on it
     r.set_option(L.GSWT_OPT_TIMING, args.timing)
+    if args.strict_vs:
+        r.set_option(L.GSWT_OPT_STRICT_VS, 1)
+    order_mode = L.GSWT_ORDER_DEPTH if args.order == "depth" else L.GSWT_ORDER_REFERENCE
     wang.upload_to(r)
     hmap = wang.height_map() if int(wang.user.surface_type) == 1 else None
     r.configure(hmap)
@@ -365,7 +372,7 @@ def main():
     # ... unless a slot's per-frame buffers are large: rotating three multi-GB buffer sets costs more than the third frame in
     # flight gains (c5, ~5.6 GB per slot: 554 frames/s with two in flight, 543 with three).  The library reuses the lowest free
     # slot, so keeping fewer frames in flight also keeps fewer buffer sets in rotation.
-    r.render_wait(r.render_async(cu0, su0, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, shard=shard))
+    r.render_wait(r.render_async(cu0, su0, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, order_mode=order_mode, shard=shard))
     per_slot_bytes = 60.0 * float(r.timings()["n_instanced"])           # rects + records per list entry, roughly
     # compositor work-item size: a segment of a tile's list cannot skip what the segments in front of it already saturated, so a dense
     # frame (many pairs per screen tile) wants long segments; a sparse one is indifferent up to ~2 k (gswt_api.hip, opt_segment)
@@ -452,7 +459,7 @@ def main():
             r.skybox_render(cu, W, H, bgp)
             r.proxy_render(pu, W, H, bgp, dpp, True)
         r.set_option(L.GSWT_OPT_TIMING, args.timing if timed else 0)      # per frame: the slot remembers its own level
-        ticket = r.render_async(cu, state["su"], W, H, o.data_ptr(), transmittance_eps=args.t_eps, shard=shard, bg_rgba_ptr=bgp, bg_depth_ptr=dpp)
+        ticket = r.render_async(cu, state["su"], W, H, o.data_ptr(), transmittance_eps=args.t_eps, order_mode=order_mode, shard=shard, bg_rgba_ptr=bgp, bg_depth_ptr=dpp)
         stats["submit_ms"].append(1e3 * (time.perf_counter() - t0))
         if trace is not None:
             trace.append(("submit", i, t0, time.perf_counter(), state["swaps"]))
@@ -575,11 +582,13 @@ def main():
     # when the last of the four frames in flight has left it (~0.9 ms of a 5.6 ms region).  `value` stays what the contract says --
     # exactly K steps inside the bracket -- and the same loop over two laps of the path is reported beside it.
     steady = None
+    steady_stats = None
     if args.mode == "flypath" and world == 1 and args.steps < 240 and worker is not None and not args.freeze_sort:
         n_long = 2 * len(cams)
         te_save, args.timing_every = args.timing_every, 3            # as the default run: every third frame carries timing events
         dt_long = timed_run(n_long, worker, 0)
         args.timing_every = te_save
+        steady_stats = {k: (list(v) if isinstance(v, list) else v) for k, v in stats.items()}
         steady = {"value": n_long / dt_long, "unit": "frames/s", "steps": n_long, "ms_per_step": 1e3 * dt_long / n_long, "sort_events_swapped_in": state["swaps"],
                   "note": f"the same fly-path loop timed over {n_long} frames right after the {args.steps}-step region: what `value` converges to when fill and drain of the four-frame pipeline stop mattering (the default `python bench.py` times 480 frames)"}
     worker_ms = None
@@ -605,7 +614,7 @@ def main():
     for i in range(6):
         if use_passes:
             r.skybox_render(cu_l, W, H, bgs[0].data_ptr()); r.proxy_render(pu, W, H, bgs[0].data_ptr(), depths[0].data_ptr(), True)
-        r.render_wait(r.render_async(cu_l, su_l, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, shard=shard,
+        r.render_wait(r.render_async(cu_l, su_l, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, order_mode=order_mode, shard=shard,
                                      bg_rgba_ptr=bgs[0].data_ptr() if use_passes else 0, bg_depth_ptr=depths[0].data_ptr() if use_passes else 0))
         iso.append(r.timings()["ms_composite_kernel"])
     iso_ms = float(np.median(iso[2:]))
@@ -613,7 +622,7 @@ def main():
     dist_check = None
     if use_dist:
         # the all-gathered frame against the same camera rendered unsharded on this rank, bit for bit
-        tk = r.render_async(cu_l, su_l, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, shard=shard,
+        tk = r.render_async(cu_l, su_l, W, H, outs[0].data_ptr(), transmittance_eps=args.t_eps, order_mode=order_mode, shard=shard,
                             bg_rgba_ptr=bgs[0].data_ptr() if use_passes else 0, bg_depth_ptr=depths[0].data_ptr() if use_passes else 0)
         if abi_comm:
             r.render_gather(tk, frame.data_ptr())
@@ -628,7 +637,7 @@ def main():
         r.render_wait(tk)
         stream.synchronize()
         full = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-        r.render_wait(r.render_async(cu_l, su_l, W, H, full.data_ptr(), transmittance_eps=args.t_eps, shard=(0, 1),
+        r.render_wait(r.render_async(cu_l, su_l, W, H, full.data_ptr(), transmittance_eps=args.t_eps, order_mode=order_mode, shard=(0, 1),
                                      bg_rgba_ptr=bgs[0].data_ptr() if use_passes else 0, bg_depth_ptr=depths[0].data_ptr() if use_passes else 0))
         torch.cuda.synchronize()
         x1 = min(W, band_w) if fake_world > 1 else W          # fake world: only this rank's band was "gathered"
@@ -656,6 +665,15 @@ def main():
     if rank == 0:
         st = main_stats
         fps = args.steps / dt
+        # k_composite's hipEvent samples: a short timed region (the driver's --steps 20) holds ~10 of them, two per frame slot -- not a
+        # measurement.  The steady-state loop right behind it runs the same frames with events on every third one (>= 150 samples):
+        # when the region has fewer than 64 samples the roofline figures are taken from that loop (and say so).
+        roof_src = "timed region"
+        if steady_stats is not None and len(st["comp_ms"]) < 64 and len(steady_stats["comp_ms"]) >= 64:
+            st = dict(st)
+            for k in ("comp_ms", "comp_slot", "pairs", "stage"):
+                st[k] = steady_stats[k]
+            roof_src = f"steady_state loop ({steady['steps']} frames right behind the {args.steps}-step region: the region itself holds {len(main_stats['comp_ms'])} event samples)"
         P = float(np.mean(st["pairs"]))
         # HIP events bracket k_composite on its frame slot's stream.  The runtime multiplexes the streams onto 4 hardware queues, so
         # a slot whose queue is shared with another slot also times that slot's kernels in front of its own.  Per-slot means are
@@ -680,7 +698,7 @@ def main():
         # (rocprofv3 --pmc, separate passes; profiles/): raw counter bytes.  MI355X_MICROARCH's x2 rule is for wide coalesced
         # streams; these reads are scattered record gathers (uncalibrated), so the raw sum is reported and the x2 figure kept beside it.
         traffic, traffic_note, valu = None, "no PMC summary for this workload under profiles/", None
-        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r03_pmc_{args.workload}.json"), os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json"), os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload}.json")) if os.path.exists(q)), None)
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r04_pmc_{args.workload}.json"), os.path.join(ROOT, "profiles", f"r03_pmc_{args.workload}.json"), os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json"), os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload}.json")) if os.path.exists(q)), None)
         if world == 1 and pmc_path:
             try:
                 pmc = json.load(open(pmc_path))
@@ -693,6 +711,7 @@ def main():
                     valu = {"valu_busy_pct": k.get("VALUBusy"), "wave_insts_valu": k["SQ_INSTS_VALU"], "wave_insts_salu": k.get("SQ_INSTS_SALU"), "wave_insts_lds": k.get("SQ_INSTS_LDS"),
                             "cycles_per_valu_inst_per_simd": cyc * 1024.0 / k["SQ_INSTS_VALU"],
                             "peak_cycles_per_valu_inst_per_simd": 2.0,
+                            "valu_issue_frac": 2.0 / (cyc * 1024.0 / k["SQ_INSTS_VALU"]),
                             "lds_bank_conflict_cycle_share": (k["SQ_LDS_BANK_CONFLICT"] / k["SQ_LDS_IDX_ACTIVE"]) if k.get("SQ_LDS_IDX_ACTIVE") else None,
                             "wave_cycles_waiting_share": (k["SQ_WAIT_ANY"] / k["SQ_WAVE_CYCLES"]) if k.get("SQ_WAVE_CYCLES") else None,
                             "source": f"profiles/{os.path.basename(pmc_path)} (committed rocprofv3 --pmc passes of the static-camera command: NOT measured in this run)",
@@ -712,9 +731,11 @@ def main():
                                   if args.mode == "flypath" else "static (the workload's own camera)"),
                        "map": [2 * w["half"][0] + 1, 2 * w["half"][1] + 1],
                        "width": W, "height": H, "n_draws": int(last["n_draws"]), "n_instanced": int(last["n_instanced"]),
-                       "n_visible": int(last["n_visible"]), "n_pairs_mean": int(P), "order": "reference",
+                       "n_visible": int(last["n_visible"]), "n_pairs_mean": int(P), "order": args.order,
+                       "vertex_stage": "strict (GSWT_OPT_STRICT_VS: gswt.wgsl:152-258 operator by operator)" if args.strict_vs else "canonical sequence v2",
                        "transmittance_eps": args.t_eps, "skybox_proxy_passes": bool(use_passes),
-                       "parallelism": f"screen-tile-column bands x{world} (projection culled per band) + RCCL all-gather" if world > 1 else "single GPU"},
+                       "parallelism": (f"screen-tile-column bands x{world} (projection culled per band) + RCCL all-gather; no hardware 1 -> N curve has been "
+                                       "measured by the builder (one-GPU boxes only): this line is the first" if world > 1 else "single GPU")},
             "frames_in_flight": slots,
             "segment": segment,
             "sort_events": {"swapped_in": swaps, "swap_in_ms_mean": float(np.mean(swap_ms)) if swap_ms else None,
@@ -729,7 +750,8 @@ def main():
             "steady_state": steady,
             "static_camera": static,
             "roofline": {"bound": "hbm", "kernel": "k_composite", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms_source": roof_src,
+                         "valu_issue_frac": valu["valu_issue_frac"] if valu else None,
                          "traffic_source": (f"profiles/{os.path.basename(pmc_path)} (committed PMC passes: NOT measured in this run)" if traffic is not None else None),
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_ms_min_slot": comp * 1e3, "kernel_ms": comp * 1e3, "kernel_ms_samples": len(by_slot.get(best_slot, st["comp_ms"])), "timed_every": max(1, args.timing_every),
@@ -766,25 +788,40 @@ def main():
             res["dist_check_max_abs_diff"] = dist_check
             res["collective"] = "gswt_render_gather (ncclAllGather behind the C ABI)" if abi_comm else "torch.distributed.all_gather_into_tensor + gswt_unshard_mode"
         if world == 1 and not args.no_cpu_baseline:
-            # the oracle renders the LAST fly-path camera from the product host's current draw list (one frame)
+            # The oracle (oracle/gswt_oracle.c, OpenMP) renders fly-path cameras from the product host's draw lists: the LAST camera first
+            # (its image is compared with the GPU's frame of the same draw list), then further cameras spread over the path until
+            # --cpu-baseline-seconds have gone (at most 24 frames): a bounded sample of the same workload, not one frame.
             wang.set_device_merge(False)
-            wang.build_tiles(pos_l) if wang.check_update(pos_l) else None
-            sort_l = wang.sort_tiles(pos_l, vp_l)
-            su_c = wang.scene_uniforms()
-            if use_passes:
-                pu.view[:] = cu_l.view[:]; pu.projection[:] = cu_l.projection[:]; pu.cam_pos[:] = cu_l.cam_pos[:]; pu.center_coord[:] = su_c.center_coord[:]
-            img_cpu, stc, cdt, nthr = cpu_baseline(wang, sort_l, cu_l, vp_l, su_c, W, H, passes=(faces, mips, pu) if use_passes else None, height_map=hmap)
-            # ... and the GPU renders exactly that draw list once more for the comparison
-            r.set_draws(sort_l.draws, sort_l.merged_gs_index, sort_l.merged_map_id, sort_l.merged_lod_id)
-            if use_passes:
-                r.skybox_render(cu_l, W, H, bgs[0].data_ptr()); r.proxy_render(pu, W, H, bgs[0].data_ptr(), depths[0].data_ptr(), True)
-            cmp_t = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
-            r.render_wait(r.render_async(cu_l, su_c, W, H, cmp_t.data_ptr(), transmittance_eps=args.t_eps,
-                                         bg_rgba_ptr=bgs[0].data_ptr() if use_passes else 0, bg_depth_ptr=depths[0].data_ptr() if use_passes else 0))
-            gpu_img = cmp_t.cpu().numpy()
-            res["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": nthr, "kind": "port",
-                                   "sample": "1 frame (the last fly-path camera) of the same workload: oracle/gswt_oracle.c, OpenMP over 16-row bands",
-                                   "max_abs_diff_vs_gpu": float(np.max(np.abs(gpu_img.astype(np.float64) - img_cpu.astype(np.float64))))}
+            cam_ids = [last_i] + [int(k * len(cams) / 23.0) % len(cams) for k in range(23)] if len(cams) > 1 else [last_i]
+            times, cmp_diff, nthr = [], None, None
+            t_budget = time.perf_counter() + max(0.0, args.cpu_baseline_seconds)
+            for n_done, ci in enumerate(cam_ids):
+                if n_done > 0 and time.perf_counter() >= t_budget:
+                    break
+                pos_c, cu_c, vp_c = cams[ci]
+                if wang.check_update(pos_c):
+                    wang.build_tiles(pos_c)
+                sort_c = wang.sort_tiles(pos_c, vp_c)
+                su_c = wang.scene_uniforms()
+                if use_passes:
+                    pu.view[:] = cu_c.view[:]; pu.projection[:] = cu_c.projection[:]; pu.cam_pos[:] = cu_c.cam_pos[:]; pu.center_coord[:] = su_c.center_coord[:]
+                img_cpu, stc, cdt, nthr = cpu_baseline(wang, sort_c, cu_c, vp_c, su_c, W, H, passes=(faces, mips, pu) if use_passes else None, height_map=hmap,
+                                                       order_mode=1 if args.order == "depth" else 0)
+                times.append(cdt)
+                if n_done == 0:
+                    # ... and the GPU renders exactly that draw list once more for the comparison
+                    r.set_draws(sort_c.draws, sort_c.merged_gs_index, sort_c.merged_map_id, sort_c.merged_lod_id)
+                    if use_passes:
+                        r.skybox_render(cu_c, W, H, bgs[0].data_ptr()); r.proxy_render(pu, W, H, bgs[0].data_ptr(), depths[0].data_ptr(), True)
+                    cmp_t = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+                    r.render_wait(r.render_async(cu_c, su_c, W, H, cmp_t.data_ptr(), transmittance_eps=args.t_eps, order_mode=order_mode,
+                                                 bg_rgba_ptr=bgs[0].data_ptr() if use_passes else 0, bg_depth_ptr=depths[0].data_ptr() if use_passes else 0))
+                    cmp_diff = float(np.max(np.abs(cmp_t.cpu().numpy().astype(np.float64) - img_cpu.astype(np.float64))))
+            res["cpu_baseline"] = {"value": len(times) / float(np.sum(times)), "unit": "frames/s", "cores": nthr, "kind": "port",
+                                   "sample": f"{len(times)} frames of the same workload (fly-path cameras spread over the path, {float(np.sum(times)):.1f} s of oracle time; "
+                                             f"order = {args.order}): oracle/gswt_oracle.c, OpenMP over 16-row bands; the reference itself (Rust + wgpu) cannot run here",
+                                   "frames_per_s_min_max": [1.0 / max(times), 1.0 / min(times)],
+                                   "max_abs_diff_vs_gpu": cmp_diff}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(res) + "\n").encode())
     if abi_comm:

@@ -29,24 +29,24 @@
 
 namespace gswt {
 void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t,
-                 uint32_t*, uint4*);
+                 uint32_t*, uint4*, uint32_t*, uint32_t);
 void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const MergeSources&, uint32_t*, uint32_t*);
 void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
 size_t radix_ws_zero_words(uint32_t, int);
-void launch_emit_depth(hipStream_t, const Frame&, uint32_t, const unsigned long long*, const uint2*, const float*, const uint32_t*,
+void launch_emit_depth(hipStream_t, const Frame&, uint32_t, uint32_t, const uint2*, const float*, const uint32_t*, const uint32_t*, const uint32_t*,
                        uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                        unsigned long long*, uint32_t*, uint32_t*);
-void launch_scan(hipStream_t, const uint32_t*, uint32_t*, size_t, uint32_t*, uint32_t*);
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, uint32_t, const uint32_t*, const uint32_t*,
                     const uint32_t*, const uint4*, const float*, const uint32_t*, const uint32_t*, uint32_t*, const uint4*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
-                    unsigned long long*, Varyings*, float4*, uint32_t);
+                    unsigned long long*, Varyings*, float4*, uint32_t, uint32_t*, uint32_t, bool);
 void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
                  uint32_t*, uint32_t*);
-int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr);
+int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr,
+                const uint32_t* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, const unsigned long long*, unsigned long long*);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
@@ -242,7 +242,9 @@ struct FrameSlot {
     DevBuf<uint2> ranges;
     DevBuf<uint32_t> item_base;
     DevBuf<uint4> item_tab;
-    DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x n_slots key/val ping-pong + per-block counts
+    DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x emit_cap key / slot ping-pong + per-block pair counts + per-chunk emitting-slot counts
+    uint32_t emit_cap = 0;                 // ... and the capacity (emitting slots) that frame was launched for
+    bool strict_vs = false;                // GSWT_OPT_STRICT_VS as it stood when the frame was submitted (a re-run keeps it)
     DevBuf<float4> partials;
     DevBuf<float4> col_f;                  // debug draw modes: float colours per slot
     DevBuf<float> depths;                  // per-slot depth: frames with a proxy depth buffer or GSWT_ORDER_DEPTH only
@@ -250,8 +252,8 @@ struct FrameSlot {
     GraphRec grec;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    hipGraphNode_t graph_nodes[24] = {};
-    GraphNodeRec graph_last[24];
+    hipGraphNode_t graph_nodes[kGraphMaxNodes] = {};
+    GraphNodeRec graph_last[kGraphMaxNodes];
     uint32_t graph_n = 0;
     void release_graph()
     {
@@ -303,6 +305,7 @@ struct gswt_ctx {
     std::vector<hipStream_t> pad_streams;  // never used: they steer the hardware-queue assignment (gswt_create)
     int opt_defer_swap = 0;
     int opt_graph = 0;
+    int opt_strict_vs = 0;                 // GSWT_OPT_STRICT_VS: k_project evaluates vs_main operator by operator (gswt.wgsl:152-258)
     unsigned long long stat_graph_launches = 0, stat_graph_rebuilds = 0, stat_graph_node_updates = 0;
     int pending_frames = 0;                // GSWT_OPT_DEFER_SWAP >= 2: frames still to be submitted on the old set
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
@@ -317,6 +320,7 @@ struct gswt_ctx {
     bool draws_ready = false;
     // frame (the per-frame buffers live in the slots)
     uint32_t pair_cap = 0;                 // capacity the pair buffers / grids are sized for (grows on overflow)
+    uint32_t emit_cap = 0;                 // GSWT_ORDER_DEPTH: capacity of the depth sort in emitting slots (<= visible splats; grows like pair_cap)
     int last_slot = 0;
     DevBuf<float4> bg_rgba, out_img;
     DevBuf<float> bg_depth;
@@ -472,8 +476,19 @@ static hipError_t collect_pending(gswt_ctx* c)
     return sync_all(c);
 }
 
+// The merged lists the draw sets retain as copy sources belong to ONE scene and ONE set of raw depths: a re-uploaded scene of the same
+// shape (same counts, other depths or gs_index values) would otherwise match the old lists by (view, member tile ids, length) from the
+// second sort event on and copy the old scene's order.
+static void invalidate_merge_sources(gswt_ctx* c)
+{
+    for (auto& ds : c->sets) { ds.g_valid = false; ds.g_desc.clear(); ds.g_members.clear(); ds.src_mask = 0; }
+}
+
 // Frames still in flight on draw set `set` are run to completion before that set is refilled.
-static void collect_set(gswt_ctx* c, int set)
+// host_upload: the refill writes the set's merged arrays with copies that are NOT ordered on the build stream (gswt_set_draws with host
+// lists), so a device-side build of another set that is still copying from them has to be waited for; a refill on the build stream
+// (gswt_set_draws_merge_groups) is ordered behind such a copy anyway.
+static void collect_set(gswt_ctx* c, int set, bool host_upload)
 {
     for (auto& sl : c->slots)
         if (sl.pending && !sl.collected && sl.set == set) {
@@ -484,6 +499,7 @@ static void collect_set(gswt_ctx* c, int set)
     // ... and no device-side list build still in flight may be COPYING from this set's merged arrays (the lists of the last sort events
     // stay addressable as copy sources): everything that refills the set on the build stream is ordered behind such a copy anyway, a
     // host-side upload (gswt_set_draws with host lists) is not
+    if (!host_upload) return;
     for (int k = 0; k < kDrawSets; k++) {
         DrawSet& o = c->sets[k];
         if (k != set && o.ev_up_pending && ((o.src_mask >> set) & 1u)) { (void)hipEventSynchronize(o.ev_up); o.ev_up_pending = false; }
@@ -593,11 +609,21 @@ try {
     switch (key) {
     case GSWT_OPT_NO_LOD_PREFILTER: c->opt_no_prefilter = value; c->draws_ready = false; return GSWT_OK;
     case GSWT_OPT_DEBUG_VARYINGS: c->opt_debug_varyings = value; return GSWT_OK;
-    case GSWT_OPT_DEBUG_FLAGS: c->opt_dbg_flags = value; return GSWT_OK;
+    case GSWT_OPT_DEBUG_FLAGS:
+#ifndef GSWT_EXPERIMENTS
+        // the ablation branches (wrong images by design) exist only in the measurement build: the product cannot be switched into them
+        if (value != 0) return fail(c, GSWT_ERR_BAD_ARG, "GSWT_OPT_DEBUG_FLAGS: this library was built without -DGSWT_EXPERIMENTS (make variants)");
+#endif
+        c->opt_dbg_flags = value; return GSWT_OK;
     case GSWT_OPT_TIMING: c->opt_timing = value; return GSWT_OK;
     case GSWT_OPT_NO_MERGE_REUSE: c->opt_no_merge_reuse = value; return GSWT_OK;
     case GSWT_OPT_DEFER_SWAP: c->opt_defer_swap = value; return GSWT_OK;
     case GSWT_OPT_GRAPH: c->opt_graph = value; return GSWT_OK;
+    case GSWT_OPT_STRICT_VS: c->opt_strict_vs = value != 0; return GSWT_OK;
+    case GSWT_OPT_EMIT_CAP:
+        if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "depth-sort capacity must be >= 0");
+        c->emit_cap = (uint32_t)value;              // 0: sized from the next draw list
+        return GSWT_OK;
     case GSWT_OPT_PAIR_CAP:
         if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "pair capacity must be >= 0");
         c->opt_fixed_pair_cap = value > 0; if (value > 0) c->pair_cap = (uint32_t)value;
@@ -620,6 +646,7 @@ try {
     hipSetDevice(c->device);
     HIP_TRY(c, collect_pending(c));
     c->scene_ready = false; c->draws_ready = false;
+    invalidate_merge_sources(c);
     HIP_TRY(c, c->tex.ensure(2 * n_splats));
     HIP_TRY(c, hipMemcpy(c->tex.p, tex_data, n_splats * 32, hipMemcpyHostToDevice));
     c->n_splats = n_splats;
@@ -757,7 +784,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     // does not drain the frame pipeline.  The upload is asynchronous on the ctx stream from the set's pinned staging; every
     // frame submitted afterwards starts behind an event recorded on that stream (enqueue_frame).
     const int target = device_merge ? c->merge_target : next_target(c);
-    collect_set(c, target);
+    collect_set(c, target, !device_merge);
     DrawSet& D = c->sets[target];
     // the set's pinned staging is free again once its previous upload has been consumed
     if (D.ev_up_pending) { HIP_TRY(c, hipEventSynchronize(D.ev_up)); D.ev_up_pending = false; }
@@ -902,6 +929,7 @@ try {
     if (!c->scene_ready) return fail(c, GSWT_ERR_STATE, "gswt_upload_raw_depth before gswt_upload_scene");
     hipSetDevice(c->device);
     HIP_TRY(c, sync_all(c));
+    invalidate_merge_sources(c);
     const size_t nlt = (size_t)c->n_lod * c->n_tile, nv = (size_t)c->n_view;
     c->raw_cnt.assign(counts, counts + nlt);
     c->raw_merge_offset.assign(merge_offset, merge_offset + nlt);
@@ -935,7 +963,7 @@ try {
     hipSetDevice(c->device);
     const int target = next_target(c);
     c->merge_target = target;
-    collect_set(c, target);
+    collect_set(c, target, false);
     DrawSet& D = c->sets[target];
     // every other set that still holds the group lists of an earlier sort event, newest first (the sets are refilled round robin)
     std::vector<int> sources;
@@ -1058,7 +1086,7 @@ try {
     for (size_t q = 0; q < n_jobs; q++) D.src_mask |= 1u << jobs[q].src_set;
     D.g_desc.swap(desc);
     D.g_members.assign(members, members + n_members);
-    D.g_valid = true;
+    D.g_valid = false;                 // (a copy source only once everything below has been enqueued: a failed HIP call leaves unbuilt lists)
     c->stat_groups_built += n_build; c->stat_groups_reused += n_jobs;
     hipStream_t s = c->set_stream;
     // block tables: every copy job / segment cut into runs of <= 1024 entries (what one workgroup handles)
@@ -1095,6 +1123,7 @@ try {
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(D.ev_up, s));
     D.ev_up_pending = true; D.built = false;
+    D.g_valid = true;
     publish_set(c, target);
     c->draws_ready = true;
     return GSWT_OK;
@@ -1227,7 +1256,9 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         const size_t n_slots_all = (size_t)D.n_chunks * kChunk;
         HIP_TRY(c, sl.rects.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
-        HIP_TRY(c, sl.block_sums.ensure_roomy((size_t)D.n_chunks + 1));
+        // (GSWT_ORDER_DEPTH: the per-chunk counts of emitting slots lie right behind the per-chunk pair counts, so that k_cull clears both
+        // with one range -- chunks of culled draws never run and must read as zero)
+        HIP_TRY(c, sl.block_sums.ensure_roomy(((size_t)D.n_chunks + 1) * (cfg->order_mode == GSWT_ORDER_DEPTH ? 2 : 1)));
         HIP_TRY(c, sl.live_tab.ensure_roomy((size_t)D.n_launch + 8));
         // (cleared ON THE SLOT'S STREAM: the slot streams are non-blocking, so a null-stream hipMemset -- asynchronous to the host for
         // device memory -- could land after this frame's k_cull had filled the counts: the slot's FIRST frame then projected nothing
@@ -1293,7 +1324,11 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         const float yr = (2.0f * (float)su->map_half_wh[1] + 1.0f) * su->tile_width * su->height_map_scale[1];
         const float sx = c->hm_du * std::fabs(hz) / std::fabs(xr), sy = c->hm_dv * std::fabs(hz) / std::fabs(yr);
         f.surf_f2 = (3.0f + sx * sx + sy * sy) * 1.01f;
-        if (!(f.surf_f2 == f.surf_f2) || !(f.surf_zlo == f.surf_zlo) || !(f.surf_zhi == f.surf_zhi)) f.band_cull = 0;
+        // a non-finite height map (gswt_configure leaves +-3e38 bounds), an infinite or NaN range or slope bound: no band culling at all
+        // (fminf / fmaxf drop NaN operands, so a box with NaN corners used to read as "misses the band")
+        const float fmax_ = 3.0e38f;
+        if (!(f.surf_f2 == f.surf_f2) || !(f.surf_zlo == f.surf_zlo) || !(f.surf_zhi == f.surf_zhi) || !(std::fabs(f.surf_f2) < fmax_) ||
+            !(std::fabs(f.surf_zlo) < fmax_) || !(std::fabs(f.surf_zhi) < fmax_) || !(c->hm_du < fmax_) || !(c->hm_dv < fmax_)) f.band_cull = 0;
     }
     if (su->surface_type == 2u) {
         const float block_w = ((float)su->map_half_wh[0] * 2.0f) * su->tile_width / 5.0f;
@@ -1303,7 +1338,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     }
     f.hm_w = c->hm_w; f.hm_h = c->hm_h;
     f.map_wh_y = 2u * su->map_half_wh[1] + (su->surface_type != 2u ? 1u : 0u);
-    f.map_wh_y_magic = f.map_wh_y ? 0xFFFFFFFFu / f.map_wh_y + 1u : 0u;
+    // (0 = "divide": a one-row map, map_wh_y == 1, would wrap the magic to 0 and the multiply-high quotient to 0 -- ADVICE r3)
+    f.map_wh_y_magic = f.map_wh_y >= 2u && f.map_wh_y < 65536u ? 0xFFFFFFFFu / f.map_wh_y + 1u : 0u;
     f.tiles_x_magic = f.tiles_x > 0 && f.tiles_x < 65536 ? 0xFFFFFFFFu / (uint32_t)f.tiles_x + 1u : 0u;
     f.dbg_flags = c->opt_dbg_flags;
 
@@ -1330,21 +1366,29 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     sl.cap = cap;
     HIP_TRY(c, sl.keys_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.keys_b.ensure_roomy((size_t)cap + 1));
     HIP_TRY(c, sl.vals_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure_roomy((size_t)cap + 1));
-    const size_t n_super2 = 3 * ((size_t)D.n_chunks / 256 + 1);     // pair sums, visible sums, exclusive pair prefix (k_totals)
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
+    const size_t n_super = (size_t)D.n_chunks / 256 + 1;
+    // pair sums, visible sums, exclusive pair prefix (k_totals); depth order: + emitting-slot sums and their exclusive prefix
+    const size_t n_super2 = (depth_order ? 5 : 3) * n_super;
     const uint32_t n_slots = D.n_chunks * (uint32_t)kChunk;
-    const size_t depth_radix_words = depth_order ? radix_ws_words(n_slots, 32) : 0;
-    const size_t radix_words = radix_ws_words(cap, key_bits) + depth_radix_words;
-    if (depth_order) {
-        HIP_TRY(c, sl.depth_ws.ensure(4 * (size_t)n_slots + (size_t)D.n_chunks + 16));
-        HIP_TRY(c, sl.scan_ws.ensure((size_t)D.n_chunks / 1024 + 4096));
-    }
-    // one contiguous u32 region cleared by k_cull: [counters: 16][super_sums: n_super2][radix histograms]
-    HIP_TRY(c, sl.ghist.ensure_roomy(16 + n_super2 + radix_words + 16));
+    // GSWT_ORDER_DEPTH sorts the slots that emit pairs (<= the visible splats), for a capacity that follows the running count like
+    // the pair capacity does; a frame that outgrows it is flagged by k_totals and re-run by finish_frame
+    if (depth_order && c->emit_cap == 0) c->emit_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(D.n_entries / 4, 1u << 18), n_slots);
+    const uint32_t ecap = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->emit_cap, 256u), std::max<uint32_t>(n_slots, 256u)) : 0u;
+    sl.emit_cap = ecap;
+    const size_t n_psuper = depth_order ? (size_t)ecap / 65536 + 2 : 0;     // sums of 256 blocks of 256 positions of the depth-ordered list
+    // radix workspaces: the zeroed parts of BOTH sorts first (group rows, digit totals), the per-workgroup rows (written in full) behind
+    const size_t rz_pair = radix_ws_zero_words(cap, key_bits), rz_depth = depth_order ? radix_ws_zero_words(ecap, 32) : 0;
+    const size_t rw_pair = radix_ws_words(cap, key_bits), rw_depth = depth_order ? radix_ws_words(ecap, 32) : 0;
+    if (depth_order) HIP_TRY(c, sl.depth_ws.ensure_roomy(4 * (size_t)ecap + ((size_t)ecap / 256 + 2) + 64));
+    // one contiguous u32 region whose head k_cull clears: [counters: 16][super_sums: n_super2][psuper][pair sort: zeroed part .. rows][depth sort likewise]
+    HIP_TRY(c, sl.ghist.ensure_roomy(16 + n_super2 + n_psuper + rw_pair + rw_depth + 16));
     uint32_t* const zero_a = sl.ghist.p;
     unsigned long long* const d_counters = reinterpret_cast<unsigned long long*>(zero_a);
     uint32_t* const d_super = zero_a + 16;
-    uint32_t* const d_radix = d_super + n_super2;
+    uint32_t* const d_psuper = d_super + n_super2;
+    uint32_t* const d_radix = d_psuper + n_psuper;
+    uint32_t* const d_radix_depth = d_radix + rw_pair;
     const uint32_t seg = (uint32_t)c->opt_segment;
     HIP_TRY(c, sl.item_base.ensure_roomy((size_t)n_tiles + 2));
     HIP_TRY(c, sl.partials.ensure_roomy(((size_t)n_tiles + cap / seg + 1) * 256));
@@ -1367,8 +1411,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     }
     if (sc > 1 && out_px > 0) HIP_TRY(c, hipMemsetAsync(d_out, 0, out_px * 16, s));
     // GSWT_OPT_GRAPH: from here to the end of the frame the launch sites record instead of launching (frames that carry timing
-    // events, the depth-ordered path with its host-to-device word, debug varyings and shards without tiles launch as before)
-    const bool use_graph = c->opt_graph != 0 && c->opt_timing == 0 && !depth_order && !dbg && n_tiles > 0 && sl.hc_dev != nullptr;
+    // events, debug varyings and shards without tiles launch as before)
+    const bool use_graph = c->opt_graph != 0 && c->opt_timing == 0 && !dbg && n_tiles > 0 && sl.hc_dev != nullptr;
     struct RecorderScope {
         explicit RecorderScope(GraphRec* r) { if (r) { r->n = 0; r->overflow = false; } graph_recorder() = r; }
         ~RecorderScope() { graph_recorder() = nullptr; }
@@ -1376,25 +1420,28 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[0], s));
     const uint32_t n_cells = f.band_cull ? (2u * su->map_half_wh[0] + 1u) * (2u * su->map_half_wh[1] + 1u) : 0u;
     HIP_TRY(c, sl.cell_culled.ensure((size_t)n_cells + 1));
-    // cleared per frame: counters, super-group sums and the atomically accumulated part of the sort's tables (depth order: both sorts' tables whole)
-    const size_t n_zero_a = 16 + n_super2 + (depth_order ? radix_words : radix_ws_zero_words(cap, key_bits));
+    // cleared per frame: counters, super-group sums and the atomically accumulated part of the sort's tables.  The pair sort's zeroed
+    // part is contiguous with the head; the depth sort's (behind the pair sort's rows) is the kernel's second clear range.
+    const size_t n_zero_a = 16 + n_super2 + n_psuper + rz_pair;
+    uint32_t* const dw = sl.depth_ws.p;
+    uint32_t* const d_block_cnt = depth_order ? dw + 4 * (size_t)ecap : nullptr;
+    uint32_t* const d_block_emit = depth_order ? sl.block_sums.p + D.n_chunks : nullptr;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
-                reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p);
+                reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks * (depth_order ? 2u : 1u), sl.live_cnt.p, sl.live_tab.p,
+                d_radix_depth, (uint32_t)rz_depth);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
-                   d_counters, c->dbg.p, sl.col_f.p, cap);
+                   d_counters, c->dbg.p, sl.col_f.p, cap, d_block_emit, ecap, sl.strict_vs);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
     // ---- emit
     if (!depth_order) {
         launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     } else {
-        // d_counters[4] = n_slots (the radix kernels read their item count from device memory)
-        sl.hc[7] = n_slots;
-        HIP_TRY(c, hipMemcpyAsync(d_counters + 4, &sl.hc[7], 8, hipMemcpyHostToDevice, s));
-        uint32_t* dw = sl.depth_ws.p;
-        launch_emit_depth(s, f, n_slots, d_counters + 4, sl.rects.p, sl.depths.p, sl.block_sums.p, dw, dw + n_slots, dw + 2 * (size_t)n_slots,
-                          dw + 3 * (size_t)n_slots, d_radix + radix_ws_words(cap, key_bits), dw + 4 * (size_t)n_slots, sl.scan_ws.p,
-                          reinterpret_cast<uint32_t*>(d_counters + 2), cap, d_counters, sl.keys_a.p, sl.vals_a.p);
+        // counters[4] = emitting slots (k_totals; the depth sort reads its item count there, counters[6] = its overflow word stays 0),
+        // counters[5] = the key range (two u32 words, k_depth_keys)
+        launch_emit_depth(s, f, D.n_chunks, ecap, sl.rects.p, sl.depths.p, sl.block_sums.p, d_block_emit, d_super + 4 * n_super,
+                          dw, dw + ecap, dw + 2 * (size_t)ecap, dw + 3 * (size_t)ecap, d_radix_depth, reinterpret_cast<uint32_t*>(d_counters + 5),
+                          d_block_cnt, d_psuper, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     }
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
     // ---- stable sort on the tile bits
@@ -1434,13 +1481,19 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
         if (P64 >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: %llu pairs exceed 2^32", P64);
         if (sl.hc[3] == 0 && P64 <= sl.cap) break;
         if (attempt >= 2) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");
-        c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 2 + 4096, 0xFFFFFF00ull));
+        if (P64 > sl.cap || sl.args.cfg.order_mode != GSWT_ORDER_DEPTH)
+            c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 2 + 4096, 0xFFFFFF00ull));
+        // depth order: the emitting slots are at most the visible splats, which the frame counted whatever overflowed
+        if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH)
+            c->emit_cap = std::max<uint32_t>(c->emit_cap, (uint32_t)std::min<uint64_t>(sl.hc[0] + sl.hc[0] / 2 + 4096, 0xFFFFFF00ull));
         int rc = enqueue_frame(c, sl);
         if (rc != GSWT_OK) return rc;
     }
     const uint32_t P = (uint32_t)sl.hc[1];
     // keep 25-50 % headroom over the running pair count without shrinking on every small dip
     if (!c->opt_fixed_pair_cap && (uint64_t)P + P / 4 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 2 + 4096, 0xFFFFFF00ull);
+    if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH && sl.hc[0] + sl.hc[0] / 4 > c->emit_cap)
+        c->emit_cap = (uint32_t)std::min<uint64_t>(sl.hc[0] + sl.hc[0] / 2 + 4096, 0xFFFFFF00ull);
     gswt_timings& t = c->timings;
     memset(&t, 0, sizeof(t));
     hipEvent_t* ev = sl.ev;
@@ -1498,6 +1551,7 @@ try {
     activate_pending(c, false);
     sl.set = c->cur_set;
     fill_args(sl.args, cam, su, cfg, width, height, d_bg, d_bgd, d_out);
+    sl.strict_vs = c->opt_strict_vs != 0;
     rc = enqueue_frame(c, sl);
     if (rc != GSWT_OK) return rc;
     rc = finish_frame(c, sl);
@@ -1534,6 +1588,7 @@ try {
     sl.seq = ++c->frame_seq;
     activate_pending(c, false);
     sl.set = c->cur_set;
+    sl.strict_vs = c->opt_strict_vs != 0;
     fill_args(sl.args, cam, su, cfg, width, height, reinterpret_cast<const float4*>(bg_rgba_dev), bg_depth_dev,
               reinterpret_cast<float4*>(out_rgba_dev));
     rc = enqueue_frame(c, sl);

@@ -173,8 +173,9 @@ struct GraphNodeRec {
                n_bytes == o.n_bytes && memcmp(args, o.args, n_bytes) == 0;
     }
 };
+constexpr uint32_t kGraphMaxNodes = 32;          // reference order: 10-12 kernels per frame; GSWT_ORDER_DEPTH: 19-23
 struct GraphRec {
-    GraphNodeRec nodes[24];
+    GraphNodeRec nodes[kGraphMaxNodes];
     uint32_t n = 0;
     bool overflow = false;
 };
@@ -185,7 +186,7 @@ template <typename... KA, typename... A>
 inline void graph_record(GraphRec* rec, void (*k)(KA...), dim3 g, dim3 b, A&&... a)
 {
     static_assert(sizeof...(KA) == sizeof...(A), "kernel argument count");
-    if (rec->n >= 24u) { rec->overflow = true; return; }
+    if (rec->n >= kGraphMaxNodes) { rec->overflow = true; return; }
     GraphNodeRec& nd = rec->nodes[rec->n++];
     nd.fn = reinterpret_cast<const void*>(k);
     nd.grid = g; nd.block = b; nd.n_args = 0; nd.n_bytes = 0;

@@ -298,6 +298,7 @@ __device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], c
         for (int k = 0; k < 3; k++) { blo[k] = slo[k]; bhi[k] = shi[k]; }
     }
     float xmin = 3.402823466e+38f, xmax = -3.402823466e+38f, wmin = 3.402823466e+38f;
+    bool odd = false;                 // a NaN anywhere: keep (fminf / fmaxf drop NaN operands, so the extremes alone would not show it)
     for (int k = 0; k < 8; k++) {
         const float px = (k & 1) ? bhi[0] : blo[0];
         const float py = (k & 2) ? bhi[1] : blo[1];
@@ -306,9 +307,10 @@ __device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], c
         const float cw = ((f.VP[3] * px + f.VP[7] * py) + f.VP[11] * pz) + f.VP[15];
         wmin = fminf(wmin, cw);
         const float xp = (0.5f * (cx / cw) + 0.5f) * f.W;
+        odd = odd || !(cw == cw) || !(xp == xp);
         xmin = fminf(xmin, xp); xmax = fmaxf(xmax, xp);
     }
-    if (!(wmin > 1e-6f && xmin == xmin && xmax == xmax)) return false;
+    if (odd || !(wmin > 1e-6f && xmin == xmin && xmax == xmax)) return false;
     const float smax = fmaxf(fabsf(f.scene_scale[0]), fmaxf(fabsf(f.scene_scale[1]), fabsf(f.scene_scale[2])));
     const float hx = 1.3f * f.htan[0], hy = 1.3f * f.htan[1];
     const float jn2 = (f.focal[0] * f.focal[0] * (1.0f + hx * hx) + f.focal[1] * f.focal[1] * (1.0f + hy * hy)) / (wmin * wmin);
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
                                               uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
                                               uint32_t* __restrict__ zero_b, uint32_t n_zero_b,
                                               uint32_t* __restrict__ zero_c, uint32_t n_zero_c,
-                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab)
+                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab,
+                                              uint32_t* __restrict__ zero_d, uint32_t n_zero_d)
 {
     // eight lanes per draw: all of them evaluate the (cheap) cull, lane 0 of the eight keeps the flag and allocates the draw's range
     // of the live-chunk table, and the eight fill it together (a merged group has up to a few hundred chunks)
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
     for (uint32_t j = gtid; j < n_zero_a; j += gridDim.x * 256u) zero_a[j] = 0u;
     for (uint32_t j = gtid; j < n_zero_b; j += gridDim.x * 256u) zero_b[j] = 0u;
     for (uint32_t j = gtid; j < n_zero_c; j += gridDim.x * 256u) zero_c[j] = 0u;       // per-chunk pair counts: culled chunks never run
+    for (uint32_t j = gtid; j < n_zero_d; j += gridDim.x * 256u) zero_d[j] = 0u;       // GSWT_ORDER_DEPTH: group rows / digit totals of the depth sort
     if (f.band_cull) {
         const uint32_t map_wh_y = f.map_wh_y;                                // 2 h + 1; 2 h on the Sphere (gswt.wgsl:52-63, 606-610)
         for (uint32_t j = gtid; j < n_cells; j += gridDim.x * 256u) {
@@ -455,6 +459,13 @@ __device__ unsigned long long g_trace[kTraceItems * 8];
 // [7] hardware id (HW_ID | XCC_ID << 32) | chunk has pairs << 63
 // The quotients and roots of the projection are IEEE operations (correctly rounded: what the CPU checker reproduces).  -DGSWT_AB_FASTMATH
 // (measurement only, WRONG bits) swaps them for the 1-ulp hardware approximations: the upper bound of what a cheaper exact sequence could gain.
+// Ablation bits of GSWT_OPT_DEBUG_FLAGS (profiling: they cut a kernel short and the image is WRONG): compiled only into the measurement
+// build (-DGSWT_EXPERIMENTS, `make variants`); the product library has no such branches and refuses a nonzero flag word.
+#ifdef GSWT_EXPERIMENTS
+#define GSWT_ABL(F, BITS) (((F).dbg_flags & (BITS)) != 0)
+#else
+#define GSWT_ABL(F, BITS) false
+#endif
 #ifdef GSWT_AB_FASTMATH
 #define GSWT_RCP(X) __builtin_amdgcn_rcpf(X)
 #define GSWT_SQRT(X) __builtin_amdgcn_sqrtf(X)
@@ -462,7 +473,13 @@ __device__ unsigned long long g_trace[kTraceItems * 8];
 #define GSWT_RCP(X) (1.0f / (X))
 #define GSWT_SQRT(X) sqrtf(X)
 #endif
-template <bool DEBUG, bool FULL>
+// STRICT (GSWT_OPT_STRICT_VS): A6..A10 as the shader text writes them (gswt.wgsl:152-258, 260-265, 402-419) -- every `*`, `+`, `-`, `/` its own
+// correctly rounded binary32 operation, matrix x vector as the left-to-right sum of column products, the full `scene_scale_mat * Vrk *
+// transpose(..)` and `transpose(T) * Vrk * T` matrix products, length = sqrt(x*x + y*y), normalize = v / length(v), no fused multiply-add:
+// the same operations, in the same order, as the CPU checker's strict mode, per splat bit for bit.  The default (sequence v2, DESIGN.md
+// section 4) evaluates the same expressions with fma chains and one reciprocal per quotient -- also legal WGSL, ~25 % fewer instructions,
+// and up to 5e-4 away from this one on thin ellipses (lambda2 = mid - radius cancels).
+template <bool DEBUG, bool FULL, bool STRICT>
 __global__ __launch_bounds__(256) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
@@ -470,9 +487,9 @@ __global__ __launch_bounds__(256) void k_project(
     const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, const uint32_t* __restrict__ cell_culled,
     const uint32_t* __restrict__ live_cnt, const uint4* __restrict__ live_tab, uint2* __restrict__ rects,
     Rec* __restrict__ recs, float* __restrict__ depths, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
-    Varyings* __restrict__ dbg, float4* __restrict__ col_f)
+    Varyings* __restrict__ dbg, float4* __restrict__ col_f, uint32_t* __restrict__ block_emit)
 {
-    __shared__ uint32_t s_wsum[4], s_wvis[4];
+    __shared__ uint32_t s_wsum[4], s_wvis[4], s_wemit[4];
     // chunk_tab is in LAUNCH order, which is not slot order: workgroup b runs on XCD b % 8, and the table is laid out so
     // that all chunks of a draw land on one XCD (draw % 8) -- a draw's gathers stay inside one tile type's 313 KB of the
     // record table, so an XCD's 4 MB L2 then holds the few tile types it is working on instead of all 48 (6.6 MB).
@@ -493,7 +510,7 @@ __global__ __launch_bounds__(256) void k_project(
         const uint4 lt = live_tab[blockIdx.x];
         ct = make_uint2(lt.x, lt.y);
         list_top = lt.z; list_cnt = lt.w;
-        if (f.dbg_flags & 256) return;      // ablation: nothing behind the launch-table entry
+        if (GSWT_ABL(f, 256)) return;      // ablation: nothing behind the launch-table entry
 #ifdef GSWT_TRACE
         { unsigned long long sink = lt.x + lt.w; asm volatile("" :: "s"(sink)); }
         GSWT_TR(1, GSWT_NOW())
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(256) void k_project(
             if (f.band_cull && d.single_draw == 1u && cell_culled[map_id_m] != 0u) break;
             // A1 gswt.wgsl:38-42
             if (d.valid_lod_id >= 0 && d.valid_lod_id != (int32_t)lod_id) break;
-            if (f.dbg_flags & 128) break;       // ablation: stop behind the list word, in front of the record gather
+            if (GSWT_ABL(f, 128)) break;       // ablation: stop behind the list word, in front of the record gather
             // A2 :45-49
             const uint4 w0 = tex[2 * (size_t)gs_index];
             const uint4 w1 = tex[2 * (size_t)gs_index + 1];
@@ -550,7 +567,7 @@ __global__ __launch_bounds__(256) void k_project(
                 // map_id / map_wh_y with a uniform divisor: for operands below 2^16 the quotient is the high word of map_id * (floor(2^32 / d) + 1)
                 // (three instructions instead of the ~40 of a 32-bit division); larger maps take the division
                 uint32_t mq, mr;
-                if (map_wh_y < 65536u && map_id < 65536u) {
+                if (f.map_wh_y_magic != 0u && map_id < 65536u) {
                     mq = __umulhi(map_id, f.map_wh_y_magic);
                     mr = map_id - mq * map_wh_y;
                 } else { mq = map_id / map_wh_y; mr = map_id % map_wh_y; }
@@ -651,101 +668,202 @@ __global__ __launch_bounds__(256) void k_project(
                 t_ratio = clampf((cam_dist - td) / thw + 0.5f, 0.0f, 1.0f);
                 if ((lod_id == higher_lod + 1u && t_ratio == 0.0f) || (lod_id == higher_lod && t_ratio == 1.0f)) break;
             }
-            // A6 :152-167 -- canonical sequence v2: dot products are fma chains, quotients are products
-            // with one correctly rounded reciprocal; the CPU checker evaluates exactly the same operations
-            float cv[4], q[4];
-            for (int rr = 0; rr < 4; rr++) cv[rr] = fmaf(f.V[8 + rr], c2, fmaf(f.V[4 + rr], c1, f.V[rr] * c0)) + f.V[12 + rr];
-            for (int rr = 0; rr < 4; rr++)
-                q[rr] = fmaf(f.GP[12 + rr], cv[3], fmaf(f.GP[8 + rr], cv[2], fmaf(f.GP[4 + rr], cv[1], f.GP[rr] * cv[0])));
-            float clip = 1.2f * q[3];
-            if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) break;
-            if (f.dbg_flags & 16) break;               // ablation: stop after the frustum cull
-            // A7 :169-205
-            float K[9];
-            {
-                float a = half_decode(w1.x & 0xFFFFu), b = half_decode(w1.x >> 16);
-                float cc = half_decode(w1.y & 0xFFFFu), dd = half_decode(w1.y >> 16);
-                float e = half_decode(w1.z & 0xFFFFu), ff = half_decode(w1.z >> 16);
-                K[0] = a; K[1] = b; K[2] = cc; K[3] = b; K[4] = dd; K[5] = e; K[6] = cc; K[7] = e; K[8] = ff;
-            }
-            if (f.point_cloud_radius > 0.0f) {
-                float pr = f.point_cloud_radius;
-                if (f.draw_mode > 0u) pr *= ldexpf(1.0f, (int)d.tile_lod);
-                K[0] = pr; K[1] = 0; K[2] = 0; K[3] = 0; K[4] = pr; K[5] = 0; K[6] = 0; K[7] = 0; K[8] = pr;
-            }
-            if (f.surface_type > 0u) {
-                float FK[9], R[9];
+            float majx, majy, minx, miny, cr, cg, cb, ca, ndcx, ndcy, depth;
+            float q[4];
+            if (STRICT) {
+                // A6 :152-167, operator by operator
+                float cv[4];
+                for (int rr = 0; rr < 4; rr++) cv[rr] = ((f.V[rr] * c0 + f.V[4 + rr] * c1) + f.V[8 + rr] * c2) + f.V[12 + rr] * 1.0f;
+                for (int rr = 0; rr < 4; rr++)
+                    q[rr] = ((f.GP[rr] * cv[0] + f.GP[4 + rr] * cv[1]) + f.GP[8 + rr] * cv[2]) + f.GP[12 + rr] * cv[3];
+                const float clip = 1.2f * q[3];
+                if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) break;
+                // A7 :169-205
+                float K[9];
+                {
+                    float a = half_decode(w1.x & 0xFFFFu), b = half_decode(w1.x >> 16);
+                    float cc = half_decode(w1.y & 0xFFFFu), dd = half_decode(w1.y >> 16);
+                    float e = half_decode(w1.z & 0xFFFFu), ff = half_decode(w1.z >> 16);
+                    K[0] = a; K[1] = b; K[2] = cc; K[3] = b; K[4] = dd; K[5] = e; K[6] = cc; K[7] = e; K[8] = ff;
+                }
+                if (f.point_cloud_radius > 0.0f) {
+                    float pr = f.point_cloud_radius;
+                    if (f.draw_mode > 0u) pr *= ldexpf(1.0f, (int)d.tile_lod);
+                    K[0] = pr; K[1] = 0; K[2] = 0; K[3] = 0; K[4] = pr; K[5] = 0; K[6] = 0; K[7] = 0; K[8] = pr;
+                }
+                if (f.surface_type > 0u) {          // Vrk = transform * Vrk * transpose(transform)
+                    float FK[9], R[9];
+                    for (int cc = 0; cc < 3; cc++)
+                        for (int rr = 0; rr < 3; rr++)
+                            FK[3 * cc + rr] = (F[rr] * K[3 * cc] + F[3 + rr] * K[3 * cc + 1]) + F[6 + rr] * K[3 * cc + 2];
+                    for (int cc = 0; cc < 3; cc++)
+                        for (int rr = 0; rr < 3; rr++)
+                            R[3 * cc + rr] = (FK[rr] * F[cc] + FK[3 + rr] * F[3 + cc]) + FK[6 + rr] * F[6 + cc];
+                    for (int k = 0; k < 9; k++) K[k] = R[k];
+                }
+                {                                   // scene_scale_mat * Vrk * transpose(scene_scale_mat): the full matrix products, zeros included
+                    const float S[9] = {f.scene_scale[0], 0.0f, 0.0f, 0.0f, f.scene_scale[1], 0.0f, 0.0f, 0.0f, f.scene_scale[2]};
+                    float SK[9], R[9];
+                    for (int cc = 0; cc < 3; cc++)
+                        for (int rr = 0; rr < 3; rr++)
+                            SK[3 * cc + rr] = (S[rr] * K[3 * cc] + S[3 + rr] * K[3 * cc + 1]) + S[6 + rr] * K[3 * cc + 2];
+                    for (int cc = 0; cc < 3; cc++)
+                        for (int rr = 0; rr < 3; rr++)
+                            R[3 * cc + rr] = (SK[rr] * S[cc] + SK[3 + rr] * S[3 + cc]) + SK[6 + rr] * S[6 + cc];
+                    for (int k = 0; k < 9; k++) K[k] = R[k];
+                }
+                // A8 :207-258
+                const float dd0 = c0 - f.cam_pos[0], dd1 = c1 - f.cam_pos[1], dd2 = c2 - f.cam_pos[2];
+                float t[3];
+                for (int rr = 0; rr < 3; rr++) t[rr] = (f.V[rr] * dd0 + f.V[4 + rr] * dd1) + f.V[8 + rr] * dd2;
+                const float txtz = t[0] / t[2], tytz = t[1] / t[2];
+                const float limx = 1.3f * f.htan[0], limy = 1.3f * f.htan[1];
+                t[0] = clampf(txtz, -limx, limx) * t[2];
+                t[1] = clampf(tytz, -limy, limy) * t[2];
+                const float tz2 = t[2] * t[2];
+                // J_T columns: (fx / tz, 0, -fx tx / tz^2), (0, fy / tz, -fy ty / tz^2), (0, 0, 0)
+                const float JT[9] = {f.focal[0] / t[2], 0.0f, (-f.focal[0] * t[0]) / tz2,
+                                     0.0f, f.focal[1] / t[2], (-f.focal[1] * t[1]) / tz2,
+                                     0.0f, 0.0f, 0.0f};
+                float Tm[9];                        // T = transpose(view3) * J_T
                 for (int cc = 0; cc < 3; cc++)
                     for (int rr = 0; rr < 3; rr++)
-                        FK[3 * cc + rr] = fmaf(F[6 + rr], K[3 * cc + 2], fmaf(F[3 + rr], K[3 * cc + 1], F[rr] * K[3 * cc]));
+                        Tm[3 * cc + rr] = (f.V[4 * rr + 0] * JT[3 * cc] + f.V[4 * rr + 1] * JT[3 * cc + 1]) + f.V[4 * rr + 2] * JT[3 * cc + 2];
+                float Am[9], C2[9];                 // cov2d = transpose(T) * Vrk * T
                 for (int cc = 0; cc < 3; cc++)
                     for (int rr = 0; rr < 3; rr++)
-                        R[3 * cc + rr] = fmaf(FK[6 + rr], F[6 + cc], fmaf(FK[3 + rr], F[3 + cc], FK[rr] * F[cc]));
-                for (int k = 0; k < 9; k++) K[k] = R[k];
-            }
-            // scene_scale_mat * Vrk * transpose(scene_scale_mat): a product with 1.0 is exact, so the usual unit scale skips 18 multiplications
-            // (uniform branch; same bits)
-            if (f.scene_scale[0] != 1.0f || f.scene_scale[1] != 1.0f || f.scene_scale[2] != 1.0f)
+                        Am[3 * cc + rr] = (Tm[3 * rr + 0] * K[3 * cc] + Tm[3 * rr + 1] * K[3 * cc + 1]) + Tm[3 * rr + 2] * K[3 * cc + 2];
                 for (int cc = 0; cc < 3; cc++)
-                    for (int rr = 0; rr < 3; rr++) K[3 * cc + rr] = (f.scene_scale[rr] * K[3 * cc + rr]) * f.scene_scale[cc];
-            // A8 :207-258
-            float d0 = c0 - f.cam_pos[0], d1 = c1 - f.cam_pos[1], d2 = c2 - f.cam_pos[2];
-            float t[3];
-            for (int rr = 0; rr < 3; rr++) t[rr] = fmaf(f.V[8 + rr], d2, fmaf(f.V[4 + rr], d1, f.V[rr] * d0));
-            const float rz = GSWT_RCP(t[2]);
-            float txtz = t[0] * rz, tytz = t[1] * rz;
-            float limx = 1.3f * f.htan[0], limy = 1.3f * f.htan[1];
-            t[0] = clampf(txtz, -limx, limx) * t[2];
-            t[1] = clampf(tytz, -limy, limy) * t[2];
-            const float rz2 = rz * rz;
-            float j00 = f.focal[0] * rz, j02 = -((f.focal[0] * t[0]) * rz2);
-            float j11 = f.focal[1] * rz, j12 = -((f.focal[1] * t[1]) * rz2);
-            float T0[3], T1[3];
-            for (int rr = 0; rr < 3; rr++) {
-                T0[rr] = fmaf(f.V[4 * rr + 2], j02, f.V[4 * rr + 0] * j00);
-                T1[rr] = fmaf(f.V[4 * rr + 2], j12, f.V[4 * rr + 1] * j11);
-            }
-            float A0[3], A1[3];
-            for (int k = 0; k < 3; k++) {
-                A0[k] = fmaf(T0[2], K[3 * k + 2], fmaf(T0[1], K[3 * k + 1], T0[0] * K[3 * k]));
-                A1[k] = fmaf(T1[2], K[3 * k + 2], fmaf(T1[1], K[3 * k + 1], T1[0] * K[3 * k]));
-            }
-            float c00 = fmaf(A0[2], T0[2], fmaf(A0[1], T0[1], A0[0] * T0[0]));
-            float c01 = fmaf(A1[2], T0[2], fmaf(A1[1], T0[1], A1[0] * T0[0]));
-            float c11 = fmaf(A1[2], T1[2], fmaf(A1[1], T1[1], A1[0] * T1[0]));
-            float mid = 0.5f * (c00 + c11);
-            float hxx = 0.5f * (c00 - c11);
-            float radius = GSWT_SQRT(fmaf(hxx, hxx, c01 * c01));
-            float l1 = mid + radius, l2 = mid - radius;
-            if (l2 < 0.0f) break;
-            float vx = c01, vy = l1 - c00;
-            float vlen = GSWT_SQRT(fmaf(vx, vx, vy * vy));
-            const float rv = GSWT_RCP(vlen);
-            float ex = vx * rv, ey = vy * rv;
-            float smaj = fminf(GSWT_SQRT(2.0f * l1), 1024.0f);
-            float smin = fminf(GSWT_SQRT(2.0f * l2), 1024.0f);
-            float majx = smaj * ex, majy = smaj * ey;
-            float minx = smin * ey, miny = smin * -ex;
-            // A9 :260-265, 402-410 (byte / 255 as byte * fl(1 / 255))
-            const float k255 = 1.0f / 255.0f;
-            float cr = (float)(w1.w & 0xFFu) * k255;
-            float cg = (float)((w1.w >> 8) & 0xFFu) * k255;
-            float cb = (float)((w1.w >> 16) & 0xFFu) * k255;
-            float ca = (float)((w1.w >> 24) & 0xFFu) * k255;
-            if (FULL && f.draw_mode != 0u) debug_draw_color(f, d, u2f(w0.x), u2f(w0.y), lod_id, t_ratio, cr, cg, cb);   // :268-399
-            if (d.changing == 1u) {
-                if (lod_id != higher_lod) ca = ca * t_ratio;
-                else ca = ca * (1.0f - t_ratio);
-            }
-            // rgba *= clamp(z/w + 1, 0, 1): identically 1 for 0 <= z/w, kept for the debug output only
-            // A10 :415-419
-            const float rq = GSWT_RCP(q[3]);
-            float ndcx = q[0] * rq, ndcy = q[1] * rq, depth = q[2] * rq;
-            if (DEBUG) {
-                float fade = clampf(fmaf(q[2], rq, 1.0f), 0.0f, 1.0f);
-                vout.ndc[0] = ndcx; vout.ndc[1] = ndcy; vout.depth = depth;
-                vout.major[0] = majx; vout.major[1] = majy; vout.minor[0] = minx; vout.minor[1] = miny;
-                vout.rgba[0] = cr * fade; vout.rgba[1] = cg * fade; vout.rgba[2] = cb * fade; vout.rgba[3] = ca * fade;
+                    for (int rr = 0; rr < 3; rr++)
+                        C2[3 * cc + rr] = (Am[rr] * Tm[3 * cc] + Am[3 + rr] * Tm[3 * cc + 1]) + Am[6 + rr] * Tm[3 * cc + 2];
+                const float c00 = C2[0], c01 = C2[1], c11 = C2[4];
+                const float mid = 0.5f * (c00 + c11);
+                const float hxx = 0.5f * (c00 - c11);
+                const float radius = sqrtf(hxx * hxx + c01 * c01);
+                const float l1 = mid + radius, l2 = mid - radius;
+                if (l2 < 0.0f) break;
+                const float vx = c01, vy = l1 - c00;
+                const float vlen = sqrtf(vx * vx + vy * vy);
+                const float ex = vx / vlen, ey = vy / vlen;
+                const float smaj = fminf(sqrtf(2.0f * l1), 1024.0f);
+                const float smin = fminf(sqrtf(2.0f * l2), 1024.0f);
+                majx = smaj * ex; majy = smaj * ey;
+                minx = smin * ey; miny = smin * -ex;
+                // A9 :260-265, 402-410
+                cr = (float)(w1.w & 0xFFu) / 255.0f;
+                cg = (float)((w1.w >> 8) & 0xFFu) / 255.0f;
+                cb = (float)((w1.w >> 16) & 0xFFu) / 255.0f;
+                ca = (float)((w1.w >> 24) & 0xFFu) / 255.0f;
+                if (FULL && f.draw_mode != 0u) debug_draw_color(f, d, u2f(w0.x), u2f(w0.y), lod_id, t_ratio, cr, cg, cb);   // :268-399
+                if (d.changing == 1u) {
+                    if (lod_id != higher_lod) ca = ca * t_ratio;
+                    else ca = ca * (1.0f - t_ratio);
+                }
+                // A10 :415-419
+                ndcx = q[0] / q[3]; ndcy = q[1] / q[3]; depth = q[2] / q[3];
+                if (DEBUG) {
+                    const float fade = clampf(q[2] / q[3] + 1.0f, 0.0f, 1.0f);
+                    vout.ndc[0] = ndcx; vout.ndc[1] = ndcy; vout.depth = depth;
+                    vout.major[0] = majx; vout.major[1] = majy; vout.minor[0] = minx; vout.minor[1] = miny;
+                    vout.rgba[0] = cr * fade; vout.rgba[1] = cg * fade; vout.rgba[2] = cb * fade; vout.rgba[3] = ca * fade;
+                }
+            } else {
+                // A6 :152-167 -- canonical sequence v2: dot products are fma chains, quotients are products
+                // with one correctly rounded reciprocal; the CPU checker evaluates exactly the same operations
+                float cv[4];
+                for (int rr = 0; rr < 4; rr++) cv[rr] = fmaf(f.V[8 + rr], c2, fmaf(f.V[4 + rr], c1, f.V[rr] * c0)) + f.V[12 + rr];
+                for (int rr = 0; rr < 4; rr++)
+                    q[rr] = fmaf(f.GP[12 + rr], cv[3], fmaf(f.GP[8 + rr], cv[2], fmaf(f.GP[4 + rr], cv[1], f.GP[rr] * cv[0])));
+                float clip = 1.2f * q[3];
+                if (q[2] < -clip || q[0] < -clip || q[0] > clip || q[1] < -clip || q[1] > clip) break;
+                if (GSWT_ABL(f, 16)) break;               // ablation: stop after the frustum cull
+                // A7 :169-205
+                float K[9];
+                {
+                    float a = half_decode(w1.x & 0xFFFFu), b = half_decode(w1.x >> 16);
+                    float cc = half_decode(w1.y & 0xFFFFu), dd = half_decode(w1.y >> 16);
+                    float e = half_decode(w1.z & 0xFFFFu), ff = half_decode(w1.z >> 16);
+                    K[0] = a; K[1] = b; K[2] = cc; K[3] = b; K[4] = dd; K[5] = e; K[6] = cc; K[7] = e; K[8] = ff;
+                }
+                if (f.point_cloud_radius > 0.0f) {
+                    float pr = f.point_cloud_radius;
+                    if (f.draw_mode > 0u) pr *= ldexpf(1.0f, (int)d.tile_lod);
+                    K[0] = pr; K[1] = 0; K[2] = 0; K[3] = 0; K[4] = pr; K[5] = 0; K[6] = 0; K[7] = 0; K[8] = pr;
+                }
+                if (f.surface_type > 0u) {
+                    float FK[9], R[9];
+                    for (int cc = 0; cc < 3; cc++)
+                        for (int rr = 0; rr < 3; rr++)
+                            FK[3 * cc + rr] = fmaf(F[6 + rr], K[3 * cc + 2], fmaf(F[3 + rr], K[3 * cc + 1], F[rr] * K[3 * cc]));
+                    for (int cc = 0; cc < 3; cc++)
+                        for (int rr = 0; rr < 3; rr++)
+                            R[3 * cc + rr] = fmaf(FK[6 + rr], F[6 + cc], fmaf(FK[3 + rr], F[3 + cc], FK[rr] * F[cc]));
+                    for (int k = 0; k < 9; k++) K[k] = R[k];
+                }
+                // scene_scale_mat * Vrk * transpose(scene_scale_mat): a product with 1.0 is exact, so the usual unit scale skips 18 multiplications
+                // (uniform branch; same bits)
+                if (f.scene_scale[0] != 1.0f || f.scene_scale[1] != 1.0f || f.scene_scale[2] != 1.0f)
+                    for (int cc = 0; cc < 3; cc++)
+                        for (int rr = 0; rr < 3; rr++) K[3 * cc + rr] = (f.scene_scale[rr] * K[3 * cc + rr]) * f.scene_scale[cc];
+                // A8 :207-258
+                float d0 = c0 - f.cam_pos[0], d1 = c1 - f.cam_pos[1], d2 = c2 - f.cam_pos[2];
+                float t[3];
+                for (int rr = 0; rr < 3; rr++) t[rr] = fmaf(f.V[8 + rr], d2, fmaf(f.V[4 + rr], d1, f.V[rr] * d0));
+                const float rz = GSWT_RCP(t[2]);
+                float txtz = t[0] * rz, tytz = t[1] * rz;
+                float limx = 1.3f * f.htan[0], limy = 1.3f * f.htan[1];
+                t[0] = clampf(txtz, -limx, limx) * t[2];
+                t[1] = clampf(tytz, -limy, limy) * t[2];
+                const float rz2 = rz * rz;
+                float j00 = f.focal[0] * rz, j02 = -((f.focal[0] * t[0]) * rz2);
+                float j11 = f.focal[1] * rz, j12 = -((f.focal[1] * t[1]) * rz2);
+                float T0[3], T1[3];
+                for (int rr = 0; rr < 3; rr++) {
+                    T0[rr] = fmaf(f.V[4 * rr + 2], j02, f.V[4 * rr + 0] * j00);
+                    T1[rr] = fmaf(f.V[4 * rr + 2], j12, f.V[4 * rr + 1] * j11);
+                }
+                float A0[3], A1[3];
+                for (int k = 0; k < 3; k++) {
+                    A0[k] = fmaf(T0[2], K[3 * k + 2], fmaf(T0[1], K[3 * k + 1], T0[0] * K[3 * k]));
+                    A1[k] = fmaf(T1[2], K[3 * k + 2], fmaf(T1[1], K[3 * k + 1], T1[0] * K[3 * k]));
+                }
+                float c00 = fmaf(A0[2], T0[2], fmaf(A0[1], T0[1], A0[0] * T0[0]));
+                float c01 = fmaf(A1[2], T0[2], fmaf(A1[1], T0[1], A1[0] * T0[0]));
+                float c11 = fmaf(A1[2], T1[2], fmaf(A1[1], T1[1], A1[0] * T1[0]));
+                float mid = 0.5f * (c00 + c11);
+                float hxx = 0.5f * (c00 - c11);
+                float radius = GSWT_SQRT(fmaf(hxx, hxx, c01 * c01));
+                float l1 = mid + radius, l2 = mid - radius;
+                if (l2 < 0.0f) break;
+                float vx = c01, vy = l1 - c00;
+                float vlen = GSWT_SQRT(fmaf(vx, vx, vy * vy));
+                const float rv = GSWT_RCP(vlen);
+                float ex = vx * rv, ey = vy * rv;
+                float smaj = fminf(GSWT_SQRT(2.0f * l1), 1024.0f);
+                float smin = fminf(GSWT_SQRT(2.0f * l2), 1024.0f);
+                majx = smaj * ex; majy = smaj * ey;
+                minx = smin * ey; miny = smin * -ex;
+                // A9 :260-265, 402-410 (byte / 255 as byte * fl(1 / 255))
+                const float k255 = 1.0f / 255.0f;
+                cr = (float)(w1.w & 0xFFu) * k255;
+                cg = (float)((w1.w >> 8) & 0xFFu) * k255;
+                cb = (float)((w1.w >> 16) & 0xFFu) * k255;
+                ca = (float)((w1.w >> 24) & 0xFFu) * k255;
+                if (FULL && f.draw_mode != 0u) debug_draw_color(f, d, u2f(w0.x), u2f(w0.y), lod_id, t_ratio, cr, cg, cb);   // :268-399
+                if (d.changing == 1u) {
+                    if (lod_id != higher_lod) ca = ca * t_ratio;
+                    else ca = ca * (1.0f - t_ratio);
+                }
+                // rgba *= clamp(z/w + 1, 0, 1): identically 1 for 0 <= z/w, kept for the debug output only
+                // A10 :415-419
+                const float rq = GSWT_RCP(q[3]);
+                ndcx = q[0] * rq; ndcy = q[1] * rq; depth = q[2] * rq;
+                if (DEBUG) {
+                    float fade = clampf(fmaf(q[2], rq, 1.0f), 0.0f, 1.0f);
+                    vout.ndc[0] = ndcx; vout.ndc[1] = ndcy; vout.depth = depth;
+                    vout.major[0] = majx; vout.major[1] = majy; vout.minor[0] = minx; vout.minor[1] = miny;
+                    vout.rgba[0] = cr * fade; vout.rgba[1] = cg * fade; vout.rgba[2] = cb * fade; vout.rgba[3] = ca * fade;
+                }
             }
             if (!(depth >= 0.0f && depth <= 1.0f)) break;
             // Fragment setup F1, F2: pixel-space centre and inverse affine map
@@ -776,7 +894,7 @@ __global__ __launch_bounds__(256) void k_project(
                 tx0 = max(tx0, f.col0); tx1 = min(tx1, f.col1 - 1);          // column band of this ctx (the whole frame when off)
                 int rows = owned_rows(ty0, ty1, f.shard_index, f.shard_count);
                 count = tx1 >= tx0 ? (uint32_t)((tx1 - tx0 + 1) * rows) : 0u;
-                if (f.dbg_flags & 8) count = 0;        // ablation: no record / rect stores, no pairs
+                if (GSWT_ABL(f, 8)) count = 0;        // ablation: no record / rect stores, no pairs
                 if (count) {
                     my_rect = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
                     // 32-byte record: the inverse map, the centre, alpha and the packed colour (unpacked by the compositor's blend);
@@ -801,6 +919,8 @@ __global__ __launch_bounds__(256) void k_project(
         wvis += __shfl_down(wvis, off, 64);
     }
     if ((tid & 63u) == 0) { s_wsum[tid >> 6] = wsum; s_wvis[tid >> 6] = wvis; }
+    // GSWT_ORDER_DEPTH: slots of this chunk that emit pairs = what the global depth sort has to order (one ballot per wave; null otherwise)
+    if (block_emit) { const uint32_t we = (uint32_t)__popcll(__ballot(count != 0u)); if ((tid & 63u) == 0) s_wemit[tid >> 6] = we; }
     __syncthreads();
     GSWT_TR(5, GSWT_NOW())
     const uint32_t bsum = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
@@ -817,6 +937,11 @@ __global__ __launch_bounds__(256) void k_project(
         if (bsum) atomicAdd(&super_sums[cid >> 8], bsum);
         uint32_t v = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
         if (v) atomicAdd(&super_sums[n_super + (cid >> 8)], v);
+        if (block_emit) {
+            const uint32_t e = s_wemit[0] + s_wemit[1] + s_wemit[2] + s_wemit[3];
+            block_emit[cid] = e;
+            if (e) atomicAdd(&super_sums[3u * n_super + (cid >> 8)], e);       // [pairs][visible][pair prefix][emitting slots][their prefix]
+        }
     }
     GSWT_TR(6, GSWT_NOW())
 }
@@ -827,9 +952,13 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 // scan of the pair half of super_sums), so that k_emit reads one word instead of summing up to n_chunks / 256 of them
 // (c5: 1 430 per workgroup).  Single workgroup.  (Folding it into k_emit -- every workgroup sums the super-group counts
 // in front of it, workgroup 0 leaves the totals -- was measured: k_emit +6 us for the 4.6 us saved, 4015 -> 3881 frames/s.)
+// GSWT_ORDER_DEPTH (emit_sums != nullptr): the same for the per-super-group counts of EMITTING slots -- their exclusive prefix goes to
+// emit_excl, their total to counters[4] (the item count of the depth sort, read on the device; counters[6], its overflow word, stays 0)
+// and a total beyond the depth sort's capacity flags the frame like a pair overflow (the host grows the capacity and re-runs it).
 __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ super_sums, uint32_t n_super,
                                                 unsigned long long* __restrict__ counters, uint32_t* __restrict__ super_excl, uint32_t pair_cap,
-                                                uint32_t* __restrict__ live_cnt)
+                                                uint32_t* __restrict__ live_cnt, const uint32_t* __restrict__ emit_sums,
+                                                uint32_t* __restrict__ emit_excl, uint32_t emit_cap)
 {
     // k_project is done with this frame's live-chunk counts: cleared here for the slot's next frame (k_cull both clears
     // buffers and adds to these counters, so it cannot clear them itself)
@@ -873,11 +1002,26 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ sup
         counters[1] = carry; counters[0] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
         if (carry > (unsigned long long)pair_cap) counters[3] = 1ull;       // pair buffers too small: the host re-runs the frame
     }
+    if (emit_sums) {                                                        // uniform
+        uint32_t ecarry = 0;                                                // (slots: < 2^32 in total)
+        for (uint32_t base = 0; base < n_super; base += 1024u) {
+            const uint32_t i = base + threadIdx.x * 4u;
+            uint32_t p[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint32_t pv = emit_sums[min(i + (uint32_t)k, n_super - 1u)]; p[k] = i + k < n_super ? pv : 0u; sum += p[k]; }
+            uint32_t tot32;
+            uint32_t ex = block_excl_scan(sum, s_w, &tot32) + ecarry;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { if (i + k < n_super) emit_excl[i + k] = ex; ex += p[k]; }
+            ecarry += tot32;
+        }
+        if (threadIdx.x == 0) {
+            counters[4] = ecarry;
+            if (ecarry > emit_cap) counters[3] = 1ull;
+        }
+    }
 }
 
-// ------------------------------------------------------------------------------------
-// Exclusive scan (u32), reduce-then-scan, 1024 items per workgroup
-// ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
 {
     for (int off = 1; off < 64; off <<= 1) {
@@ -900,47 +1044,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w /*
     *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     __syncthreads();
     return base + inc - v;
-}
-
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ partial)
-{
-    __shared__ uint32_t s_w[4];
-    size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    uint32_t s = 0;
-    for (int k = 0; k < 4; k++) if (base + k < n) s += in[base + k];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-// single workgroup: exclusive scan of n items in place (loops with carry); total -> *total_out
-__global__ __launch_bounds__(256) void k_scan_single(uint32_t* __restrict__ data, size_t n, uint32_t* __restrict__ total_out)
-{
-    __shared__ uint32_t s_w[4];
-    uint32_t carry = 0;
-    for (size_t base = 0; base < n; base += 1024) {
-        size_t i = base + threadIdx.x * 4;
-        uint32_t v[4], s = 0;
-        for (int k = 0; k < 4; k++) { v[k] = (i + k < n) ? data[i + k] : 0u; s += v[k]; }
-        uint32_t tot;
-        uint32_t ex = block_excl_scan(s, s_w, &tot) + carry;
-        for (int k = 0; k < 4; k++) { if (i + k < n) data[i + k] = ex; ex += v[k]; }
-        carry += tot;
-    }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
-}
-
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n,
-                                                    const uint32_t* __restrict__ partial_scanned)
-{
-    __shared__ uint32_t s_w[4];
-    size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
-    uint32_t v[4], s = 0;
-    for (int k = 0; k < 4; k++) { v[k] = (i + k < n) ? in[i + k] : 0u; s += v[k]; }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(s, s_w, &tot) + partial_scanned[blockIdx.x];
-    for (int k = 0; k < 4; k++) { if (i + k < n) out[i + k] = ex; ex += v[k]; }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1079,6 +1182,24 @@ constexpr uint32_t kSortWideMax = 0xFFFFFFFFu;  // pair capacities up to this us
 constexpr uint32_t kSupShift = 5;
 constexpr uint32_t kSupDirect = 32;             // up to this many groups the scatter kernel reads every group row instead of digit totals
 
+// Key range of the depth sort as k_depth_keys leaves it: [0] = ~smallest key, [1] = largest (both through atomicMax, so the frame's zeroed
+// scratch words are the neutral start); no keys at all reads as (0, 0).
+__device__ __forceinline__ void load_krange(const uint32_t* __restrict__ krange, uint32_t& kmin, uint32_t& kmax)
+{
+    kmin = ~krange[0]; kmax = krange[1];
+    if (kmax < kmin) { kmin = 0u; kmax = 0u; }
+}
+// Number of radix passes that really ran for keys in [kmin, kmax] (see k_radix_hist): pass p covers bits 8p .. 8p+7 of key - kmin.
+__device__ __forceinline__ uint32_t sort_passes_run(const uint32_t* __restrict__ krange)
+{
+    uint32_t kmin, kmax;
+    load_krange(krange, kmin, kmax);
+    const uint32_t span = kmax - kmin;
+    uint32_t p = 1;                                     // the first pass always runs
+    for (uint32_t sh = 8; sh < 32u; sh += 8u) if ((span >> sh) != 0u) p++;
+    return p;
+}
+
 // Lanes of the wave that hold the same digit as this one (match-any on `nbits` bits), restricted to valid lanes.
 __device__ __forceinline__ unsigned long long match_digit(uint32_t dgt, bool valid, uint32_t nbits)
 {
@@ -1095,9 +1216,14 @@ template <int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ n_ptr,
                                                     uint32_t n_cap, uint32_t shift, uint32_t mask, uint32_t nbits, uint32_t* __restrict__ ghist,
                                                     uint32_t* __restrict__ gsup, uint32_t* __restrict__ gtot, uint32_t nblk,
-                                                    uint32_t nsup)
+                                                    uint32_t nsup, const uint32_t* __restrict__ krange)
 {
     constexpr int kSortItems = kSortBlock / kSortThreads;
+    // krange (the depth sort only): [0] = smallest key, [1] = largest.  Digits are taken from key - smallest, and a pass whose shift is
+    // beyond the bits of (largest - smallest) would move nothing: its two kernels leave at once and the consumer of the sorted list picks
+    // the buffer by the same rule (sort_passes_run).  Visible depths of one frame span ~2^21 ulps at c3: three passes, not four.
+    uint32_t kmin = 0;
+    if (krange) { uint32_t kmax; load_krange(krange, kmin, kmax); if (shift != 0u && ((kmax - kmin) >> shift) == 0u) return; }
     const uint32_t n = clamped_count(n_ptr, n_cap);
     __shared__ uint32_t s_h[256];
     if (threadIdx.x < 256u) s_h[threadIdx.x] = 0;
@@ -1118,7 +1244,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
 #pragma unroll
         for (int k = 0; k < kSortItems; k++) {
             const bool valid = base + (uint32_t)k * 64u + lane < n;           // valid lanes are a prefix of the wave
-            const uint32_t dgt = (key[k] >> shift) & mask;
+            const uint32_t dgt = ((key[k] - kmin) >> shift) & mask;
             const uint32_t prev = (uint32_t)__shfl_up((int)dgt, 1, 64);
             const unsigned long long heads = __ballot(valid && (lane == 0u || prev != dgt));
             const unsigned long long vmask = __ballot(valid);
@@ -1178,9 +1304,11 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
                                                        const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
                                                        uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist,
                                                        const uint32_t* __restrict__ gsup, const uint32_t* __restrict__ gtot,
-                                                       uint32_t nblk, uint32_t nsup, uint2* __restrict__ ranges)
+                                                       uint32_t nblk, uint32_t nsup, uint2* __restrict__ ranges, const uint32_t* __restrict__ krange)
 {
     constexpr int kSortItems = kSortBlock / kSortThreads, kSortWaves = kSortThreads / 64;
+    uint32_t kmin = 0;                                  // (see k_radix_hist)
+    if (krange) { uint32_t kmax; load_krange(krange, kmin, kmax); if (shift != 0u && ((kmax - kmin) >> shift) == 0u) return; }
     const uint32_t n = clamped_count(n_ptr, n_cap);
     if (blockIdx.x * kSortBlock >= n) return;
 #ifdef GSWT_TRACE
@@ -1255,7 +1383,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
 #pragma unroll
     for (int k = 0; k < kSortItems; k++) {
         const bool valid = base + (uint32_t)k * 64u + lane < n;
-        const uint32_t dgt = (key[k] >> shift) & mask;
+        const uint32_t dgt = ((key[k] - kmin) >> shift) & mask;
         const unsigned long long peers = match_digit(dgt, valid, nbits);
         if (kCachePeers) pm[k] = peers;
         if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
@@ -1300,7 +1428,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     for (int k = 0; k < kSortItems; k++) {
         uint32_t i = base + k * 64 + lane;
         bool valid = i < n;
-        uint32_t dgt = valid ? ((key[k] >> shift) & mask) : 0u;
+        uint32_t dgt = valid ? (((key[k] - kmin) >> shift) & mask) : 0u;
         const unsigned long long peers = kCachePeers ? pm[kCachePeers ? k : 0] : match_digit(dgt, valid, nbits);
         const uint32_t rank = __popcll(peers & lt);
         uint32_t pos = 0;
@@ -1317,7 +1445,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         const uint32_t i = (uint32_t)k * kSortThreads + threadIdx.x;
         if (i < n_blk) {
             const uint2 kv = s_kv[i];
-            const uint32_t gp = s_g[(kv.x >> shift) & mask] + i;
+            const uint32_t gp = s_g[((kv.x - kmin) >> shift) & mask] + i;
             vals_out[gp] = kv.y;
             if (!ranges) keys_out[gp] = kv.x;
             else {
@@ -1336,62 +1464,118 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
 }
 
 // ------------------------------------------------------------------------------------
-// GSWT_ORDER_DEPTH: true global per-splat depth order.  k_depth_keys builds (depth bits, slot) for every
-// slot (0xFFFFFFFF for slots without pairs), the radix sort above orders them on all 32 bits (stable, so
-// equal depths keep composite order), and k_emit_perm emits the pairs in that order; the tile-bit sort
-// and the compositor are unchanged.
+// GSWT_ORDER_DEPTH: true global per-splat depth order (north_star's "global radix depth sort"; the reference itself orders tiles and
+// presorted lists, wangtile.rs:489-499 + scene.rs:685-695 -- that is GSWT_ORDER_REFERENCE).
+//   k_project       also leaves, per chunk, the number of slots that emit pairs (block_emit) and their per-super-group sums
+//   k_totals        scans those sums: exclusive prefix per super-group, total -> counters[4] = the depth sort's item count (on the device)
+//   k_depth_keys    compacts the emitting slots, in slot order, to (depth bits, slot) and leaves the smallest / largest key
+//   radix sort      stable LSD on the bits of (key - smallest) that are in use: equal depths keep composite order; only what can be
+//                   visible is sorted (round 3 sorted every slot of the frame: 10 M at c3 for 1.9 M that emit), and no host word enters
+//                   the chain, so the frame is one hipGraph like any other
+//   k_perm_counts   pairs of every 256 positions of the sorted list + their per-65 536 sums (atomics on a few words)
+//   k_emit_perm     emits the pairs in depth order; a block's first pair = the super sums in front of it + the block counts of its
+//                   own super-group in front of it (summed by the block itself, as k_emit does: no scan launch)
+// The tile-bit sort and the compositor are unchanged.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ rects, const float* __restrict__ depths,
-                                                    const uint32_t* __restrict__ block_sums, uint32_t n_slots,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                                    const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_emit,
+                                                    const uint32_t* __restrict__ emit_excl, uint32_t n_chunks, uint32_t emit_cap,
+                                                    const unsigned long long* __restrict__ counters,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ krange)
 {
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    if (slot >= n_slots) return;
-    uint32_t key = 0xFFFFFFFFu;
-    if (block_sums[slot >> 8] != 0u) {
-        const uint2 rc = rects[slot];
-        if ((rc.x >> 16) >= (rc.x & 0xFFFFu)) key = __float_as_uint(depths[slot]);   // depth in [0, 1]: bit order = value order
+    __shared__ uint32_t s_w[8];
+    if (counters[4] > (unsigned long long)emit_cap) return;             // flagged by k_totals: the host re-runs the frame with more room
+    uint32_t cid[kEmitGroup], sums[kEmitGroup], be[kEmitGroup], sbase[kEmitGroup];
+    uint2 rcs[kEmitGroup];
+    float dep[kEmitGroup];
+    const uint32_t c0 = blockIdx.x * kEmitGroup;
+    const uint32_t n_mine = min(kEmitGroup, n_chunks - c0);
+#pragma unroll
+    for (uint32_t k = 0; k < kEmitGroup; k++) cid[k] = min(c0 + k, n_chunks - 1u);
+#pragma unroll
+    for (uint32_t k = 0; k < kEmitGroup; k++) {                       // (all loads up front, clamped: see k_emit)
+        sums[k] = block_sums[cid[k]];
+        be[k] = block_emit[min((cid[k] & ~255u) + threadIdx.x, cid[k])];
+        sbase[k] = emit_excl[cid[k] >> 8];
     }
-    keys[slot] = key;
-    vals[slot] = slot;
+    uint32_t any = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kEmitGroup; k++) { if (k >= n_mine) sums[k] = 0u; any |= sums[k]; }
+    if (any == 0u) return;
+#pragma unroll
+    for (uint32_t k = 0; k < kEmitGroup; k++) {                       // rects / depths of a chunk exist only when it has pairs
+        const bool live = sums[k] != 0u;
+        rcs[k] = live ? rects[(size_t)cid[k] * 256u + threadIdx.x] : make_uint2(1u, 0u);
+        dep[k] = live ? depths[(size_t)cid[k] * 256u + threadIdx.x] : 0.0f;
+    }
+    uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kEmitGroup; k++) {
+        if (sums[k] == 0u) continue;                                 // workgroup-uniform
+        const uint2 rc = rcs[k];
+        const bool emits = (rc.x >> 16) >= (rc.x & 0xFFFFu);          // k_project left an empty rect (1, 0) in slots without pairs
+        uint32_t tot, chunk_base;
+        uint32_t off = block_scan_and_sum(emits ? 1u : 0u, (cid[k] & ~255u) + threadIdx.x < cid[k] ? be[k] : 0u, s_w, &tot, &chunk_base);
+        off += chunk_base + sbase[k];
+        if (emits) {
+            const uint32_t key = __float_as_uint(dep[k]);             // depth in [0, 1]: bit order = value order
+            keys[off] = key;
+            vals[off] = cid[k] * 256u + threadIdx.x;
+            kmn = min(kmn, key); kmx = max(kmx, key);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, (uint32_t)__shfl_down((int)kmn, o, 64)); kmx = max(kmx, (uint32_t)__shfl_down((int)kmx, o, 64)); }
+    if ((threadIdx.x & 63u) == 0u && kmn <= kmx) { atomicMax(&krange[0], ~kmn); atomicMax(&krange[1], kmx); }    // (load_krange)
 }
 
-// pair count of every 256-position block of the depth-ordered slot list
-__global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2* __restrict__ rects, const uint32_t* __restrict__ sorted_keys,
-                                                     const uint32_t* __restrict__ perm, uint32_t n_slots, uint32_t* __restrict__ block_cnt)
+// pair count of every 256-position block of the depth-ordered slot list, and the sums of 256 consecutive blocks
+__global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2* __restrict__ rects, const uint32_t* __restrict__ perm_a,
+                                                     const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
+                                                     const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
+                                                     uint32_t* __restrict__ block_cnt, uint32_t* __restrict__ super_cnt)
 {
     __shared__ uint32_t s_w[4];
+    const uint32_t n = clamped_count(n_ptr, emit_cap);
+    if (blockIdx.x * 256u >= n) return;
+    const uint32_t* perm = (sort_passes_run(krange) & 1u) ? perm_b : perm_a;
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t slot = perm[min(pos, n - 1u)];
+    const uint2 rc = rects[slot];
     uint32_t count = 0;
-    if (pos < n_slots && sorted_keys[pos] != 0xFFFFFFFFu) {
-        const uint2 rc = rects[perm[pos]];
+    if (pos < n) {
         const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
         count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
     }
     uint32_t tot;
     (void)block_excl_scan(count, s_w, &tot);
-    if (threadIdx.x == 0) block_cnt[blockIdx.x] = tot;
+    if (threadIdx.x == 0) { block_cnt[blockIdx.x] = tot; if (tot) atomicAdd(&super_cnt[blockIdx.x >> 8], tot); }
 }
 
-__global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* __restrict__ rects, const uint32_t* __restrict__ sorted_keys,
-                                                   const uint32_t* __restrict__ perm, uint32_t n_slots,
-                                                   const uint32_t* __restrict__ block_off, uint32_t pair_cap,
+__global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* __restrict__ rects, const uint32_t* __restrict__ perm_a,
+                                                   const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
+                                                   const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
+                                                   const uint32_t* __restrict__ block_cnt, const uint32_t* __restrict__ super_cnt, uint32_t pair_cap,
                                                    unsigned long long* __restrict__ counters, uint32_t* __restrict__ keys,
                                                    uint32_t* __restrict__ vals)
 {
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[8];
+    const uint32_t n = clamped_count(n_ptr, emit_cap);
+    if (blockIdx.x * 256u >= n) return;
+    const uint32_t* perm = (sort_passes_run(krange) & 1u) ? perm_b : perm_a;
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    uint32_t count = 0, slot = 0;
-    int tx0 = 0, tx1 = -1, ty0 = 0, ty1 = -1;
-    if (pos < n_slots && sorted_keys[pos] != 0xFFFFFFFFu) {
-        slot = perm[pos];
-        const uint2 rc = rects[slot];
-        tx0 = rc.x & 0xFFFFu; tx1 = rc.x >> 16; ty0 = rc.y & 0xFFFFu; ty1 = rc.y >> 16;
-        count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
-    }
-    uint32_t tot;
-    const uint32_t chunk_base = block_off[blockIdx.x];
-    uint32_t off = chunk_base + block_excl_scan(count, s_w, &tot);
+    const uint32_t sb = blockIdx.x >> 8, b0 = blockIdx.x & ~255u;
+    // pairs in front of this block: the super-groups in front of its own (thread t sums supers t, t + 256, ...) + the blocks of its own
+    // super-group in front of it
+    uint32_t front = b0 + threadIdx.x < blockIdx.x ? block_cnt[b0 + threadIdx.x] : 0u;
+    for (uint32_t j = threadIdx.x; j < sb; j += 256u) front += super_cnt[j];
+    const uint32_t slot = perm[min(pos, n - 1u)];
+    const uint2 rc = rects[slot];
+    uint32_t count = 0;
+    const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
+    if (pos < n) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
+    uint32_t tot, chunk_base;
+    uint32_t off = block_scan_and_sum(count, front, s_w, &tot, &chunk_base);
+    off += chunk_base;
     if ((unsigned long long)chunk_base + tot > (unsigned long long)pair_cap) {
         if (threadIdx.x == 0 && tot) atomicOr(&counters[3], 1ull);
         return;
@@ -1702,7 +1886,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
     const uint32_t n_mine = grp == 0u ? cnt0 : grp == 1u ? cnt1 : grp == 2u ? cnt2 : cnt3;
     const uint32_t n_max = max(max(cnt0, cnt1), max(cnt2, cnt3));
     GSWT_STAT_BATCH(n_max, cnt0, cnt1, cnt2, cnt3)
-    if ((f.dbg_flags & 1) || n_max == 0u) return;
+    if (GSWT_ABL(f, 1) || n_max == 0u) return;
     if (DPPW && !DEPTH && !COLF && !PK) {
         // ---- register-broadcast walk (measurement variant, -DGSWT_EXPERIMENTS only: 123-128 us against 95 us at c3, 312 against 242 at c3d) ----
         // In rounds of 16 steps: lane j of a 16-lane group loads the record of its list's entry 16 r + j ONCE (one list read + two
@@ -1981,9 +2165,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     const uint32_t last_pair = rg.y - 1u;
     // profiling ablations of the gather chain (output is wrong): 32 = no `vals` level (the pair index stands in for the slot),
     // 64 = no record gather (every pair reads record 0)
-    const bool abl_vals = (f.dbg_flags & 32) != 0, abl_recs = (f.dbg_flags & 64) != 0;
+    const bool abl_vals = GSWT_ABL(f, 32), abl_recs = GSWT_ABL(f, 64);
 #define GSWT_VAL(I) (abl_vals ? (I) : vals[(I)])
-    if (rg.x < rg.y && !(f.dbg_flags & 4)) {
+    if (rg.x < rg.y && !GSWT_ABL(f, 4)) {
         uint32_t slot0 = GSWT_VAL(min(rg.x + tid, last_pair));
         if (abl_recs) slot0 = 0u;
         GSWT_LOAD_REC(slot0)
@@ -1992,7 +2176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     }
     for (uint32_t base = rg.x; base < rg.y; base += 256u) {
         const uint32_t n = min(256u, rg.y - base);
-        if (f.dbg_flags & 4) break;                       // ablation: no staging at all
+        if (GSWT_ABL(f, 4)) break;                       // ablation: no staging at all
         if (tid < n) {
             // F3: per-(splat, tile) constants
             const float ox = rb.x - fbx, oy = rb.y - fby;
@@ -2040,7 +2224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
             if (COLF) rd = col_f[slot_nxt];
             slot_nxt = GSWT_VAL(min(base + 512u + tid, last_pair));
         }
-        if (wave_live && !(f.dbg_flags & 2))               // ablation bit 2: stage only
+        if (wave_live && !GSWT_ABL(f, 2))               // ablation bit 2: stage only
             composite_bin_walk<EARLY, DEPTH, COLF, PK, DPPW>(f, cl, n, s_q0, s_q1, s_q2, s_bb, s_dep, wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
 #ifdef GSWT_TRACE
         tr_walk += GSWT_NOW() - tr_t0;
@@ -2179,47 +2363,36 @@ GraphRec*& graph_recorder()
 
 void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, uint32_t* cell_culled, uint32_t n_cells,
                  uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b, uint32_t* zero_c, uint32_t n_zero_c,
-                 uint32_t* live_cnt, uint4* live_tab)
+                 uint32_t* live_cnt, uint4* live_tab, uint32_t* zero_d, uint32_t n_zero_d)
 {
     uint32_t grid = (n_draws * 8u + 255u) / 256u;          // eight lanes per draw
     if (grid < 32) grid = 32;
-    GSWT_LAUNCH(k_cull, dim3(grid), dim3(256), s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, live_cnt, live_tab);
+    GSWT_LAUNCH(k_cull, dim3(grid), dim3(256), s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, live_cnt, live_tab, zero_d, n_zero_d);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
                     const float* hmap, const uint32_t* draw_culled, const uint32_t* cell_culled, uint32_t* live_cnt, const uint4* live_tab, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
-                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap)
+                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap,
+                    uint32_t* block_emit, uint32_t emit_cap, bool strict)
 {
     if (n_chunks == 0) return;
-    const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs x n_super][visible x n_super], zeroed by the caller
+    // super_sums = [pairs][visible][exclusive pair prefix] x n_super, zeroed by the caller; with block_emit (GSWT_ORDER_DEPTH) two more
+    // rows: [emitting slots][their exclusive prefix]
+    const uint32_t n_super = n_chunks / 256u + 1u;
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
-#define GSWT_LAUNCH_PROJECT(D, F)                                                                                              \
-    GSWT_LAUNCH((k_project<D, F>), dim3(n_launch), dim3(256), s, f, draws, chunk_tab, static_list, merged_list,        \
-                       merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f)
+#define GSWT_LAUNCH_PROJECT_S(D, F, S)                                                                                         \
+    GSWT_LAUNCH((k_project<D, F, S>), dim3(n_launch), dim3(256), s, f, draws, chunk_tab, static_list, merged_list,        \
+                       merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f, block_emit)
+#define GSWT_LAUNCH_PROJECT(D, F) do { if (strict) GSWT_LAUNCH_PROJECT_S(D, F, true); else GSWT_LAUNCH_PROJECT_S(D, F, false); } while (0)
     if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
     else if (debug) { GSWT_LAUNCH_PROJECT(true, false); }
     else if (full) { GSWT_LAUNCH_PROJECT(false, true); }
     else { GSWT_LAUNCH_PROJECT(false, false); }
 #undef GSWT_LAUNCH_PROJECT
-    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, live_cnt);
-}
-
-// exclusive scan of `n` u32 in `data` -> `out` (may alias), total -> *total_out.
-// ws: workspace of at least (n/1024 + 2) + (n/1048576 + 2) u32.
-void launch_scan(hipStream_t s, const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_out, uint32_t* ws)
-{
-    if (n == 0) { hipMemsetAsync(total_out, 0, 4, s); return; }
-    size_t nb1 = (n + 1023) / 1024;
-    if (nb1 == 1) {
-        if (in != out) hipMemcpyAsync(out, in, n * 4, hipMemcpyDeviceToDevice, s);
-        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(256), 0, s, out, n, total_out);
-        return;
-    }
-    uint32_t* p1 = ws;
-    hipLaunchKernelGGL(k_scan_reduce, dim3((uint32_t)nb1), dim3(256), 0, s, in, n, p1);
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(256), 0, s, p1, nb1, total_out);
-    hipLaunchKernelGGL(k_scan_apply, dim3((uint32_t)nb1), dim3(256), 0, s, in, out, n, p1);
+#undef GSWT_LAUNCH_PROJECT_S
+    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, live_cnt,
+                block_emit ? super_sums + 3u * n_super : (const uint32_t*)nullptr, super_sums + 4u * n_super, emit_cap);
 }
 
 void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* rects, const uint32_t* block_sums,
@@ -2253,7 +2426,7 @@ size_t radix_ws_zero_words(uint32_t n_cap, int key_bits)
 }
 
 int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n_cap,
-                const unsigned long long* n_ptr, int key_bits, uint32_t* ws, uint2* ranges = nullptr)
+                const unsigned long long* n_ptr, int key_bits, uint32_t* ws, uint2* ranges = nullptr, const uint32_t* krange = nullptr)
 {
     if (n_cap == 0) return 0;
     const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
@@ -2273,10 +2446,10 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
 #define GSWT_SORT_PASS(T)                                                                                                        \
-        GSWT_LAUNCH(k_radix_hist<T>, dim3(nblk), dim3(T), s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup); \
+        GSWT_LAUNCH(k_radix_hist<T>, dim3(nblk), dim3(T), s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup, krange); \
         if (nsup > kSupDirect) GSWT_LAUNCH(k_radix_supscan, dim3(64), dim3(256), s, gsup, gtot, nsup);                          \
         GSWT_LAUNCH(k_radix_scatter<T>, dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
-                           ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr)
+                           ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr, krange)
         if (threads == 512) { GSWT_SORT_PASS(512); }
         else { GSWT_SORT_PASS(256); }
 #undef GSWT_SORT_PASS
@@ -2285,22 +2458,25 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
     return cur;
 }
 
-// GSWT_ORDER_DEPTH front end: depth keys -> 32-bit radix sort -> per-block counts -> scan -> emission in depth order.
-// dk_a/dv_a/dk_b/dv_b: n_slots u32 each; ws: radix_ws_words(n_slots, 32) zeroed words; n_slots_dev: device u64 = n_slots.
-void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_slots, const unsigned long long* n_slots_dev, const uint2* rects,
-                       const float* depths, const uint32_t* block_sums, uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b,
-                       uint32_t* radix_ws, uint32_t* block_cnt, uint32_t* scan_ws, uint32_t* scratch_total, uint32_t pair_cap,
+// GSWT_ORDER_DEPTH front end (after k_project / k_totals): compaction of the emitting slots -> radix sort on the depth bits in use ->
+// per-block pair counts -> emission in depth order.  dk_a/dv_a/dk_b/dv_b: emit_cap u32 each; radix_ws: radix_ws_words(emit_cap, 32)
+// words whose radix_ws_zero_words(emit_cap, 32) first are zero; krange = (~0, 0) and super_cnt zero on entry (k_cull's zero region);
+// counters[4] = number of emitting slots (k_totals).  Every launch goes through GSWT_LAUNCH: the frame is graph-able.
+void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_chunks, uint32_t emit_cap, const uint2* rects,
+                       const float* depths, const uint32_t* block_sums, const uint32_t* block_emit, const uint32_t* emit_excl,
+                       uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b,
+                       uint32_t* radix_ws, uint32_t* krange, uint32_t* block_cnt, uint32_t* super_cnt, uint32_t pair_cap,
                        unsigned long long* counters, uint32_t* keys, uint32_t* vals)
 {
-    if (n_slots == 0) return;
-    const uint32_t nb = (n_slots + 255) / 256;
-    hipLaunchKernelGGL(k_depth_keys, dim3(nb), dim3(256), 0, s, rects, depths, block_sums, n_slots, dk_a, dv_a);
-    const int where = launch_sort(s, dk_a, dv_a, dk_b, dv_b, n_slots, n_slots_dev, 32, radix_ws);
-    const uint32_t* sk = where ? dk_b : dk_a;
-    const uint32_t* perm = where ? dv_b : dv_a;
-    hipLaunchKernelGGL(k_perm_counts, dim3(nb), dim3(256), 0, s, f, rects, sk, perm, n_slots, block_cnt);
-    launch_scan(s, block_cnt, block_cnt, nb, scratch_total, scan_ws);
-    hipLaunchKernelGGL(k_emit_perm, dim3(nb), dim3(256), 0, s, f, rects, sk, perm, n_slots, block_cnt, pair_cap, counters, keys, vals);
+    if (n_chunks == 0 || emit_cap == 0) return;
+    GSWT_LAUNCH(k_depth_keys, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), s, rects, depths, block_sums, block_emit, emit_excl, n_chunks,
+                emit_cap, (const unsigned long long*)counters, dk_a, dv_a, krange);
+    (void)launch_sort(s, dk_a, dv_a, dk_b, dv_b, emit_cap, counters + 4, 32, radix_ws, nullptr, krange);
+    const uint32_t nb = (emit_cap + 255u) / 256u;
+    GSWT_LAUNCH(k_perm_counts, dim3(nb), dim3(256), s, f, rects, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
+                (const unsigned long long*)(counters + 4), emit_cap, block_cnt, super_cnt);
+    GSWT_LAUNCH(k_emit_perm, dim3(nb), dim3(256), s, f, rects, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
+                (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)block_cnt, (const uint32_t*)super_cnt, pair_cap, counters, keys, vals);
 }
 
 // Builds every merged group's (gs_index | lod, map_id) list on the device.  keys/vals a,b: n_total u32 each;
@@ -2430,7 +2606,8 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 // k_totals alone on caller-provided sums (unit test of the 64-bit pair count)
 void launch_totals(hipStream_t s, uint32_t* super_sums, uint32_t n_super, unsigned long long* counters, uint32_t pair_cap)
 {
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, (uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded, int band_px)

@@ -26,7 +26,7 @@
 #include "host/gswt_surface.h"
 
 namespace gswt {
-int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr);
+int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr, const uint32_t* = nullptr);
 size_t radix_ws_words(uint32_t, int);
 int ctx_device(const gswt_ctx*);
 }  // namespace gswt
@@ -957,9 +957,11 @@ try {
     *out = nullptr;
     gswt_worker* w = new (std::nothrow) gswt_worker();
     if (!w) return GSWT_ERR_CAPACITY;
+    // (an exception thrown below -- std::string, std::mutex, allocation -- unwinds into GSWT_WCATCH: the guard destroys the half-built worker)
+    struct Guard { gswt_worker* w; ~Guard() { if (w) gswt_worker_destroy(w); } } guard{w};
     w->ctx = ctx;
     w->device = gswt::ctx_device(ctx);
-    auto bail = [&](int code) { gswt_worker_destroy(w); return code; };
+    auto bail = [&](int code) { guard.w = nullptr; gswt_worker_destroy(w); return code; };
     const size_t cells = (size_t)cfg->map_w * cfg->map_h;
     if (cells == 0 || cfg->n_lod == 0 || cfg->n_lod > 16 || cfg->n_tile == 0 || cfg->n_view == 0 || !cfg->lod_transition_dist || !cfg->tile_center || !cfg->tile_aabb ||
         !cfg->splat_count || !cfg->presort_dirs || !cfg->neighbors || cfg->surface_type > 2 || cfg->tile_sort_type > 3 || cfg->merge_type > 2 ||
@@ -983,7 +985,7 @@ try {
     d.merge_dist0 = cfg->merge_tile_dist[0]; d.merge_dist1 = cfg->merge_tile_dist[1];
     d.merge_dot_thr = cfg->merge_dot_threshold; d.merge_topk = cfg->merge_topk;
     int rc;
-#define WTRY(x) do { rc = (x); if (rc != GSWT_OK) { gswt_worker_destroy(w); return rc; } } while (0)
+#define WTRY(x) do { rc = (x); if (rc != GSWT_OK) return bail(rc); } while (0)
     if (cfg->height_map && cfg->hm_w && cfg->hm_h) WTRY(upload(w, w->height_map, cfg->height_map, (size_t)cfg->hm_w * cfg->hm_h));
     WTRY(upload(w, w->lod_dist, cfg->lod_transition_dist, cfg->n_lod));
     WTRY(upload(w, w->tile_center, cfg->tile_center, (size_t)cfg->n_tile * 3));
@@ -1002,7 +1004,7 @@ try {
     A(w->tiles.alloc(cells)); A(w->groups.alloc(cells)); A(w->members.alloc(cells)); A(w->draws.alloc(cells));
     for (auto& h : w->hs) { A(h.tiles.alloc(cells)); A(h.groups.alloc(cells)); A(h.members.alloc(cells)); A(h.draws.alloc(cells)); }
     A(w->h_counts.alloc(C_COUNT));
-    if (e != hipSuccess) { gswt_worker_destroy(w); return GSWT_ERR_HIP; }
+    if (e != hipSuccess) return bail(GSWT_ERR_HIP);
     // (stream-ordered: the worker's stream is non-blocking and does not wait for null-stream memsets)
     A(hipMemsetAsync(w->st.p, 0, cells * sizeof(gswt_cell_state), w->stream)); A(hipMemsetAsync(w->head_len.p, 0, cells * 4, w->stream));
     A(hipMemsetAsync(w->counts.p, 0, C_COUNT * 4, w->stream));
@@ -1021,23 +1023,22 @@ try {
         h.release();
     }
     A(hipStreamSynchronize(w->stream));
-    if (e != hipSuccess) { gswt_worker_destroy(w); return GSWT_ERR_HIP; }
+    if (e != hipSuccess) return bail(GSWT_ERR_HIP);
     d.sp.height_map = w->height_map.p; d.lod_dist = w->lod_dist.p; d.tile_center = w->tile_center.p; d.tile_aabb = w->tile_aabb.p;
     d.presort_dirs = w->presort_dirs.p; d.splat_count = w->splat_count.p; d.nb = w->nb.p; d.cell = w->cell.p; d.st = w->st.p;
     d.head_off = w->head_off.p; d.head_len = w->head_len.p; d.pool = w->pool.p; d.counts = w->counts.p;
     // LDS budgets: the edge-merge tables (9 B per cell) must fit; the graph tables do for small maps and live in global memory otherwise
     w->lds_merge = (3 * cells + 3 * (cells / 2 + 1)) * sizeof(uint16_t);
-    if (cfg->merge_type == MERGE_EDGE && w->lds_merge > 156u * 1024u) { gswt_worker_destroy(w); return GSWT_ERR_CAPACITY; }
+    if (cfg->merge_type == MERGE_EDGE && w->lds_merge > 156u * 1024u) return bail(GSWT_ERR_CAPACITY);
     w->lds_graph = graph_tab_bytes((int)cells);
     w->graph_in_lds = w->lds_graph <= 140u * 1024u;     // beside the kernel's 8 KB of static LDS
-    if (w->lds_merge > 48u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_merge) != hipSuccess) {
-        gswt_worker_destroy(w); return GSWT_ERR_HIP;
-    }
+    if (w->lds_merge > 48u * 1024u && hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_merge), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_merge) != hipSuccess)
+        return bail(GSWT_ERR_HIP);
     if (w->graph_in_lds && w->lds_graph > 48u * 1024u &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_order_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_graph) != hipSuccess) {
-        gswt_worker_destroy(w); return GSWT_ERR_HIP;
-    }
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_w_order_seq<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)w->lds_graph) != hipSuccess)
+        return bail(GSWT_ERR_HIP);
 #undef WTRY
+    guard.w = nullptr;
     *out = w;
     return GSWT_OK;
 } GSWT_WCATCH

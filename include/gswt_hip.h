@@ -172,7 +172,8 @@ GSWT_API int gswt_set_stream(gswt_ctx *ctx, void *hip_stream);
 enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
        GSWT_OPT_SEGMENT = 3 /* pairs per compositor work item, multiple of 256 (default 1536; dense scenes with the early-out on
                                gain from up to 4096: a segment cannot skip what the segments in front of it already saturated) */,
-       GSWT_OPT_DEBUG_FLAGS = 4 /* ablation bits for profiling; output is wrong when nonzero */,
+       GSWT_OPT_DEBUG_FLAGS = 4 /* ablation bits for profiling (the image is wrong when nonzero): only the measurement build
+                                   (-DGSWT_EXPERIMENTS, `make variants`) has them; the product library rejects a nonzero value */,
        GSWT_OPT_TIMING = 5 /* hipEvent timing: 0 none, 1 frame + k_composite, 2 every stage (default) */,
        GSWT_OPT_PAIR_CAP = 6 /* test hook: pin the pair-buffer capacity to `value` pairs until a frame overflows it (0: automatic) */,
        GSWT_OPT_NO_MERGE_REUSE = 7 /* gswt_set_draws_merge_groups re-sorts every merged group at every sort event instead of copying
@@ -185,8 +186,14 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
        GSWT_OPT_GRAPH = 9 /* 1: a frame's kernel launches are replayed as ONE hipGraphLaunch per frame slot (a chain of kernel nodes;
                              only the nodes whose grid or arguments changed since the slot's previous frame are updated in the
                              executable graph) instead of ~13 separate launches: less submitting-thread time per frame, same
-                             kernels, same results.  Frames with GSWT_OPT_TIMING > 0, GSWT_ORDER_DEPTH or debug varyings
-                             launch as before.  0 (default): separate launches */ };
+                             kernels, same results.  Frames with GSWT_OPT_TIMING > 0 or debug varyings
+                             launch as before.  0 (default): separate launches */,
+       GSWT_OPT_STRICT_VS = 10 /* 1: the vertex stage evaluates gswt.wgsl:152-258,260-265,402-419 operator by operator (one correctly rounded
+                                  binary32 operation per written `*` `+` `-` `/`, full matrix products, no fused multiply-add) instead of the
+                                  default rounding sequence (fma chains, one reciprocal per quotient: also legal WGSL).  Per splat
+                                  bit-identical to the CPU checker's strict mode; see DESIGN.md section 4 for what the two differ by */,
+       GSWT_OPT_EMIT_CAP = 11 /* test hook: start the GSWT_ORDER_DEPTH sort capacity (splats that emit pairs) at `value`; a frame that
+                                 outgrows it is re-run with more room, like a pair overflow (0: sized from the next draw list) */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

@@ -524,8 +524,10 @@ static void debug_draw_color(const orc_scene *s, const orc_tile *u, const float 
 /* image are both measured against (tests/test_strict_oracle*.py).             */
 /* Process-wide switch; set it before orc_render / orc_project_draws.          */
 /* ------------------------------------------------------------------------- */
+/* 0 = canonical sequence v2 everywhere; 1 = strict vertex AND fragment stage (the anchor image); 2 = strict vertex stage with the  */
+/* v2 fragment sequence F1..F4 -- what the HIP path computes with GSWT_OPT_STRICT_VS (its compositor always evaluates F1..F4).   */
 static int g_strict = 0;
-ORC_API void orc_set_strict(int on) { g_strict = on ? 1 : 0; }
+ORC_API void orc_set_strict(int on) { g_strict = on == 2 ? 2 : (on ? 1 : 0); }
 ORC_API int orc_get_strict(void) { return g_strict; }
 
 /* vs_main, gswt.wgsl:27-422, every draw_mode.  Canonical float sequence "A1..A10"
@@ -815,7 +817,7 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
                         const uint32_t *tex, uint32_t gs_index, uint32_t map_id, uint32_t lod_id,
                         const float *hmap, int hm_w, int hm_h, orc_splat *out)
 {
-    return project_impl(cam, s, u, tex, gs_index, map_id, lod_id, hmap, hm_w, hm_h, out, g_strict);
+    return project_impl(cam, s, u, tex, gs_index, map_id, lod_id, hmap, hm_w, hm_h, out, g_strict != 0);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1079,7 +1081,7 @@ ORC_API int orc_render(const orc_camera *cam, const orc_scene *scene, const uint
                 int y_lo = band * 16, y_hi = y_lo + 16 > H ? H : y_lo + 16;
                 for (uint64_t i = band_off[band]; i < band_off[band + 1]; i++) {
                     uint64_t k = blist[i];
-                    if (g_strict) raster_over_strict(&sp[k], scene->splat_scale, W, H, y_lo, y_hi, bg_depth, out_rgba);
+                    if (g_strict == 1) raster_over_strict(&sp[k], scene->splat_scale, W, H, y_lo, y_hi, bg_depth, out_rgba);
                     else raster_over(&sp[k], &fs[k], W, H, y_lo, y_hi, bg_depth, out_rgba);
                 }
             }
@@ -1126,9 +1128,11 @@ static inline int cover_strict(const orc_splat *sp, float splat_scale, int W, in
  * counts[0] = splats visible in exactly one mode, [1] = (pixel, splat) decisions that differ, [2] = marked pixels,
  * [3] = splats visible in both modes.  A marked pixel may differ by up to alpha * e^-4 per flipped splat; an unmarked pixel
  * blends the same splats in both modes and differs only by the continuous part of the arithmetic. */
-ORC_API int orc_compare_modes(const orc_camera *cam, const orc_scene *scene, const uint32_t *tex,
-                              const orc_draw *draws, int n_draws, const float *hmap, int hm_w, int hm_h,
-                              int W, int H, const float *bg_depth, int n_threads, uint8_t *mask, uint64_t counts[4])
+/* vs_a_strict: side A's vertex stage (0 = v2, 1 = strict); its fragment stage is always F1..F4.  Side B is strict throughout.
+ * (0: the product's default against the shader text; 1: the product with GSWT_OPT_STRICT_VS against the shader text.) */
+ORC_API int orc_compare_modes2(const orc_camera *cam, const orc_scene *scene, const uint32_t *tex,
+                               const orc_draw *draws, int n_draws, const float *hmap, int hm_w, int hm_h,
+                               int W, int H, const float *bg_depth, int n_threads, int vs_a_strict, uint8_t *mask, uint64_t counts[4])
 {
     if (W <= 0 || H <= 0) return -1;
 #ifdef _OPENMP
@@ -1147,7 +1151,7 @@ ORC_API int orc_compare_modes(const orc_camera *cam, const orc_scene *scene, con
             uint32_t lid = dr->lod_id ? dr->lod_id[j] : 0u;
             orc_splat a, b;
             orc_frag_setup fa, fb;
-            project_impl(cam, scene, &dr->tile, tex, dr->gs_index[j], mid, lid, hmap, hm_w, hm_h, &a, 0);
+            project_impl(cam, scene, &dr->tile, tex, dr->gs_index[j], mid, lid, hmap, hm_w, hm_h, &a, vs_a_strict != 0);
             project_impl(cam, scene, &dr->tile, tex, dr->gs_index[j], mid, lid, hmap, hm_w, hm_h, &b, 1);
             fa.ok = fb.ok = 0;
             if (a.visible) { frag_setup(&a, scene->splat_scale, (float)W, (float)H, &fa); if (!fa.ok) a.visible = 0; }
@@ -1176,6 +1180,13 @@ ORC_API int orc_compare_modes(const orc_camera *cam, const orc_scene *scene, con
     for (size_t i = 0; i < (size_t)W * (size_t)H; i++) marked += mask[i];
     counts[0] = one_mode; counts[1] = flips; counts[2] = marked; counts[3] = both;
     return 0;
+}
+
+ORC_API int orc_compare_modes(const orc_camera *cam, const orc_scene *scene, const uint32_t *tex,
+                              const orc_draw *draws, int n_draws, const float *hmap, int hm_w, int hm_h,
+                              int W, int H, const float *bg_depth, int n_threads, uint8_t *mask, uint64_t counts[4])
+{
+    return orc_compare_modes2(cam, scene, tex, draws, n_draws, hmap, hm_w, hm_h, W, H, bg_depth, n_threads, 0, mask, counts);
 }
 
 /* Vertex stage only, for per-splat parity checks: out[k] for every instance. */

@@ -137,17 +137,25 @@ def lib():
         _lib.orc_compare_modes.restype = C.c_int
         _lib.orc_compare_modes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                            C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _lib.orc_compare_modes2.restype = C.c_int
+        _lib.orc_compare_modes2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return _lib
 
 
 class strict:
     """Context manager: the oracle evaluates gswt.wgsl:152-258,402-435 operator by operator (IEEE `/`, no fused
     multiply-add, exact quad interpolation) instead of the canonical sequence v2 the kernels reproduce (gswt_oracle.c,
-    "STRICT mode").  Process-wide switch."""
+    "STRICT mode").  Process-wide switch.
+    fragment=False: only the vertex stage is strict and the fragment stage stays the sequence F1..F4 -- what the HIP path computes
+    with GSWT_OPT_STRICT_VS (its compositor always evaluates F1..F4)."""
+
+    def __init__(self, fragment: bool = True):
+        self.mode = 1 if fragment else 2
 
     def __enter__(self):
         self.prev = lib().orc_get_strict()
-        lib().orc_set_strict(1)
+        lib().orc_set_strict(self.mode)
         return self
 
     def __exit__(self, *exc):
@@ -570,18 +578,20 @@ def render(cam: Camera176, scene: Scene160, tex: np.ndarray, draws, width: int, 
 
 
 def compare_modes(cam: Camera176, scene: Scene160, tex: np.ndarray, draws, width: int, height: int, *, height_map=None,
-                  bg_depth=None, n_threads: int = 0):
+                  bg_depth=None, n_threads: int = 0, strict_vs: bool = False):
     """Where the canonical sequence v2 and the strict (shader-text) evaluation DECIDE differently (orc_compare_modes):
-    returns (mask [H, W] bool of the pixels holding at least one flipped coverage / cull decision, counts dict)."""
+    returns (mask [H, W] bool of the pixels holding at least one flipped coverage / cull decision, counts dict).
+    strict_vs: the first side's vertex stage is the strict one too (the HIP path with GSWT_OPT_STRICT_VS); what is left to flip is
+    the fragment stage's coverage test F4 against the exact quad interpolation."""
     tex = np.ascontiguousarray(tex, dtype=np.uint32)
     arr, keep = _pack_draws(draws)
     hm = np.ascontiguousarray(height_map, dtype=np.float32) if height_map is not None else None
     bgd = np.ascontiguousarray(bg_depth, dtype=np.float32) if bg_depth is not None else None
     mask = np.zeros((height, width), dtype=np.uint8)
     counts = np.zeros(4, dtype=np.uint64)
-    rc = lib().orc_compare_modes(C.byref(cam), C.byref(scene), _ptr(tex), arr, len(draws), _ptr(hm),
-                                 hm.shape[1] if hm is not None else 0, hm.shape[0] if hm is not None else 0,
-                                 width, height, _ptr(bgd), n_threads, _ptr(mask), _ptr(counts))
+    rc = lib().orc_compare_modes2(C.byref(cam), C.byref(scene), _ptr(tex), arr, len(draws), _ptr(hm),
+                                  hm.shape[1] if hm is not None else 0, hm.shape[0] if hm is not None else 0,
+                                  width, height, _ptr(bgd), n_threads, 1 if strict_vs else 0, _ptr(mask), _ptr(counts))
     if rc != 0:
         raise RuntimeError(f"orc_compare_modes failed: {rc}")
     return mask.astype(bool), {"visible_in_one_mode": int(counts[0]), "decision_flips": int(counts[1]),

@@ -1,0 +1,133 @@
+"""GSWT_ORDER_DEPTH -- the "global radix depth sort" BASELINE.json's north_star names -- at BASELINE sizes.
+
+The reference orders TILES back to front and each tile's presorted list (wangtile.rs:489-499, scene.rs:685-695): that is
+GSWT_ORDER_REFERENCE.  GSWT_ORDER_DEPTH composites every visible splat of the frame in true depth order (stable: equal depths keep
+the reference order); the CPU checker's order_mode 1 does the same with a stable merge sort (oracle/gswt_oracle.c orc_render).
+Checked here: c3 and the dense c3d at 1920x1080 against the checker (image <= 1e-4, visible / pair counts equal), with and without
+the early-out; the 8 column bands of c4's layout (bitwise union); the frame as one hipGraph; the depth sort's own capacity overflow."""
+import numpy as np
+import pytest
+
+from gswt_renderer_amd import _lib as L
+from oracle import gswt_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _setup(renderer, name):
+    import bench
+    w, wang, cu, vp, sort = bench.build_workload(name)
+    W, Hh = w["width"], w["height"]
+    su = wang.scene_uniforms()
+    hm = wang.height_map() if int(wang.user.surface_type) == 1 else None
+    wang.upload_to(renderer)
+    renderer.configure(hm)
+    renderer.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
+    tex, draws = bench.oracle_draws(wang, sort, vp)
+    ocu = orc.Camera176.from_buffer_copy(bytes(cu))
+    osu = orc.Scene160.from_buffer_copy(bytes(su))
+    return dict(W=W, H=Hh, cu=cu, su=su, hm=hm, tex=tex, draws=draws, ocu=ocu, osu=osu)
+
+
+@pytest.mark.parametrize("name", ["c3", "c3d"])
+def test_depth_order_at_baseline_size(renderer, name):
+    s = _setup(renderer, name)
+    W, Hh = s["W"], s["H"]
+    ref_d, st = orc.render(s["ocu"], s["osu"], s["tex"], s["draws"], W, Hh, height_map=s["hm"], order_mode=1)
+    ref_r, _ = orc.render(s["ocu"], s["osu"], s["tex"], s["draws"], W, Hh, height_map=s["hm"], order_mode=0)
+    assert st["n_visible"] > 1_000_000
+    img = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+    t = renderer.timings()
+    assert t["n_visible"] == st["n_visible"] and t["n_pairs"] == st["n_pairs16"]
+    assert H.max_abs_diff(img, ref_d) <= TOL
+    # what bench.py --order depth times: the early-out at 1e-5
+    img_e = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH, transmittance_eps=1e-5)
+    assert H.max_abs_diff(img_e, ref_d) <= TOL
+    # the mode is not a no-op: neighbouring Wang tiles interpenetrate, and a tile's presorted list is only ordered along one of nine
+    # directions, so the reference order and the true depth order give different images
+    d = H.max_abs_diff(ref_d, ref_r)
+    print(f"{name}: depth order vs reference order L-inf {d:.3e}; GPU vs checker (depth) {H.max_abs_diff(img, ref_d):.3e}")
+    assert d > 1e-3
+    # the reference order on the same context right after: the two modes share every buffer but the depth sort's
+    img_r = renderer.render(s["cu"], s["su"], W, Hh)
+    assert H.max_abs_diff(img_r, ref_r) <= TOL
+    if name == "c3":
+        # c4's layout in depth order: 8 column bands, each with its own cull and its own (smaller) depth sort; bitwise the frame
+        n = 8
+        bw = renderer.shard_cols_padded(W, n)
+        uni = np.zeros_like(img)
+        for r in range(n):
+            part = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH, shard=(r, n, "cols"))
+            x0, x1 = r * bw, min(W, (r + 1) * bw)
+            uni[:, x0:x1] = part[:, :x1 - x0]
+        assert np.array_equal(uni, img)
+        # interleaved rows, three ranks
+        rows = renderer.shard_rows_padded(Hh, 3)
+        uni = np.zeros_like(img)
+        for r in range(3):
+            part = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH, shard=(r, 3))
+            for ty in range(r, (Hh + 15) // 16, 3):
+                y0, y1 = ty * 16, min(Hh, ty * 16 + 16)
+                uni[y0:y1] = part[(ty // 3) * 16:(ty // 3) * 16 + (y1 - y0)]
+        assert rows >= 16 and np.array_equal(uni, img)
+
+
+def test_depth_order_frames_replay_as_one_graph(renderer):
+    """No host word enters the depth-ordered chain any more (the sort reads its item count and key range on the device), so
+    GSWT_OPT_GRAPH covers it: same bits as launch by launch, over a moving camera, all frame slots in flight."""
+    import torch
+    import bench
+    from gswt_renderer_amd import host, workloads
+    s = _setup(renderer, "c3")
+    W, Hh = s["W"], s["H"]
+    cam = workloads.camera_for("c3")
+    cams = []
+    for k in range(6):
+        pos = (cam["pos"][0] + 0.15 * k, cam["pos"][1] + 0.4 * k, cam["pos"][2])
+        tgt = (cam["target"][0] + 0.15 * k, cam["target"][1] + 0.4 * k, cam["target"][2] - 0.05 * k)
+        cams.append(host.camera_uniforms(pos, tgt, cam["up"], cam["fovy"], cam["near"], cam["far"], W, Hh)[0])
+    outs = [torch.empty((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
+    renderer.set_option(L.GSWT_OPT_TIMING, 0)
+    try:
+        want = []
+        for cu, o in zip(cams, outs):
+            renderer.render_wait(renderer.render_async(cu, s["su"], W, Hh, o.data_ptr(), order_mode=L.GSWT_ORDER_DEPTH, transmittance_eps=1e-5))
+            want.append(o.cpu().numpy().copy())
+        g0 = renderer.graph_stats()
+        renderer.set_option(L.GSWT_OPT_GRAPH, 1)
+        tickets = []
+        for cu, o in zip(cams, outs):
+            o.zero_()
+            if len(tickets) >= renderer.frame_slots():
+                renderer.render_wait(tickets.pop(0))
+            tickets.append(renderer.render_async(cu, s["su"], W, Hh, o.data_ptr(), order_mode=L.GSWT_ORDER_DEPTH, transmittance_eps=1e-5))
+        for tk in tickets:
+            renderer.render_wait(tk)
+        g1 = renderer.graph_stats()
+    finally:
+        renderer.set_option(L.GSWT_OPT_GRAPH, 0)
+        renderer.set_option(L.GSWT_OPT_TIMING, 2)
+    assert g1[0] - g0[0] == len(cams)                   # every frame went through hipGraphLaunch
+    for a, o in zip(want, outs):
+        assert np.array_equal(a, o.cpu().numpy())
+    assert not np.array_equal(want[0], want[-1])
+
+
+def test_depth_sort_capacity_overflow_is_rerun(renderer):
+    """The depth sort is launched for a capacity (emitting slots); a frame that outgrows it is flagged on the device and re-run with
+    more room, like a pair overflow: the image never shows a partially sorted frame."""
+    s = _setup(renderer, "c1")
+    W, Hh = s["W"], s["H"]
+    ref_d, st = orc.render(s["ocu"], s["osu"], s["tex"], s["draws"], W, Hh, order_mode=1)
+    renderer.set_option(L.GSWT_OPT_EMIT_CAP, 256)
+    try:
+        img = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+    finally:
+        renderer.set_option(L.GSWT_OPT_EMIT_CAP, 0)
+    t = renderer.timings()
+    assert st["n_visible"] > 10000 and t["n_visible"] == st["n_visible"] and t["n_pairs"] == st["n_pairs16"]
+    assert H.max_abs_diff(img, ref_d) <= TOL
+    img2 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)       # capacity sized from the draw list again
+    assert np.array_equal(img, img2)

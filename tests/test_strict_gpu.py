@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from gswt_renderer_amd import _lib as L
+from oracle import gswt_oracle as orc
 from tests.test_strict_oracle import both_modes, check_bounds
 
 pytestmark = pytest.mark.gpu
@@ -46,3 +47,53 @@ def test_gpu_vs_strict_full_error_stack(renderer, name):
     r = check_bounds(d, img, d["strict"], extra=1.1e-5, **lim)
     print(f"{name}: GPU (eps 1e-5) vs strict L-inf {r['linf']:.3e}, unmarked {r['linf_unmarked']:.3e}, "
           f"{r['over_1e4_unmarked']} unmarked pixels above 1e-4, {r['marked']} marked")
+
+
+@pytest.mark.parametrize("name", ["c3", "c3h", "c5"])
+def test_gpu_strict_vertex_stage_meets_1e4_off_the_ellipse_borders(renderer, name):
+    """GSWT_OPT_STRICT_VS: with the vertex stage evaluated as the shader text writes it, what is left between the HIP image and the strict
+    image is (a) the fragment stage's |p|^2 <= 4 decisions that fall the other way (inherent to two rasterisations: F4 evaluates the
+    inverse affine map tile-locally in binary32, the strict image interpolates the quad exactly), and (b) off those pixels the
+    continuous terms: the early-out cut, blend order, exp2 / log2.  (b) meets north_star's 1e-4 (+ the 1e-5 cut) at c3, c3h AND c5 --
+    the thin-ellipse term of the default sequence v2 (2.8e-4 / 4.6e-4 / 1.5e-3) came from the vertex stage."""
+    import bench
+    import torch
+    w, wang, cu, vp, sort = bench.build_workload(name)
+    W, H = w["width"], w["height"]
+    su = wang.scene_uniforms()
+    hm = wang.height_map() if int(wang.user.surface_type) == 1 else None
+    tex, draws = bench.oracle_draws(wang, sort, vp)
+    ocu = orc.Camera176.from_buffer_copy(bytes(cu))
+    osu = orc.Scene160.from_buffer_copy(bytes(su))
+    with orc.strict():
+        strict_img, sts = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
+    with orc.strict(fragment=False):
+        mixed_img, stm = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
+    mask, counts = orc.compare_modes(ocu, osu, tex, draws, W, H, height_map=hm, strict_vs=True)
+    wang.upload_to(renderer)
+    renderer.configure(hm)
+    renderer.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
+    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    renderer.set_option(L.GSWT_OPT_STRICT_VS, 1)
+    try:
+        renderer.render_wait(renderer.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
+        t = renderer.timings()
+    finally:
+        renderer.set_option(L.GSWT_OPT_STRICT_VS, 0)
+    img = out.cpu().numpy()
+    del out
+    torch.cuda.empty_cache()
+    assert t["n_visible"] == sts["n_visible"] == stm["n_visible"] and t["n_pairs"] == stm["n_pairs16"]
+    assert counts["visible_in_one_mode"] == 0
+    # the product's contract in this mode: the same operation sequence on both sides (strict vertex stage, F1..F4)
+    assert np.abs(img.astype(np.float64) - mixed_img).max() <= 1e-4
+    diff = np.abs(img.astype(np.float64) - strict_img).max(axis=2)
+    n = diff.size
+    off = diff[~mask]
+    over = int((off > 1e-4 + 1.1e-5).sum())
+    print(f"{name}: GPU (strict VS, eps 1e-5) vs strict image: L-inf {diff.max():.3e}; {int(mask.sum())} of {n} pixels hold a flipped coverage "
+          f"decision ({counts['decision_flips']} decisions); elsewhere L-inf {off.max():.3e}, {over} pixels above 1e-4 + cut")
+    assert mask.sum() <= 2e-3 * n
+    assert off.max() <= 1e-4 + 1.1e-5, off.max()
+    if mask.any():
+        assert diff[mask].max() <= 2 * float(np.exp(-4.0)) + 1e-3

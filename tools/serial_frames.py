@@ -19,11 +19,14 @@ if os.environ.get("GSWT_SEGMENT"):                 # kernel-variant sweeps: pair
     r.set_option(L.GSWT_OPT_SEGMENT, int(os.environ["GSWT_SEGMENT"], 0))
 if os.environ.get("GSWT_DBG_FLAGS"):
     r.set_option(L.GSWT_OPT_DEBUG_FLAGS, int(os.environ["GSWT_DBG_FLAGS"], 0))
+if os.environ.get("GSWT_STRICT_VS"):
+    r.set_option(L.GSWT_OPT_STRICT_VS, 1)
+order = L.GSWT_ORDER_DEPTH if os.environ.get("GSWT_ORDER", "") == "depth" else L.GSWT_ORDER_REFERENCE
 wang.upload_to(r)
 r.configure(wang.height_map() if int(wang.user.surface_type) == 1 else None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
 for i in range(n):
-    r.render_wait(r.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
+    r.render_wait(r.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5, order_mode=order))
 print("done", r.timings()["n_pairs"])
