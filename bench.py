@@ -81,7 +81,7 @@ def oracle_draws(wang, sort, vp, culling_dist=1.0):
     return tex, draws
 
 
-def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, height_map=None, order_mode=0):
+def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, height_map=None, order_mode=0, v2=False):
     """Times the CPU oracle (oracle/gswt_oracle.c, OpenMP) on ONE frame of the same workload."""
     from oracle import gswt_oracle as orc
     tex, draws = oracle_draws(wang, sort, vp, culling_dist)
@@ -98,7 +98,8 @@ def cpu_baseline(wang, sort, cu, vp, su, W, H, culling_dist=1.0, passes=None, he
         bg = orc.skybox_render(cam, faces, W, H)
         bgd = np.ones((H, W), np.float32)
         orc.proxy_render(orc.Proxy224.from_buffer_copy(bytes(pu)), W, H, bg, bgd, mips)
-    img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads, bg_rgba=bg, bg_depth=bgd, height_map=height_map, order_mode=order_mode)
+    with (orc.v2() if v2 else orc.strict(fragment=False)):      # the same vertex-stage sequence as the GPU frame it is compared with
+        img, st = orc.render(ocu, osu, tex, draws, W, H, n_threads=n_threads, bg_rgba=bg, bg_depth=bgd, height_map=height_map, order_mode=order_mode)
     dt = time.perf_counter() - t0
     return img, st, dt, n_threads
 
@@ -279,7 +280,8 @@ def main():
     ap.add_argument("--static-steps", type=int, default=100, help="flypath mode: frames of the static-camera comparison run (0: skip)")
     ap.add_argument("--order", default="reference", choices=["reference", "depth"], help="reference: tiles back to front, presorted lists (wangtile.rs:489-499, "
                     "scene.rs:685-695); depth: GSWT_ORDER_DEPTH, every visible splat of the frame in true depth order (the global radix depth sort)")
-    ap.add_argument("--strict-vs", action="store_true", help="GSWT_OPT_STRICT_VS: the vertex stage operator by operator as gswt.wgsl:152-258 writes it")
+    ap.add_argument("--vertex-stage", default="strict", choices=["strict", "v2"], help="strict (default, GSWT_OPT_STRICT_VS = 1): vs_main operator by operator as "
+                    "gswt.wgsl:152-258 writes it; v2: the fma-chain / single-reciprocal rounding sequence (the default until round 3)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU baseline: fly-path frames are rendered by the oracle until this much time has gone (at most 24 frames)")
     args = ap.parse_args()
     if args.timing_every <= 0:
@@ -325,8 +327,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     r.set_stream(stream.cuda_stream)                    # ctx stream: fences, all-gather and unshard are ordered on it
     r.set_option(L.GSWT_OPT_TIMING, args.timing)
-    if args.strict_vs:
-        r.set_option(L.GSWT_OPT_STRICT_VS, 1)
+    r.set_option(L.GSWT_OPT_STRICT_VS, 1 if args.vertex_stage == "strict" else 0)
     order_mode = L.GSWT_ORDER_DEPTH if args.order == "depth" else L.GSWT_ORDER_REFERENCE
     wang.upload_to(r)
     hmap = wang.height_map() if int(wang.user.surface_type) == 1 else None
@@ -732,7 +733,7 @@ def main():
                        "map": [2 * w["half"][0] + 1, 2 * w["half"][1] + 1],
                        "width": W, "height": H, "n_draws": int(last["n_draws"]), "n_instanced": int(last["n_instanced"]),
                        "n_visible": int(last["n_visible"]), "n_pairs_mean": int(P), "order": args.order,
-                       "vertex_stage": "strict (GSWT_OPT_STRICT_VS: gswt.wgsl:152-258 operator by operator)" if args.strict_vs else "canonical sequence v2",
+                       "vertex_stage": "strict (gswt.wgsl:152-258 operator by operator; the default)" if args.vertex_stage == "strict" else "rounding sequence v2 (GSWT_OPT_STRICT_VS = 0)",
                        "transmittance_eps": args.t_eps, "skybox_proxy_passes": bool(use_passes),
                        "parallelism": (f"screen-tile-column bands x{world} (projection culled per band) + RCCL all-gather; no hardware 1 -> N curve has been "
                                        "measured by the builder (one-GPU boxes only): this line is the first" if world > 1 else "single GPU")},
@@ -806,7 +807,7 @@ def main():
                 if use_passes:
                     pu.view[:] = cu_c.view[:]; pu.projection[:] = cu_c.projection[:]; pu.cam_pos[:] = cu_c.cam_pos[:]; pu.center_coord[:] = su_c.center_coord[:]
                 img_cpu, stc, cdt, nthr = cpu_baseline(wang, sort_c, cu_c, vp_c, su_c, W, H, passes=(faces, mips, pu) if use_passes else None, height_map=hmap,
-                                                       order_mode=1 if args.order == "depth" else 0)
+                                                       order_mode=1 if args.order == "depth" else 0, v2=args.vertex_stage == "v2")
                 times.append(cdt)
                 if n_done == 0:
                     # ... and the GPU renders exactly that draw list once more for the comparison

@@ -35,7 +35,7 @@ void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, u
 size_t radix_ws_words(uint32_t, int);
 size_t radix_ws_zero_words(uint32_t, int);
 void launch_emit_depth(hipStream_t, const Frame&, uint32_t, uint32_t, const uint2*, const float*, const uint32_t*, const uint32_t*, const uint32_t*,
-                       uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
+                       uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                        unsigned long long*, uint32_t*, uint32_t*);
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
@@ -305,7 +305,9 @@ struct gswt_ctx {
     std::vector<hipStream_t> pad_streams;  // never used: they steer the hardware-queue assignment (gswt_create)
     int opt_defer_swap = 0;
     int opt_graph = 0;
-    int opt_strict_vs = 0;                 // GSWT_OPT_STRICT_VS: k_project evaluates vs_main operator by operator (gswt.wgsl:152-258)
+    // GSWT_OPT_STRICT_VS (default ON since round 4: k_project<.,.,STRICT> costs +1 us of 71 at c3 and nothing in frames/s): vs_main is
+    // evaluated operator by operator as gswt.wgsl:152-258 writes it; 0 selects the fma-chain / single-reciprocal sequence v2
+    int opt_strict_vs = 1;
     unsigned long long stat_graph_launches = 0, stat_graph_rebuilds = 0, stat_graph_node_updates = 0;
     int pending_frames = 0;                // GSWT_OPT_DEFER_SWAP >= 2: frames still to be submitted on the old set
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
@@ -1380,7 +1382,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // radix workspaces: the zeroed parts of BOTH sorts first (group rows, digit totals), the per-workgroup rows (written in full) behind
     const size_t rz_pair = radix_ws_zero_words(cap, key_bits), rz_depth = depth_order ? radix_ws_zero_words(ecap, 32) : 0;
     const size_t rw_pair = radix_ws_words(cap, key_bits), rw_depth = depth_order ? radix_ws_words(ecap, 32) : 0;
-    if (depth_order) HIP_TRY(c, sl.depth_ws.ensure_roomy(4 * (size_t)ecap + ((size_t)ecap / 256 + 2) + 64));
+    // depth sort: key / index ping-pong (4 x ecap), compact rects (2 x ecap, 8-byte aligned at the front) and slots (ecap), block counts
+    if (depth_order) HIP_TRY(c, sl.depth_ws.ensure_roomy(7 * (size_t)ecap + ((size_t)ecap / 256 + 2) + 64));
     // one contiguous u32 region whose head k_cull clears: [counters: 16][super_sums: n_super2][psuper][pair sort: zeroed part .. rows][depth sort likewise]
     HIP_TRY(c, sl.ghist.ensure_roomy(16 + n_super2 + n_psuper + rw_pair + rw_depth + 16));
     uint32_t* const zero_a = sl.ghist.p;
@@ -1423,8 +1426,10 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // cleared per frame: counters, super-group sums and the atomically accumulated part of the sort's tables.  The pair sort's zeroed
     // part is contiguous with the head; the depth sort's (behind the pair sort's rows) is the kernel's second clear range.
     const size_t n_zero_a = 16 + n_super2 + n_psuper + rz_pair;
-    uint32_t* const dw = sl.depth_ws.p;
-    uint32_t* const d_block_cnt = depth_order ? dw + 4 * (size_t)ecap : nullptr;
+    uint32_t* const d_crect = sl.depth_ws.p;
+    uint32_t* const dw = depth_order ? d_crect + 2 * (size_t)ecap : nullptr;
+    uint32_t* const d_cslot = depth_order ? dw + 4 * (size_t)ecap : nullptr;
+    uint32_t* const d_block_cnt = depth_order ? d_cslot + ecap : nullptr;
     uint32_t* const d_block_emit = depth_order ? sl.block_sums.p + D.n_chunks : nullptr;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks * (depth_order ? 2u : 1u), sl.live_cnt.p, sl.live_tab.p,
@@ -1440,7 +1445,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         // counters[4] = emitting slots (k_totals; the depth sort reads its item count there, counters[6] = its overflow word stays 0),
         // counters[5] = the key range (two u32 words, k_depth_keys)
         launch_emit_depth(s, f, D.n_chunks, ecap, sl.rects.p, sl.depths.p, sl.block_sums.p, d_block_emit, d_super + 4 * n_super,
-                          dw, dw + ecap, dw + 2 * (size_t)ecap, dw + 3 * (size_t)ecap, d_radix_depth, reinterpret_cast<uint32_t*>(d_counters + 5),
+                          dw, dw + ecap, dw + 2 * (size_t)ecap, dw + 3 * (size_t)ecap, reinterpret_cast<uint2*>(d_crect), d_cslot, d_radix_depth,
+                          reinterpret_cast<uint32_t*>(d_counters + 5),
                           d_block_cnt, d_psuper, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     }
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));

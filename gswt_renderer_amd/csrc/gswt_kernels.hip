@@ -1481,9 +1481,10 @@ __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ re
                                                     const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_emit,
                                                     const uint32_t* __restrict__ emit_excl, uint32_t n_chunks, uint32_t emit_cap,
                                                     const unsigned long long* __restrict__ counters,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ krange)
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ crect,
+                                                    uint32_t* __restrict__ cslot, uint32_t* __restrict__ krange)
 {
-    __shared__ uint32_t s_w[8];
+    __shared__ uint32_t s_w[8], s_mn[4], s_mx[4];
     if (counters[4] > (unsigned long long)emit_cap) return;             // flagged by k_totals: the host re-runs the frame with more room
     uint32_t cid[kEmitGroup], sums[kEmitGroup], be[kEmitGroup], sbase[kEmitGroup];
     uint2 rcs[kEmitGroup];
@@ -1519,17 +1520,32 @@ __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ re
         off += chunk_base + sbase[k];
         if (emits) {
             const uint32_t key = __float_as_uint(dep[k]);             // depth in [0, 1]: bit order = value order
+            // the sort carries the COMPACT index; the tile rect and the slot stay behind in compact arrays (12 B per emitting splat,
+            // dense), which is what the depth-ordered emission gathers from -- not the frame's slot-indexed arrays (8 B per SLOT, sparse:
+            // 80 MB at c3; that gather was 66 us of cold misses)
             keys[off] = key;
-            vals[off] = cid[k] * 256u + threadIdx.x;
+            vals[off] = off;
+            crect[off] = rc;
+            cslot[off] = cid[k] * 256u + threadIdx.x;
             kmn = min(kmn, key); kmx = max(kmx, key);
         }
     }
+    // key range: one guarded atomic pair per workgroup.  (One pair per WAVE on the two words was 70 k atomics on two addresses: the
+    // kernel took 189 us at c3.)  The words only grow, so a stale read can only cause a redundant atomic, never a missed one.
     for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, (uint32_t)__shfl_down((int)kmn, o, 64)); kmx = max(kmx, (uint32_t)__shfl_down((int)kmx, o, 64)); }
-    if ((threadIdx.x & 63u) == 0u && kmn <= kmx) { atomicMax(&krange[0], ~kmn); atomicMax(&krange[1], kmx); }    // (load_krange)
+    if ((threadIdx.x & 63u) == 0u) { s_mn[threadIdx.x >> 6] = kmn; s_mx[threadIdx.x >> 6] = kmx; }
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        kmn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3])); kmx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+        if (kmn <= kmx) {
+            if (~kmn > __builtin_nontemporal_load(&krange[0])) atomicMax(&krange[0], ~kmn);                         // (load_krange)
+            if (kmx > __builtin_nontemporal_load(&krange[1])) atomicMax(&krange[1], kmx);
+        }
+    }
 }
 
 // pair count of every 256-position block of the depth-ordered slot list, and the sums of 256 consecutive blocks
-__global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2* __restrict__ rects, const uint32_t* __restrict__ perm_a,
+__global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2* __restrict__ crect, const uint32_t* __restrict__ perm_a,
                                                      const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
                                                      const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
                                                      uint32_t* __restrict__ block_cnt, uint32_t* __restrict__ super_cnt)
@@ -1539,8 +1555,7 @@ __global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2*
     if (blockIdx.x * 256u >= n) return;
     const uint32_t* perm = (sort_passes_run(krange) & 1u) ? perm_b : perm_a;
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t slot = perm[min(pos, n - 1u)];
-    const uint2 rc = rects[slot];
+    const uint2 rc = crect[perm[min(pos, n - 1u)]];
     uint32_t count = 0;
     if (pos < n) {
         const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
@@ -1551,7 +1566,8 @@ __global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2*
     if (threadIdx.x == 0) { block_cnt[blockIdx.x] = tot; if (tot) atomicAdd(&super_cnt[blockIdx.x >> 8], tot); }
 }
 
-__global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* __restrict__ rects, const uint32_t* __restrict__ perm_a,
+__global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* __restrict__ crect, const uint32_t* __restrict__ cslot,
+                                                   const uint32_t* __restrict__ perm_a,
                                                    const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
                                                    const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
                                                    const uint32_t* __restrict__ block_cnt, const uint32_t* __restrict__ super_cnt, uint32_t pair_cap,
@@ -1568,8 +1584,9 @@ __global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* _
     // super-group in front of it
     uint32_t front = b0 + threadIdx.x < blockIdx.x ? block_cnt[b0 + threadIdx.x] : 0u;
     for (uint32_t j = threadIdx.x; j < sb; j += 256u) front += super_cnt[j];
-    const uint32_t slot = perm[min(pos, n - 1u)];
-    const uint2 rc = rects[slot];
+    const uint32_t ci = perm[min(pos, n - 1u)];
+    const uint2 rc = crect[ci];
+    const uint32_t slot = cslot[ci];
     uint32_t count = 0;
     const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
     if (pos < n) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
@@ -2459,23 +2476,23 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
 }
 
 // GSWT_ORDER_DEPTH front end (after k_project / k_totals): compaction of the emitting slots -> radix sort on the depth bits in use ->
-// per-block pair counts -> emission in depth order.  dk_a/dv_a/dk_b/dv_b: emit_cap u32 each; radix_ws: radix_ws_words(emit_cap, 32)
+// per-block pair counts -> emission in depth order.  dk_a/dv_a/dk_b/dv_b: emit_cap u32 each; crect / cslot: emit_cap uint2 / u32; radix_ws: radix_ws_words(emit_cap, 32)
 // words whose radix_ws_zero_words(emit_cap, 32) first are zero; krange = (~0, 0) and super_cnt zero on entry (k_cull's zero region);
 // counters[4] = number of emitting slots (k_totals).  Every launch goes through GSWT_LAUNCH: the frame is graph-able.
 void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_chunks, uint32_t emit_cap, const uint2* rects,
                        const float* depths, const uint32_t* block_sums, const uint32_t* block_emit, const uint32_t* emit_excl,
-                       uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b,
+                       uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b, uint2* crect, uint32_t* cslot,
                        uint32_t* radix_ws, uint32_t* krange, uint32_t* block_cnt, uint32_t* super_cnt, uint32_t pair_cap,
                        unsigned long long* counters, uint32_t* keys, uint32_t* vals)
 {
     if (n_chunks == 0 || emit_cap == 0) return;
     GSWT_LAUNCH(k_depth_keys, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), s, rects, depths, block_sums, block_emit, emit_excl, n_chunks,
-                emit_cap, (const unsigned long long*)counters, dk_a, dv_a, krange);
+                emit_cap, (const unsigned long long*)counters, dk_a, dv_a, crect, cslot, krange);
     (void)launch_sort(s, dk_a, dv_a, dk_b, dv_b, emit_cap, counters + 4, 32, radix_ws, nullptr, krange);
     const uint32_t nb = (emit_cap + 255u) / 256u;
-    GSWT_LAUNCH(k_perm_counts, dim3(nb), dim3(256), s, f, rects, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
+    GSWT_LAUNCH(k_perm_counts, dim3(nb), dim3(256), s, f, (const uint2*)crect, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
                 (const unsigned long long*)(counters + 4), emit_cap, block_cnt, super_cnt);
-    GSWT_LAUNCH(k_emit_perm, dim3(nb), dim3(256), s, f, rects, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
+    GSWT_LAUNCH(k_emit_perm, dim3(nb), dim3(256), s, f, (const uint2*)crect, (const uint32_t*)cslot, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
                 (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)block_cnt, (const uint32_t*)super_cnt, pair_cap, counters, keys, vals);
 }
 

@@ -188,10 +188,11 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                              executable graph) instead of ~13 separate launches: less submitting-thread time per frame, same
                              kernels, same results.  Frames with GSWT_OPT_TIMING > 0 or debug varyings
                              launch as before.  0 (default): separate launches */,
-       GSWT_OPT_STRICT_VS = 10 /* 1: the vertex stage evaluates gswt.wgsl:152-258,260-265,402-419 operator by operator (one correctly rounded
-                                  binary32 operation per written `*` `+` `-` `/`, full matrix products, no fused multiply-add) instead of the
-                                  default rounding sequence (fma chains, one reciprocal per quotient: also legal WGSL).  Per splat
-                                  bit-identical to the CPU checker's strict mode; see DESIGN.md section 4 for what the two differ by */,
+       GSWT_OPT_STRICT_VS = 10 /* 1 (default): the vertex stage evaluates gswt.wgsl:152-258,260-265,402-419 operator by operator -- one correctly
+                                  rounded binary32 operation per written `*` `+` `-` `/`, full matrix products, no fused multiply-add; per
+                                  splat bit-identical to the CPU checker's restatement of the shader text.  0: the rounding sequence "v2"
+                                  (fma chains, one reciprocal per quotient: also legal WGSL, ~25 % fewer instructions, the default until
+                                  round 3); the two differ by up to 5e-4 in the image on thin ellipses */,
        GSWT_OPT_EMIT_CAP = 11 /* test hook: start the GSWT_ORDER_DEPTH sort capacity (splats that emit pairs) at `value`; a frame that
                                  outgrows it is re-run with more room, like a pair overflow (0: sized from the next draw list) */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);

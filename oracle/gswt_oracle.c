@@ -524,9 +524,10 @@ static void debug_draw_color(const orc_scene *s, const orc_tile *u, const float 
 /* image are both measured against (tests/test_strict_oracle*.py).             */
 /* Process-wide switch; set it before orc_render / orc_project_draws.          */
 /* ------------------------------------------------------------------------- */
-/* 0 = canonical sequence v2 everywhere; 1 = strict vertex AND fragment stage (the anchor image); 2 = strict vertex stage with the  */
-/* v2 fragment sequence F1..F4 -- what the HIP path computes with GSWT_OPT_STRICT_VS (its compositor always evaluates F1..F4).   */
-static int g_strict = 0;
+/* 2 (DEFAULT since round 4) = strict vertex stage + the fragment sequence F1..F4: what the HIP path computes by default (its      */
+/* compositor always evaluates F1..F4); 1 = strict vertex AND fragment stage (the anchor image: exact quad interpolation);        */
+/* 0 = the rounding sequence v2 everywhere (fma chains, one reciprocal per quotient: the HIP path with GSWT_OPT_STRICT_VS = 0).   */
+static int g_strict = 2;
 ORC_API void orc_set_strict(int on) { g_strict = on == 2 ? 2 : (on ? 1 : 0); }
 ORC_API int orc_get_strict(void) { return g_strict; }
 

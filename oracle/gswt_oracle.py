@@ -144,11 +144,12 @@ def lib():
 
 
 class strict:
-    """Context manager: the oracle evaluates gswt.wgsl:152-258,402-435 operator by operator (IEEE `/`, no fused
-    multiply-add, exact quad interpolation) instead of the canonical sequence v2 the kernels reproduce (gswt_oracle.c,
-    "STRICT mode").  Process-wide switch.
-    fragment=False: only the vertex stage is strict and the fragment stage stays the sequence F1..F4 -- what the HIP path computes
-    with GSWT_OPT_STRICT_VS (its compositor always evaluates F1..F4)."""
+    """Context manager, process-wide switch of the evaluation mode (gswt_oracle.c, "STRICT mode"):
+    default (mode 2, no context needed): the vertex stage gswt.wgsl:152-258,260-265,402-419 operator by operator (IEEE `/`, no fused
+        multiply-add, full matrix products) + the fragment sequence F1..F4 -- what the HIP path computes by default;
+    strict() (mode 1): the fragment stage too -- exact quad interpolation, fs_main as written: the anchor image;
+    strict(fragment=False): mode 2 explicitly;
+    v2() (mode 0): the rounding sequence v2 (fma chains, one reciprocal per quotient) = the HIP path with GSWT_OPT_STRICT_VS = 0."""
 
     def __init__(self, fragment: bool = True):
         self.mode = 1 if fragment else 2
@@ -161,6 +162,13 @@ class strict:
     def __exit__(self, *exc):
         lib().orc_set_strict(self.prev)
         return False
+
+
+class v2(strict):
+    """Context manager: the rounding sequence v2 everywhere (see `strict`)."""
+
+    def __init__(self):
+        self.mode = 0
 
 
 def _ptr(a):

@@ -80,8 +80,11 @@ def main():
             draws = wo.renderer_draws(pp, osort, cam.view_proj())
         su = wo.scene_uniforms_from_data(ou, osd["center_coord"], **c.get("render_config", {}))
         hm = ou.height_map.reshape(ou.height_map_wh[1], ou.height_map_wh[0]) if ou.surface_type == 1 else None
-        img, st = orc.render(cam.uniforms(), su, pp.tex, draws, c["W"], c["H"], height_map=hm)
-        var = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
+        with orc.v2():          # the rounding sequence v2 (GSWT_OPT_STRICT_VS = 0): `image`, `varyings`, `stats` as in rounds 2 and 3
+            img, st = orc.render(cam.uniforms(), su, pp.tex, draws, c["W"], c["H"], height_map=hm)
+            var = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
+        # the default since round 4: strict vertex stage (= `varyings_strict`) + the fragment sequence F1..F4
+        img_d, st_d = orc.render(cam.uniforms(), su, pp.tex, draws, c["W"], c["H"], height_map=hm)
         with orc.strict():      # the shader text operator by operator (oracle/gswt_oracle.c, "STRICT mode")
             img_s, st_s = orc.render(cam.uniforms(), su, pp.tex, draws, c["W"], c["H"], height_map=hm)
             var_s = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
@@ -96,7 +99,8 @@ def main():
             views=np.array([t.view_id for t in osort["tile_instance_vec"]], dtype=np.int32),
             lods=np.array([t.tid[0] for t in osort["tile_instance_vec"]], dtype=np.int32),
             draw_classes=np.array(classes, dtype=np.int32),
-            image=img, varyings=var, image_strict=img_s, varyings_strict=var_s, stats=np.array([st["n_instanced"], st["n_visible"], st["n_pairs16"]], dtype=np.int64))
+            image=img, varyings=var, image_strict=img_s, varyings_strict=var_s, stats=np.array([st["n_instanced"], st["n_visible"], st["n_pairs16"]], dtype=np.int64),
+            image_default=img_d, stats_default=np.array([st_d["n_instanced"], st_d["n_visible"], st_d["n_pairs16"]], dtype=np.int64))
         print(name, "strict vs v2 image", float(np.abs(img - img_s).max()))
         print(name, "draws", len(draws), "classes", np.bincount(classes, minlength=3).tolist(), st, "img max", float(img.max()))
 

@@ -28,7 +28,8 @@ def _setup(renderer, name):
     tex, draws = bench.oracle_draws(wang, sort, vp)
     ocu = orc.Camera176.from_buffer_copy(bytes(cu))
     osu = orc.Scene160.from_buffer_copy(bytes(su))
-    return dict(W=W, H=Hh, cu=cu, su=su, hm=hm, tex=tex, draws=draws, ocu=ocu, osu=osu)
+    # (wang owns the memory tex and the draws' index arrays are views of: it has to outlive them)
+    return dict(W=W, H=Hh, cu=cu, su=su, hm=hm, tex=tex, draws=draws, ocu=ocu, osu=osu, wang=wang, sort=sort)
 
 
 @pytest.mark.parametrize("name", ["c3", "c3d"])

@@ -68,11 +68,18 @@ def test_oracle_reproduces_golden(path):
     assert [t.view_id for t in osort["tile_instance_vec"]] == g["views"].tolist()
     hm = ou.height_map.reshape(ou.height_map_wh[1], ou.height_map_wh[0]) if ou.surface_type == 1 else None
     su = wo.scene_uniforms_from_data(ou, osd["center_coord"], **rc)
-    img, st = orc.render(cam.uniforms(), su, pp.tex, draws, W, H, height_map=hm)
+    with orc.v2():           # the rounding sequence v2: arrays byte-identical to the round-2 / round-3 files
+        img, st = orc.render(cam.uniforms(), su, pp.tex, draws, W, H, height_map=hm)
+        var = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
     assert [st["n_instanced"], st["n_visible"], st["n_pairs16"]] == g["stats"].tolist()
     assert np.max(np.abs(img - g["image"])) <= 1e-6      # expf may differ in the last ulp across libm builds
-    var = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
     assert var.tobytes() == g["varyings"].tobytes()
+    # the default (round 4): strict vertex stage + the fragment sequence F1..F4
+    img, st = orc.render(cam.uniforms(), su, pp.tex, draws, W, H, height_map=hm)
+    var = orc.project_draws(cam.uniforms(), su, pp.tex, draws, height_map=hm)
+    assert [st["n_instanced"], st["n_visible"], st["n_pairs16"]] == g["stats_default"].tolist()
+    assert np.max(np.abs(img - g["image_default"])) <= 1e-6
+    assert var.tobytes() == g["varyings_strict"].tobytes()
 
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
@@ -106,7 +113,15 @@ def test_gpu_matches_golden_image(renderer, path):
     su = w.scene_uniforms()
     su.draw_mode = int(rc.get("draw_mode", 0))
     img = renderer.render(cu, su, W, H)
-    assert np.max(np.abs(img.astype(np.float64) - g["image"].astype(np.float64))) <= 1e-4
+    assert np.max(np.abs(img.astype(np.float64) - g["image_default"].astype(np.float64))) <= 1e-4
+    t = renderer.timings()
+    assert [t["n_instanced"], t["n_visible"], t["n_pairs"]] == g["stats_default"].tolist()
+    renderer.set_option(L.GSWT_OPT_STRICT_VS, 0)           # the rounding sequence v2
+    try:
+        img2 = renderer.render(cu, su, W, H)
+    finally:
+        renderer.set_option(L.GSWT_OPT_STRICT_VS, 1)
+    assert np.max(np.abs(img2.astype(np.float64) - g["image"].astype(np.float64))) <= 1e-4
     t = renderer.timings()
     assert [t["n_visible"], t["n_pairs"]] == g["stats"].tolist()[1:]
 

@@ -59,10 +59,11 @@ def test_vertex_stage_bit_exact(renderer):
 
 
 @pytest.mark.parametrize("surface", ["plane", "hmap", "sphere"])
-def test_strict_vertex_stage_bit_exact(renderer, surface):
-    """GSWT_OPT_STRICT_VS: k_project<., ., STRICT> evaluates gswt.wgsl:152-258,260-265,402-419 operator by operator; per splat bit for
-    bit what the CPU checker's strict mode computes (oracle/gswt_oracle.c project_impl, strict branch), on all three surfaces, with a
-    non-unit scene scale (the full scene_scale_mat products) and debug colours on the sphere."""
+def test_both_vertex_stage_sequences_bit_exact(renderer, surface):
+    """k_project<., ., STRICT> (the default) evaluates gswt.wgsl:152-258,260-265,402-419 operator by operator, k_project<., ., false>
+    (GSWT_OPT_STRICT_VS = 0) the rounding sequence v2; each per splat bit for bit what the CPU checker computes in the same mode
+    (oracle/gswt_oracle.c project_impl), on all three surfaces, with a non-unit scene scale (the full scene_scale_mat products) and
+    debug colours on the sphere."""
     pp = H.tileset()
     W, Hh = 320, 240
     hm = None
@@ -79,34 +80,37 @@ def test_strict_vertex_stage_bit_exact(renderer, surface):
         su = _scene(pp, **kw)
         case = H.grid_case(pp)
         cam = orc.default_camera(W, Hh).uniforms()
-    renderer.set_option(L.GSWT_OPT_NO_LOD_PREFILTER, 1)
-    renderer.set_option(L.GSWT_OPT_DEBUG_VARYINGS, 1)
-    renderer.set_option(L.GSWT_OPT_STRICT_VS, 1)
-    try:
-        renderer.configure(hm)
-        case.upload(renderer)
-        img = renderer.render(cam, su, W, Hh)
-        got = renderer.read_projected()
-        t = renderer.timings()
-    finally:
-        renderer.set_option(L.GSWT_OPT_NO_LOD_PREFILTER, 0)
-        renderer.set_option(L.GSWT_OPT_DEBUG_VARYINGS, 0)
-        renderer.set_option(L.GSWT_OPT_STRICT_VS, 0)
-        renderer.configure(None)
-    with orc.strict(fragment=False):
-        want = orc.project_draws(cam, su, pp.tex, case.orc_draws, height_map=hm)
-        ref, st = orc.render(cam, su, pp.tex, case.orc_draws, W, Hh, height_map=hm)
-    v2 = orc.project_draws(cam, su, pp.tex, case.orc_draws, height_map=hm)
-    assert np.array_equal(got["visible"], want["visible"])
-    vis = want["visible"] == 1
-    assert vis.sum() > 1000
-    for fld in ("ndc", "depth", "major", "minor", "rgba"):
-        assert np.array_equal(got[fld][vis].view(np.uint32), want[fld][vis].view(np.uint32)), fld
-    # ... and the strict sequence really is another one than v2 (else this test would pass with the option ignored)
-    assert not np.array_equal(want["major"][vis].view(np.uint32), v2["major"][vis].view(np.uint32))
-    # image: strict vertex stage + the compositor's F1..F4 = the checker's mode 2
-    assert t["n_visible"] == st["n_visible"] and t["n_pairs"] == st["n_pairs16"]
-    assert H.max_abs_diff(img, ref) <= TOL
+    wants = {}
+    for strict_vs in (1, 0):
+        renderer.set_option(L.GSWT_OPT_NO_LOD_PREFILTER, 1)
+        renderer.set_option(L.GSWT_OPT_DEBUG_VARYINGS, 1)
+        renderer.set_option(L.GSWT_OPT_STRICT_VS, strict_vs)
+        try:
+            renderer.configure(hm)
+            case.upload(renderer)
+            img = renderer.render(cam, su, W, Hh)
+            got = renderer.read_projected()
+            t = renderer.timings()
+        finally:
+            renderer.set_option(L.GSWT_OPT_NO_LOD_PREFILTER, 0)
+            renderer.set_option(L.GSWT_OPT_DEBUG_VARYINGS, 0)
+            renderer.set_option(L.GSWT_OPT_STRICT_VS, 1)
+            renderer.configure(None)
+        with (orc.strict(fragment=False) if strict_vs else orc.v2()):
+            want = orc.project_draws(cam, su, pp.tex, case.orc_draws, height_map=hm)
+            ref, st = orc.render(cam, su, pp.tex, case.orc_draws, W, Hh, height_map=hm)
+        wants[strict_vs] = want
+        assert np.array_equal(got["visible"], want["visible"])
+        vis = want["visible"] == 1
+        assert vis.sum() > 1000
+        for fld in ("ndc", "depth", "major", "minor", "rgba"):
+            assert np.array_equal(got[fld][vis].view(np.uint32), want[fld][vis].view(np.uint32)), (strict_vs, fld)
+        # image: the same vertex stage + the compositor's F1..F4 on both sides
+        assert t["n_visible"] == st["n_visible"] and t["n_pairs"] == st["n_pairs16"]
+        assert H.max_abs_diff(img, ref) <= TOL
+    # ... and the two sequences really differ (else this test would pass with the option ignored)
+    vis = (wants[0]["visible"] == 1) & (wants[1]["visible"] == 1)
+    assert not np.array_equal(wants[1]["major"][vis].view(np.uint32), wants[0]["major"][vis].view(np.uint32))
 
 
 def _sphere_case(pp, half=(5, 2), tile_width=4.0, merged_cells=((2, 1), (3, 1))):

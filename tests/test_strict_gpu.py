@@ -8,8 +8,10 @@ reference's default HeightMap surface (c3h), with bench.py's early-out threshold
                                                     pixels above 1e-4      elsewhere
   v2 vs strict, flipped |p|^2 <= 4 decisions        alpha e^-4 = 0.018     719 / 775 of 2 073 600 pixels
 
-The product's 1e-4 contract is against the canonical sequence v2 (tests/test_baseline_configs_gpu.py); this file shows what is
-left between v2 and ANOTHER legal binary32 evaluation of /root/reference/src/gswt.wgsl:152-258,402-435."""
+Round 4: the product's DEFAULT vertex stage is the strict one (k_project<., ., STRICT>: +1 us of 71 at c3); the second test below shows
+that the default image then meets 1e-4 (+ the early-out cut) against the strict image on every pixel that holds no flipped coverage
+decision, at c3, c3h and c5.  The first test keeps the numbers of the v2 option (GSWT_OPT_STRICT_VS = 0), whose thin-ellipse term the
+table above lists.  /root/reference/src/gswt.wgsl:152-258,402-435."""
 import numpy as np
 import pytest
 
@@ -21,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("name", ["c3", "c3h", "c5"])
-def test_gpu_vs_strict_full_error_stack(renderer, name):
+def test_gpu_v2_option_vs_strict_full_error_stack(renderer, name):
     import bench
     import torch
     d = both_modes(name, varyings=False)
@@ -32,11 +34,15 @@ def test_gpu_vs_strict_full_error_stack(renderer, name):
     renderer.configure(wang.height_map() if int(wang.user.surface_type) == 1 else None)
     renderer.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
     out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-    renderer.render_wait(renderer.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
+    renderer.set_option(L.GSWT_OPT_STRICT_VS, 0)           # this test is about the rounding sequence v2 (the default until round 3)
+    try:
+        renderer.render_wait(renderer.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
+        t = renderer.timings()
+    finally:
+        renderer.set_option(L.GSWT_OPT_STRICT_VS, 1)
     img = out.cpu().numpy()
     del out
     torch.cuda.empty_cache()
-    t = renderer.timings()
     assert t["n_visible"] == d["st2"]["n_visible"] == d["sts"]["n_visible"]
     # against v2: the product's contract
     assert np.abs(img.astype(np.float64) - d["v2"]).max() <= 1e-4
@@ -51,7 +57,7 @@ def test_gpu_vs_strict_full_error_stack(renderer, name):
 
 @pytest.mark.parametrize("name", ["c3", "c3h", "c5"])
 def test_gpu_strict_vertex_stage_meets_1e4_off_the_ellipse_borders(renderer, name):
-    """GSWT_OPT_STRICT_VS: with the vertex stage evaluated as the shader text writes it, what is left between the HIP image and the strict
+    """The default (GSWT_OPT_STRICT_VS = 1 since round 4): with the vertex stage evaluated as the shader text writes it, what is left between the HIP image and the strict
     image is (a) the fragment stage's |p|^2 <= 4 decisions that fall the other way (inherent to two rasterisations: F4 evaluates the
     inverse affine map tile-locally in binary32, the strict image interpolates the quad exactly), and (b) off those pixels the
     continuous terms: the early-out cut, blend order, exp2 / log2.  (b) meets north_star's 1e-4 (+ the 1e-5 cut) at c3, c3h AND c5 --
@@ -67,19 +73,14 @@ def test_gpu_strict_vertex_stage_meets_1e4_off_the_ellipse_borders(renderer, nam
     osu = orc.Scene160.from_buffer_copy(bytes(su))
     with orc.strict():
         strict_img, sts = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
-    with orc.strict(fragment=False):
-        mixed_img, stm = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
+    mixed_img, stm = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)          # the checker's default: strict vertex stage + F1..F4
     mask, counts = orc.compare_modes(ocu, osu, tex, draws, W, H, height_map=hm, strict_vs=True)
     wang.upload_to(renderer)
     renderer.configure(hm)
     renderer.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
     out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-    renderer.set_option(L.GSWT_OPT_STRICT_VS, 1)
-    try:
-        renderer.render_wait(renderer.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
-        t = renderer.timings()
-    finally:
-        renderer.set_option(L.GSWT_OPT_STRICT_VS, 0)
+    renderer.render_wait(renderer.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
+    t = renderer.timings()
     img = out.cpu().numpy()
     del out
     torch.cuda.empty_cache()

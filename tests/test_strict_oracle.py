@@ -26,15 +26,18 @@ def both_modes(name, varyings=True):
     tex, draws = bench.oracle_draws(wang, sort, vp)
     ocu = orc.Camera176.from_buffer_copy(bytes(cu))
     osu = orc.Scene160.from_buffer_copy(bytes(su))
-    v2, st2 = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
+    with orc.v2():
+        assert orc.lib().orc_get_strict() == 0
+        v2, st2 = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
+        var_2 = orc.project_draws(ocu, osu, tex, draws, height_map=hm) if varyings else None
     with orc.strict():
         assert orc.lib().orc_get_strict() == 1
         st_img, sts = orc.render(ocu, osu, tex, draws, W, H, height_map=hm)
         var_s = orc.project_draws(ocu, osu, tex, draws, height_map=hm) if varyings else None
-    assert orc.lib().orc_get_strict() == 0
-    var_2 = orc.project_draws(ocu, osu, tex, draws, height_map=hm) if varyings else None
+    assert orc.lib().orc_get_strict() == 2          # the default: strict vertex stage + F1..F4
     mask, counts = orc.compare_modes(ocu, osu, tex, draws, W, H, height_map=hm)
-    return dict(W=W, H=H, v2=v2, strict=st_img, st2=st2, sts=sts, var2=var_2, vars=var_s, mask=mask, counts=counts)
+    # (wang owns the memory tex and the draws' arrays are views of)
+    return dict(W=W, H=H, v2=v2, strict=st_img, st2=st2, sts=sts, var2=var_2, vars=var_s, mask=mask, counts=counts, wang=wang, sort=sort)
 
 
 def check_bounds(d, img_a, img_b, *, flip_frac=1e-3, cont_max=1e-3, cont_over_frac=1e-4, extra=0.0):
