@@ -35,7 +35,7 @@ void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, u
 size_t radix_ws_words(uint32_t, int);
 size_t radix_ws_zero_words(uint32_t, int);
 void launch_emit_depth(hipStream_t, const Frame&, uint32_t, uint32_t, const uint2*, const float*, const uint32_t*, const uint32_t*, const uint32_t*,
-                       uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint2*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
+                       uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint2*, uint2*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
                        unsigned long long*, uint32_t*, uint32_t*);
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
@@ -46,7 +46,7 @@ void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
                  uint32_t*, uint32_t*);
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr,
-                const uint32_t* = nullptr);
+                const uint32_t* = nullptr, uint2* = nullptr, uint2* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, const unsigned long long*, unsigned long long*);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
@@ -1382,8 +1382,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // radix workspaces: the zeroed parts of BOTH sorts first (group rows, digit totals), the per-workgroup rows (written in full) behind
     const size_t rz_pair = radix_ws_zero_words(cap, key_bits), rz_depth = depth_order ? radix_ws_zero_words(ecap, 32) : 0;
     const size_t rw_pair = radix_ws_words(cap, key_bits), rw_depth = depth_order ? radix_ws_words(ecap, 32) : 0;
-    // depth sort: key / index ping-pong (4 x ecap), compact rects (2 x ecap, 8-byte aligned at the front) and slots (ecap), block counts
-    if (depth_order) HIP_TRY(c, sl.depth_ws.ensure_roomy(7 * (size_t)ecap + ((size_t)ecap / 256 + 2) + 64));
+    // depth sort: tile-rect payload ping-pong (2 x 2 x ecap words, 8-byte aligned at the front), key / slot ping-pong (4 x ecap), block counts
+    if (depth_order) HIP_TRY(c, sl.depth_ws.ensure_roomy(8 * (size_t)ecap + ((size_t)ecap / 256 + 2) + 64));
     // one contiguous u32 region whose head k_cull clears: [counters: 16][super_sums: n_super2][psuper][pair sort: zeroed part .. rows][depth sort likewise]
     HIP_TRY(c, sl.ghist.ensure_roomy(16 + n_super2 + n_psuper + rw_pair + rw_depth + 16));
     uint32_t* const zero_a = sl.ghist.p;
@@ -1427,9 +1427,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // part is contiguous with the head; the depth sort's (behind the pair sort's rows) is the kernel's second clear range.
     const size_t n_zero_a = 16 + n_super2 + n_psuper + rz_pair;
     uint32_t* const d_crect = sl.depth_ws.p;
-    uint32_t* const dw = depth_order ? d_crect + 2 * (size_t)ecap : nullptr;
-    uint32_t* const d_cslot = depth_order ? dw + 4 * (size_t)ecap : nullptr;
-    uint32_t* const d_block_cnt = depth_order ? d_cslot + ecap : nullptr;
+    uint32_t* const dw = depth_order ? d_crect + 4 * (size_t)ecap : nullptr;
+    uint32_t* const d_block_cnt = depth_order ? dw + 4 * (size_t)ecap : nullptr;
     uint32_t* const d_block_emit = depth_order ? sl.block_sums.p + D.n_chunks : nullptr;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
                 reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks * (depth_order ? 2u : 1u), sl.live_cnt.p, sl.live_tab.p,
@@ -1445,7 +1444,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         // counters[4] = emitting slots (k_totals; the depth sort reads its item count there, counters[6] = its overflow word stays 0),
         // counters[5] = the key range (two u32 words, k_depth_keys)
         launch_emit_depth(s, f, D.n_chunks, ecap, sl.rects.p, sl.depths.p, sl.block_sums.p, d_block_emit, d_super + 4 * n_super,
-                          dw, dw + ecap, dw + 2 * (size_t)ecap, dw + 3 * (size_t)ecap, reinterpret_cast<uint2*>(d_crect), d_cslot, d_radix_depth,
+                          dw, dw + ecap, dw + 2 * (size_t)ecap, dw + 3 * (size_t)ecap, reinterpret_cast<uint2*>(d_crect),
+                          reinterpret_cast<uint2*>(d_crect) + ecap, d_radix_depth,
                           reinterpret_cast<uint32_t*>(d_counters + 5),
                           d_block_cnt, d_psuper, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     }

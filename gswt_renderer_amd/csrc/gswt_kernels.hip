@@ -1298,13 +1298,19 @@ __global__ __launch_bounds__(256) void k_radix_supscan(uint32_t* __restrict__ gs
 // The block's 4096 items are first ranked INTO LDS (sorted by digit inside the block), then copied out: consecutive threads
 // write consecutive addresses of a digit's run instead of every lane storing two separate words to its own rank position
 // (a wave's store instruction used to touch as many regions as it held distinct digits).
-template <int kSortThreads>
+// AUX (the depth sort): an 8-byte payload per item travels with it.  It is NOT staged through LDS with the (key, value) pair (12 more bytes
+// per item would cost a workgroup per CU): the ranking leaves each sorted item's source position inside the block (u16), and the copy-out
+// fetches the payload from there -- a gather confined to the block's own 32 KB window of the input, every sector of which this workgroup
+// consumes -- and stores it at the item's global position beside the value.  What this replaces: gathering the payload AFTER the sort
+// through the sorted index (1.9 M random 8-byte reads at c3, 64-byte sectors: 60 us cold).
+template <int kSortThreads, bool AUX>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
                                                        uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist,
                                                        const uint32_t* __restrict__ gsup, const uint32_t* __restrict__ gtot,
-                                                       uint32_t nblk, uint32_t nsup, uint2* __restrict__ ranges, const uint32_t* __restrict__ krange)
+                                                       uint32_t nblk, uint32_t nsup, uint2* __restrict__ ranges, const uint32_t* __restrict__ krange,
+                                                       const uint2* __restrict__ aux_in, uint2* __restrict__ aux_out)
 {
     constexpr int kSortItems = kSortBlock / kSortThreads, kSortWaves = kSortThreads / 64;
     uint32_t kmin = 0;                                  // (see k_radix_hist)
@@ -1322,6 +1328,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     __shared__ uint32_t s_w[4], s_w2[4];
     __shared__ uint32_t s_gs[2][256];                   // direct group sums: [0] earlier groups, [1] all groups (waves 4..7 -> waves 0..3)
     __shared__ uint2 s_kv[kSortBlock];
+    __shared__ uint16_t s_src[AUX ? kSortBlock : 1];    // AUX: sorted position inside the block -> source position inside the block
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (int k = 0; k < kSortWaves * 256 / kSortThreads; k++) (&s_h[0][0])[k * kSortThreads + threadIdx.x] = 0;
     __syncthreads();
@@ -1435,7 +1442,10 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
         const int leader = valid ? (int)__ffsll((long long)peers) - 1 : (int)lane;
         pos = (uint32_t)__shfl((int)pos, leader, 64);
-        if (valid) s_kv[pos + rank] = make_uint2(key[k], val[k]);
+        if (valid) {
+            s_kv[pos + rank] = make_uint2(key[k], val[k]);
+            if (AUX) s_src[AUX ? pos + rank : 0u] = (uint16_t)(w * (64u * kSortItems) + (uint32_t)k * 64u + lane);
+        }
     }
     __syncthreads();
     GSWT_TR(4, GSWT_NOW())
@@ -1447,6 +1457,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
             const uint2 kv = s_kv[i];
             const uint32_t gp = s_g[((kv.x - kmin) >> shift) & mask] + i;
             vals_out[gp] = kv.y;
+            if (AUX) aux_out[gp] = aux_in[blk0 + s_src[AUX ? i : 0u]];
             if (!ranges) keys_out[gp] = kv.x;
             else {
                 // LAST pass of the frame's pair sort: the block in LDS is sorted by the whole key (the passes before ordered the
@@ -1482,7 +1493,7 @@ __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ re
                                                     const uint32_t* __restrict__ emit_excl, uint32_t n_chunks, uint32_t emit_cap,
                                                     const unsigned long long* __restrict__ counters,
                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ crect,
-                                                    uint32_t* __restrict__ cslot, uint32_t* __restrict__ krange)
+                                                    uint32_t* __restrict__ krange)
 {
     __shared__ uint32_t s_w[8], s_mn[4], s_mx[4];
     if (counters[4] > (unsigned long long)emit_cap) return;             // flagged by k_totals: the host re-runs the frame with more room
@@ -1520,13 +1531,11 @@ __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ re
         off += chunk_base + sbase[k];
         if (emits) {
             const uint32_t key = __float_as_uint(dep[k]);             // depth in [0, 1]: bit order = value order
-            // the sort carries the COMPACT index; the tile rect and the slot stay behind in compact arrays (12 B per emitting splat,
-            // dense), which is what the depth-ordered emission gathers from -- not the frame's slot-indexed arrays (8 B per SLOT, sparse:
-            // 80 MB at c3; that gather was 66 us of cold misses)
+            // the slot is the sort's value, the tile rect its 8-byte payload (k_radix_scatter<., AUX>): the depth-ordered emission then reads
+            // both in order -- gathering the rects through the sorted slots afterwards was 60 us of cold 8-byte reads at c3
             keys[off] = key;
-            vals[off] = off;
+            vals[off] = cid[k] * 256u + threadIdx.x;
             crect[off] = rc;
-            cslot[off] = cid[k] * 256u + threadIdx.x;
             kmn = min(kmn, key); kmx = max(kmx, key);
         }
     }
@@ -1545,17 +1554,17 @@ __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ re
 }
 
 // pair count of every 256-position block of the depth-ordered slot list, and the sums of 256 consecutive blocks
-__global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2* __restrict__ crect, const uint32_t* __restrict__ perm_a,
-                                                     const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
+__global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
+                                                     const uint32_t* __restrict__ krange,
                                                      const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
                                                      uint32_t* __restrict__ block_cnt, uint32_t* __restrict__ super_cnt)
 {
     __shared__ uint32_t s_w[4];
     const uint32_t n = clamped_count(n_ptr, emit_cap);
     if (blockIdx.x * 256u >= n) return;
-    const uint32_t* perm = (sort_passes_run(krange) & 1u) ? perm_b : perm_a;
+    const uint2* rect = (sort_passes_run(krange) & 1u) ? rect_b : rect_a;
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    const uint2 rc = crect[perm[min(pos, n - 1u)]];
+    const uint2 rc = rect[min(pos, n - 1u)];
     uint32_t count = 0;
     if (pos < n) {
         const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
@@ -1566,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2*
     if (threadIdx.x == 0) { block_cnt[blockIdx.x] = tot; if (tot) atomicAdd(&super_cnt[blockIdx.x >> 8], tot); }
 }
 
-__global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* __restrict__ crect, const uint32_t* __restrict__ cslot,
+__global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
                                                    const uint32_t* __restrict__ perm_a,
                                                    const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
                                                    const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
@@ -1577,16 +1586,17 @@ __global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* _
     __shared__ uint32_t s_w[8];
     const uint32_t n = clamped_count(n_ptr, emit_cap);
     if (blockIdx.x * 256u >= n) return;
-    const uint32_t* perm = (sort_passes_run(krange) & 1u) ? perm_b : perm_a;
+    const bool in_b = (sort_passes_run(krange) & 1u) != 0u;
+    const uint32_t* perm = in_b ? perm_b : perm_a;
+    const uint2* rect = in_b ? rect_b : rect_a;
     const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
     const uint32_t sb = blockIdx.x >> 8, b0 = blockIdx.x & ~255u;
     // pairs in front of this block: the super-groups in front of its own (thread t sums supers t, t + 256, ...) + the blocks of its own
     // super-group in front of it
     uint32_t front = b0 + threadIdx.x < blockIdx.x ? block_cnt[b0 + threadIdx.x] : 0u;
     for (uint32_t j = threadIdx.x; j < sb; j += 256u) front += super_cnt[j];
-    const uint32_t ci = perm[min(pos, n - 1u)];
-    const uint2 rc = crect[ci];
-    const uint32_t slot = cslot[ci];
+    const uint32_t slot = perm[min(pos, n - 1u)];
+    const uint2 rc = rect[min(pos, n - 1u)];
     uint32_t count = 0;
     const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
     if (pos < n) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
@@ -2443,7 +2453,8 @@ size_t radix_ws_zero_words(uint32_t n_cap, int key_bits)
 }
 
 int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n_cap,
-                const unsigned long long* n_ptr, int key_bits, uint32_t* ws, uint2* ranges = nullptr, const uint32_t* krange = nullptr)
+                const unsigned long long* n_ptr, int key_bits, uint32_t* ws, uint2* ranges = nullptr, const uint32_t* krange = nullptr,
+                uint2* aux_a = nullptr, uint2* aux_b = nullptr)
 {
     if (n_cap == 0) return 0;
     const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
@@ -2462,11 +2473,14 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         hist_rows += (size_t)256 * nblk;
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
+        const uint2* xi = cur ? aux_b : aux_a; uint2* xo = cur ? aux_a : aux_b;
 #define GSWT_SORT_PASS(T)                                                                                                        \
         GSWT_LAUNCH(k_radix_hist<T>, dim3(nblk), dim3(T), s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup, krange); \
         if (nsup > kSupDirect) GSWT_LAUNCH(k_radix_supscan, dim3(64), dim3(256), s, gsup, gtot, nsup);                          \
-        GSWT_LAUNCH(k_radix_scatter<T>, dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
-                           ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr, krange)
+        if (aux_a) GSWT_LAUNCH((k_radix_scatter<T, true>), dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
+                           ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr, krange, xi, xo);                  \
+        else GSWT_LAUNCH((k_radix_scatter<T, false>), dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
+                           ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr, krange, xi, xo)
         if (threads == 512) { GSWT_SORT_PASS(512); }
         else { GSWT_SORT_PASS(256); }
 #undef GSWT_SORT_PASS
@@ -2476,23 +2490,23 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
 }
 
 // GSWT_ORDER_DEPTH front end (after k_project / k_totals): compaction of the emitting slots -> radix sort on the depth bits in use ->
-// per-block pair counts -> emission in depth order.  dk_a/dv_a/dk_b/dv_b: emit_cap u32 each; crect / cslot: emit_cap uint2 / u32; radix_ws: radix_ws_words(emit_cap, 32)
+// per-block pair counts -> emission in depth order.  dk_a/dv_a/dk_b/dv_b: emit_cap u32 each; rect_a / rect_b: emit_cap uint2 each; radix_ws: radix_ws_words(emit_cap, 32)
 // words whose radix_ws_zero_words(emit_cap, 32) first are zero; krange = (~0, 0) and super_cnt zero on entry (k_cull's zero region);
 // counters[4] = number of emitting slots (k_totals).  Every launch goes through GSWT_LAUNCH: the frame is graph-able.
 void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_chunks, uint32_t emit_cap, const uint2* rects,
                        const float* depths, const uint32_t* block_sums, const uint32_t* block_emit, const uint32_t* emit_excl,
-                       uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b, uint2* crect, uint32_t* cslot,
+                       uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b, uint2* rect_a, uint2* rect_b,
                        uint32_t* radix_ws, uint32_t* krange, uint32_t* block_cnt, uint32_t* super_cnt, uint32_t pair_cap,
                        unsigned long long* counters, uint32_t* keys, uint32_t* vals)
 {
     if (n_chunks == 0 || emit_cap == 0) return;
     GSWT_LAUNCH(k_depth_keys, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), s, rects, depths, block_sums, block_emit, emit_excl, n_chunks,
-                emit_cap, (const unsigned long long*)counters, dk_a, dv_a, crect, cslot, krange);
-    (void)launch_sort(s, dk_a, dv_a, dk_b, dv_b, emit_cap, counters + 4, 32, radix_ws, nullptr, krange);
+                emit_cap, (const unsigned long long*)counters, dk_a, dv_a, rect_a, krange);
+    (void)launch_sort(s, dk_a, dv_a, dk_b, dv_b, emit_cap, counters + 4, 32, radix_ws, nullptr, krange, rect_a, rect_b);
     const uint32_t nb = (emit_cap + 255u) / 256u;
-    GSWT_LAUNCH(k_perm_counts, dim3(nb), dim3(256), s, f, (const uint2*)crect, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
+    GSWT_LAUNCH(k_perm_counts, dim3(nb), dim3(256), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)krange,
                 (const unsigned long long*)(counters + 4), emit_cap, block_cnt, super_cnt);
-    GSWT_LAUNCH(k_emit_perm, dim3(nb), dim3(256), s, f, (const uint2*)crect, (const uint32_t*)cslot, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
+    GSWT_LAUNCH(k_emit_perm, dim3(nb), dim3(256), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
                 (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)block_cnt, (const uint32_t*)super_cnt, pair_cap, counters, keys, vals);
 }
 
