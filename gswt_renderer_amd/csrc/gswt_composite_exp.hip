@@ -223,7 +223,7 @@ __global__ __launch_bounds__(64) void k_composite_p(const Frame f, const uint32_
             const uint32_t idx = (uint32_t)k * 64u + lane;
             if (idx < n) {
                 // F3 and the tile-local pixel-centre box: as in k_composite
-                const float ox = rb[k].x - fbx, oy = rb[k].y - fby;
+                const float ox = fmaf(0.5f * f.W, rb[k].x, 0.5f * f.W - fbx), oy = fmaf(-0.5f * f.H, rb[k].y, 0.5f * f.H - fby);   // F3, sequence v3
                 const float nku = -fmaf(ra[k].x, ox, ra[k].y * oy);
                 const float nkv = -fmaf(ra[k].z, ox, ra[k].w * oy);
                 s_q0[idx] = make_float4(ra[k].x, ra[k].y, nku, __builtin_amdgcn_logf(rb[k].z));
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(OCC, 8))) v
         for (int k = 0; k < NB2; k++) {
             const uint32_t idx = (uint32_t)k * 128u + tid;
             if (idx < n) {
-                const float ox = rb[k].x - fbx, oy = rb[k].y - fby;
+                const float ox = fmaf(0.5f * f.W, rb[k].x, 0.5f * f.W - fbx), oy = fmaf(-0.5f * f.H, rb[k].y, 0.5f * f.H - fby);   // F3, sequence v3
                 const float nku = -fmaf(ra[k].x, ox, ra[k].y * oy);
                 const float nkv = -fmaf(ra[k].z, ox, ra[k].w * oy);
                 s_q0[idx] = make_float4(ra[k].x, ra[k].y, nku, __builtin_amdgcn_logf(rb[k].z));
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64) void k_composite_s(const Frame f, const uint32_
             const uint32_t idx = (uint32_t)k * 64u + lane;
             if (idx < n) {
                 // the tile-local pixel-centre box first (k_composite's): a pair that misses this wave's rows is not staged
-                const float ox = rb[k].x - fbx, oy = rb[k].y - fby;
+                const float ox = fmaf(0.5f * f.W, rb[k].x, 0.5f * f.W - fbx), oy = fmaf(-0.5f * f.H, rb[k].y, 0.5f * f.H - fby);   // F3, sequence v3
                 const float ria = __builtin_amdgcn_rcpf(fmaf(ra[k].y, ra[k].y, ra[k].x * ra[k].x)), rib = __builtin_amdgcn_rcpf(fmaf(ra[k].w, ra[k].w, ra[k].z * ra[k].z));
                 const float qux = ra[k].x * ria, quy = ra[k].y * ria, qwx = ra[k].z * rib, qwy = ra[k].w * rib;
                 const float bhx = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwx, qwx, qux * qux)), 1.0001f, 0.002f);

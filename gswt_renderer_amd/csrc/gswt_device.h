@@ -76,13 +76,14 @@ struct Frame {
 };
 
 // Projected splat record consumed by the compositor (32 B, two 16-B words; one 32-B-aligned sector per gather).
-//   q0 = (iux, iuy, ivx, ivy)   q1 = (cxp, cyp, alpha, rgba8 bits)
-// iu / iv: rows of the inverse affine map pixel -> quad space (F2); (cxp, cyp): pixel-space centre (F1).
+//   q0 = (iux, iuy, ivx, ivy)   q1 = (ndc.x, ndc.y, alpha, rgba8 bits)
+// iu / iv: rows of the inverse affine map pixel -> quad space (F2); the centre stays in NDC (round 4): the compositor derives its offset
+// from a tile origin with one rounding (F3), instead of subtracting the origin from a pixel-space centre that carries two roundings at ~W.
 // The conservative pixel half extents of |p| <= 2 are re-derived from iu / iv by the compositor's staging lane; the depth
 // lives in a side array (4 B per slot) that only depth-tested (proxy depth bound) and depth-ordered frames touch.
 struct __attribute__((aligned(32))) Rec {
     float iux, iuy, ivx, ivy;
-    float cxp, cyp, alpha, rgba8;
+    float ndcx, ndcy, alpha, rgba8;
 };
 
 // Device-side merged-list building (see k_mg_* in gswt_kernels.hip)

@@ -902,7 +902,8 @@ __global__ __launch_bounds__(256) void k_project(
                     // goes to a side array that only depth-tested / depth-ordered frames read
                     Rec* dst = recs + slot;
                     reinterpret_cast<float4*>(dst)[0] = make_float4(r_iux, r_iuy, r_ivx, r_ivy);
-                    reinterpret_cast<float4*>(dst)[1] = make_float4(cxp, cyp, ca, __uint_as_float(w1.w));
+                    // (the centre travels in NDC: the compositor takes its offset from a tile origin with one rounding, F3 of DESIGN.md section 4)
+                    reinterpret_cast<float4*>(dst)[1] = make_float4(ndcx, ndcy, ca, __uint_as_float(w1.w));
                     if (depths) depths[slot] = depth;
                     if (FULL && f.draw_mode != 0u) col_f[slot] = make_float4(cr, cg, cb, 0.0f);   // debug colours are not bytes
                 }
@@ -1483,9 +1484,9 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
 //   radix sort      stable LSD on the bits of (key - smallest) that are in use: equal depths keep composite order; only what can be
 //                   visible is sorted (round 3 sorted every slot of the frame: 10 M at c3 for 1.9 M that emit), and no host word enters
 //                   the chain, so the frame is one hipGraph like any other
-//   k_perm_counts   pairs of every 256 positions of the sorted list + their per-65 536 sums (atomics on a few words)
-//   k_emit_perm     emits the pairs in depth order; a block's first pair = the super sums in front of it + the block counts of its
-//                   own super-group in front of it (summed by the block itself, as k_emit does: no scan launch)
+//   k_perm_counts   pairs of every 1024 positions of the sorted list (one plain store per workgroup)
+//   k_perm_scan     their exclusive prefix (one workgroup)
+//   k_emit_perm     emits the pairs in depth order: first pair of a workgroup = its prefix word, then a workgroup-wide scan
 // The tile-bit sort and the compositor are unchanged.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ rects, const float* __restrict__ depths,
@@ -1553,56 +1554,95 @@ __global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ re
     }
 }
 
-// pair count of every 256-position block of the depth-ordered slot list, and the sums of 256 consecutive blocks
-__global__ __launch_bounds__(256) void k_perm_counts(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
-                                                     const uint32_t* __restrict__ krange,
-                                                     const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
-                                                     uint32_t* __restrict__ block_cnt, uint32_t* __restrict__ super_cnt)
+// 1024-thread workgroup: exclusive scan of one value per thread, *total = workgroup sum
+__device__ __forceinline__ uint32_t block1024_excl_scan(uint32_t v, uint32_t* s_w /*[16]*/, uint32_t* total)
 {
-    __shared__ uint32_t s_w[4];
-    const uint32_t n = clamped_count(n_ptr, emit_cap);
-    if (blockIdx.x * 256u >= n) return;
-    const uint2* rect = (sort_passes_run(krange) & 1u) ? rect_b : rect_a;
-    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    const uint2 rc = rect[min(pos, n - 1u)];
-    uint32_t count = 0;
-    if (pos < n) {
-        const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
-        count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
-    }
-    uint32_t tot;
-    (void)block_excl_scan(count, s_w, &tot);
-    if (threadIdx.x == 0) { block_cnt[blockIdx.x] = tot; if (tot) atomicAdd(&super_cnt[blockIdx.x >> 8], tot); }
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63u) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; i++) { const uint32_t t = s_w[i]; if (i < w) base += t; tot += t; }
+    *total = tot;
+    __syncthreads();
+    return base + inc - v;
 }
 
-__global__ __launch_bounds__(256) void k_emit_perm(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
-                                                   const uint32_t* __restrict__ perm_a,
-                                                   const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
-                                                   const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
-                                                   const uint32_t* __restrict__ block_cnt, const uint32_t* __restrict__ super_cnt, uint32_t pair_cap,
-                                                   unsigned long long* __restrict__ counters, uint32_t* __restrict__ keys,
-                                                   uint32_t* __restrict__ vals)
+__device__ __forceinline__ uint32_t rect_pairs(const Frame& f, uint2 rc)
 {
-    __shared__ uint32_t s_w[8];
+    const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
+    return (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
+}
+
+// Pairs of every 1024 positions of the depth-ordered list (the rects arrive in that order: the sort carried them).  Plain stores, one per
+// workgroup; k_perm_scan turns them into exclusive prefixes.  (Round-4 first version: 256-position blocks adding their counts to per-65 536
+// sums with atomics -- neighbouring workgroups then hit the same word at the same time: 58 us for 7.4 k atomics at c3.)
+__global__ __launch_bounds__(1024) void k_perm_counts(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
+                                                      const uint32_t* __restrict__ krange,
+                                                      const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
+                                                      uint32_t* __restrict__ group_cnt)
+{
+    __shared__ uint32_t s_w[16];
     const uint32_t n = clamped_count(n_ptr, emit_cap);
-    if (blockIdx.x * 256u >= n) return;
+    if (blockIdx.x * 1024u >= n) return;
+    const uint2* rect = (sort_passes_run(krange) & 1u) ? rect_b : rect_a;
+    const uint32_t pos = blockIdx.x * 1024u + threadIdx.x;
+    const uint2 rc = rect[min(pos, n - 1u)];
+    uint32_t count = pos < n ? rect_pairs(f, rc) : 0u;
+    for (int o = 32; o > 0; o >>= 1) count += (uint32_t)__shfl_down((int)count, o, 64);
+    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = count;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) t += s_w[i];
+        group_cnt[blockIdx.x] = t;
+    }
+}
+
+// single workgroup: group_cnt[0 .. ceil(n / 1024)) -> exclusive prefix, in place
+__global__ __launch_bounds__(1024) void k_perm_scan(uint32_t* __restrict__ group_cnt, const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap)
+{
+    __shared__ uint32_t s_w[16];
+    const uint32_t n = clamped_count(n_ptr, emit_cap);
+    const uint32_t G = (n + 1023u) >> 10;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < G; base += 4096u) {
+        const uint32_t i = base + threadIdx.x * 4u;
+        uint32_t p[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint32_t v = group_cnt[min(i + (uint32_t)k, G - 1u)]; p[k] = i + k < G ? v : 0u; sum += p[k]; }
+        uint32_t tot;
+        uint32_t ex = block1024_excl_scan(sum, s_w, &tot) + carry;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (i + k < G) group_cnt[i + k] = ex; ex += p[k]; }
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_emit_perm(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
+                                                    const uint32_t* __restrict__ perm_a,
+                                                    const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
+                                                    const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
+                                                    const uint32_t* __restrict__ group_excl, uint32_t pair_cap,
+                                                    unsigned long long* __restrict__ counters, uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals)
+{
+    __shared__ uint32_t s_w[16];
+    const uint32_t n = clamped_count(n_ptr, emit_cap);
+    if (blockIdx.x * 1024u >= n) return;
     const bool in_b = (sort_passes_run(krange) & 1u) != 0u;
     const uint32_t* perm = in_b ? perm_b : perm_a;
     const uint2* rect = in_b ? rect_b : rect_a;
-    const uint32_t pos = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t sb = blockIdx.x >> 8, b0 = blockIdx.x & ~255u;
-    // pairs in front of this block: the super-groups in front of its own (thread t sums supers t, t + 256, ...) + the blocks of its own
-    // super-group in front of it
-    uint32_t front = b0 + threadIdx.x < blockIdx.x ? block_cnt[b0 + threadIdx.x] : 0u;
-    for (uint32_t j = threadIdx.x; j < sb; j += 256u) front += super_cnt[j];
+    const uint32_t pos = blockIdx.x * 1024u + threadIdx.x;
+    const uint32_t chunk_base = group_excl[blockIdx.x];
     const uint32_t slot = perm[min(pos, n - 1u)];
     const uint2 rc = rect[min(pos, n - 1u)];
-    uint32_t count = 0;
     const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
-    if (pos < n) count = (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
-    uint32_t tot, chunk_base;
-    uint32_t off = block_scan_and_sum(count, front, s_w, &tot, &chunk_base);
-    off += chunk_base;
+    const uint32_t count = pos < n ? rect_pairs(f, rc) : 0u;
+    uint32_t tot;
+    uint32_t off = chunk_base + block1024_excl_scan(count, s_w, &tot);
     if ((unsigned long long)chunk_base + tot > (unsigned long long)pair_cap) {
         if (threadIdx.x == 0 && tot) atomicOr(&counters[3], 1ull);
         return;
@@ -2155,6 +2195,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     // tile origin as floats: uniform, kept in SGPRs (a v_cvt of a scalar would park them in two VGPRs for the whole kernel)
     const float fbx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)bx)));
     const float fby = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)by)));
+    // F3 (sequence v3): centre - tile origin = fma(W/2, ndc.x, W/2 - bx), fma(-H/2, ndc.y, H/2 - by): ONE rounding at the magnitude of the
+    // offset; W/2 - bx and H/2 - by are exact and uniform (SGPRs)
+    const float hW = 0.5f * f.W, hHn = -0.5f * f.H;
+    const float c0x = hW - fbx, c0y = 0.5f * f.H - fby;
     uint16_t* const wlist = &s_list[wave][0][0];
     const CompLane cl = {lx, ly, (int)(wave * 4u), lane, grp};
     const uint2 rg = make_uint2(it.z, it.w);         // this item's slice of the tile's pair list
@@ -2206,7 +2250,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
         if (GSWT_ABL(f, 4)) break;                       // ablation: no staging at all
         if (tid < n) {
             // F3: per-(splat, tile) constants
-            const float ox = rb.x - fbx, oy = rb.y - fby;
+            const float ox = fmaf(hW, rb.x, c0x), oy = fmaf(hHn, rb.y, c0y);
             const float nku = -fmaf(ra.x, ox, ra.y * oy);
             const float nkv = -fmaf(ra.z, ox, ra.w * oy);
             const float l2a = __builtin_amdgcn_logf(rb.z);                           // v_log_f32 = log2; log2(0) = -inf -> B = 0
@@ -2503,11 +2547,13 @@ void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_chunks, uint32_
     GSWT_LAUNCH(k_depth_keys, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), s, rects, depths, block_sums, block_emit, emit_excl, n_chunks,
                 emit_cap, (const unsigned long long*)counters, dk_a, dv_a, rect_a, krange);
     (void)launch_sort(s, dk_a, dv_a, dk_b, dv_b, emit_cap, counters + 4, 32, radix_ws, nullptr, krange, rect_a, rect_b);
-    const uint32_t nb = (emit_cap + 255u) / 256u;
-    GSWT_LAUNCH(k_perm_counts, dim3(nb), dim3(256), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)krange,
-                (const unsigned long long*)(counters + 4), emit_cap, block_cnt, super_cnt);
-    GSWT_LAUNCH(k_emit_perm, dim3(nb), dim3(256), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
-                (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)block_cnt, (const uint32_t*)super_cnt, pair_cap, counters, keys, vals);
+    const uint32_t ng = (emit_cap + 1023u) / 1024u;
+    (void)super_cnt;
+    GSWT_LAUNCH(k_perm_counts, dim3(ng), dim3(1024), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)krange,
+                (const unsigned long long*)(counters + 4), emit_cap, block_cnt);
+    GSWT_LAUNCH(k_perm_scan, dim3(1), dim3(1024), s, block_cnt, (const unsigned long long*)(counters + 4), emit_cap);
+    GSWT_LAUNCH(k_emit_perm, dim3(ng), dim3(1024), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
+                (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)block_cnt, pair_cap, counters, keys, vals);
 }
 
 // Builds every merged group's (gs_index | lod, map_id) list on the device.  keys/vals a,b: n_total u32 each;

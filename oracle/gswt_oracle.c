@@ -832,7 +832,8 @@ ORC_API int orc_project(const orc_camera *cam, const orc_scene *s, const orc_til
 /* does per screen tile).                                                       */
 /* ------------------------------------------------------------------------- */
 typedef struct {
-    float cxp, cyp;       /* pixel-space centre                     */
+    float cxp, cyp;       /* pixel-space centre (conservative box only) */
+    float ndcx, ndcy;     /* the centre in NDC: F3 takes the block-local offset from it with ONE rounding */
     float iux, iuy;       /* quad-x row of the inverse affine map   */
     float ivx, ivy;       /* quad-y row                             */
     float hx, hy;         /* conservative half extents in pixels    */
@@ -844,6 +845,7 @@ static void frag_setup(const orc_splat *sp, float splat_scale, float W, float H,
     /* F1: pixel-space centre */
     fs->cxp = fmaf(0.5f, sp->ndc[0], 0.5f) * W;
     fs->cyp = fmaf(-0.5f, sp->ndc[1], 0.5f) * H;
+    fs->ndcx = sp->ndc[0]; fs->ndcy = sp->ndc[1];
     /* F2: pixel-space image of the unit quad axes (framebuffer y is down); the rows of the inverse affine map are
      * iu = u / |u|^2, iv = w / |w|^2, each with ONE reciprocal */
     float hs = 0.5f * splat_scale;
@@ -878,8 +880,12 @@ static void raster_over(const orc_splat *sp, const orc_frag_setup *fs, int W, in
     if (y1 < y0) return;
     for (int by = y0 & ~15; by <= y1; by += 16) {
         for (int bx = x0 & ~15; bx <= x1; bx += 16) {
-            /* F3: per-block constants */
-            float ox = fs->cxp - (float)bx, oy = fs->cyp - (float)by;
+            /* F3: per-block constants.  Sequence v3 (round 4): the centre's offset from the block origin straight from NDC with ONE
+             * rounding, o = fma(W/2, ndc.x, W/2 - bx) (W/2 - bx is exact), instead of (pixel-space centre) - bx: the pixel-space centre
+             * carries two roundings at magnitude ~W (ulp 1.2e-4 px at x = 1900), which a thin ellipse (|iv| ~ 20 / px) turns into
+             * ~2e-3 in p -- the continuous term that kept single pixels 1.2e-4 away from the strict image. */
+            float ox = fmaf(0.5f * (float)W, fs->ndcx, 0.5f * (float)W - (float)bx);
+            float oy = fmaf(-0.5f * (float)H, fs->ndcy, 0.5f * (float)H - (float)by);
             float nku = -fmaf(fs->iux, ox, fs->iuy * oy);
             float nkv = -fmaf(fs->ivx, ox, fs->ivy * oy);
             int ya = by < y0 ? y0 : by, yb = by + 15 > y1 ? y1 : by + 15;
@@ -1096,10 +1102,11 @@ ORC_API int orc_render(const orc_camera *cam, const orc_scene *scene, const uint
 }
 
 /* v2 coverage decision of one pixel (F3 / F4 of raster_over, the sequence the HIP compositor evaluates) */
-static inline int cover_v2(const orc_frag_setup *fs, int x, int y)
+static inline int cover_v2(const orc_frag_setup *fs, int W, int H, int x, int y)
 {
     int bx = x & ~15, by = y & ~15;
-    float ox = fs->cxp - (float)bx, oy = fs->cyp - (float)by;
+    float ox = fmaf(0.5f * (float)W, fs->ndcx, 0.5f * (float)W - (float)bx);
+    float oy = fmaf(-0.5f * (float)H, fs->ndcy, 0.5f * (float)H - (float)by);
     float nku = -fmaf(fs->iux, ox, fs->iuy * oy);
     float nkv = -fmaf(fs->ivx, ox, fs->ivy * oy);
     float ly = (float)(y - by) + 0.5f, lx = (float)(x - bx) + 0.5f;
@@ -1171,7 +1178,7 @@ ORC_API int orc_compare_modes2(const orc_camera *cam, const orc_scene *scene, co
             for (int y = y0; y <= y1; y++)
                 for (int x = x0; x <= x1; x++) {
                     float dbuf = bg_depth ? bg_depth[(size_t)y * W + x] : 1.0f;
-                    int ca = a.visible && cover_v2(&fa, x, y) && a.depth < dbuf;
+                    int ca = a.visible && cover_v2(&fa, W, H, x, y) && a.depth < dbuf;
                     int cb = b.visible && cover_strict(&b, scene->splat_scale, W, H, x, y) && b.depth < dbuf;
                     if (ca != cb) { flips++; mask[(size_t)y * W + x] = 1; }
                 }
