@@ -35,7 +35,7 @@ void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, u
 size_t radix_ws_words(uint32_t, int);
 size_t radix_ws_zero_words(uint32_t, int);
 void launch_emit_depth(hipStream_t, const Frame&, uint32_t, uint32_t, const uint2*, const float*, const uint32_t*, const uint32_t*, const uint32_t*,
-                       uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint2*, uint2*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t,
+                       uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint2*, uint2*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t,
                        unsigned long long*, uint32_t*, uint32_t*);
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
@@ -245,6 +245,7 @@ struct FrameSlot {
     DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x emit_cap key / slot ping-pong + per-block pair counts + per-chunk emitting-slot counts
     uint32_t emit_cap = 0;                 // ... and the capacity (emitting slots) that frame was launched for
     bool strict_vs = false;                // GSWT_OPT_STRICT_VS as it stood when the frame was submitted (a re-run keeps it)
+    uint32_t depth_passes = 0;             // GSWT_ORDER_DEPTH: radix passes this frame's depth sort was launched with
     DevBuf<float4> partials;
     DevBuf<float4> col_f;                  // debug draw modes: float colours per slot
     DevBuf<float> depths;                  // per-slot depth: frames with a proxy depth buffer or GSWT_ORDER_DEPTH only
@@ -323,6 +324,10 @@ struct gswt_ctx {
     // frame (the per-frame buffers live in the slots)
     uint32_t pair_cap = 0;                 // capacity the pair buffers / grids are sized for (grows on overflow)
     uint32_t emit_cap = 0;                 // GSWT_ORDER_DEPTH: capacity of the depth sort in emitting slots (<= visible splats; grows like pair_cap)
+    // ... and its number of 8-bit passes: as many as the key ranges of the recent frames needed (the depths of one c3 frame span ~2^21
+    // ulps: three).  A frame that needs more is flagged on the device and re-run; 32 frames in a row that need fewer give one back.
+    uint32_t depth_passes = 3;
+    uint32_t depth_passes_low_run = 0, depth_passes_low_max = 0;
     int last_slot = 0;
     DevBuf<float4> bg_rgba, out_img;
     DevBuf<float> bg_depth;
@@ -625,6 +630,10 @@ try {
     case GSWT_OPT_EMIT_CAP:
         if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "depth-sort capacity must be >= 0");
         c->emit_cap = (uint32_t)value;              // 0: sized from the next draw list
+        return GSWT_OK;
+    case GSWT_OPT_DEPTH_PASSES:
+        if (value < 1 || value > 4) return fail(c, GSWT_ERR_BAD_ARG, "depth-sort passes must be 1..4");
+        c->depth_passes = (uint32_t)value; c->depth_passes_low_run = 0;
         return GSWT_OK;
     case GSWT_OPT_PAIR_CAP:
         if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "pair capacity must be >= 0");
@@ -1378,7 +1387,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     if (depth_order && c->emit_cap == 0) c->emit_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(D.n_entries / 4, 1u << 18), n_slots);
     const uint32_t ecap = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->emit_cap, 256u), std::max<uint32_t>(n_slots, 256u)) : 0u;
     sl.emit_cap = ecap;
-    const size_t n_psuper = depth_order ? (size_t)ecap / 65536 + 2 : 0;     // sums of 256 blocks of 256 positions of the depth-ordered list
+    const size_t n_psuper = 0;
+    sl.depth_passes = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->depth_passes, 1u), 4u) : 0u;
     // radix workspaces: the zeroed parts of BOTH sorts first (group rows, digit totals), the per-workgroup rows (written in full) behind
     const size_t rz_pair = radix_ws_zero_words(cap, key_bits), rz_depth = depth_order ? radix_ws_zero_words(ecap, 32) : 0;
     const size_t rw_pair = radix_ws_words(cap, key_bits), rw_depth = depth_order ? radix_ws_words(ecap, 32) : 0;
@@ -1447,7 +1457,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
                           dw, dw + ecap, dw + 2 * (size_t)ecap, dw + 3 * (size_t)ecap, reinterpret_cast<uint2*>(d_crect),
                           reinterpret_cast<uint2*>(d_crect) + ecap, d_radix_depth,
                           reinterpret_cast<uint32_t*>(d_counters + 5),
-                          d_block_cnt, d_psuper, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
+                          d_block_cnt, sl.depth_passes, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
     }
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
     // ---- stable sort on the tile bits
@@ -1490,16 +1500,24 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
         if (P64 > sl.cap || sl.args.cfg.order_mode != GSWT_ORDER_DEPTH)
             c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 2 + 4096, 0xFFFFFF00ull));
         // depth order: the emitting slots are at most the visible splats, which the frame counted whatever overflowed
-        if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH)
+        if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH) {
             c->emit_cap = std::max<uint32_t>(c->emit_cap, (uint32_t)std::min<uint64_t>(sl.hc[0] + sl.hc[0] / 2 + 4096, 0xFFFFFF00ull));
+            if (sl.hc[2] > sl.depth_passes) { c->depth_passes = (uint32_t)std::min<unsigned long long>(sl.hc[2], 4ull); c->depth_passes_low_run = 0; }
+        }
         int rc = enqueue_frame(c, sl);
         if (rc != GSWT_OK) return rc;
     }
     const uint32_t P = (uint32_t)sl.hc[1];
     // keep 25-50 % headroom over the running pair count without shrinking on every small dip
     if (!c->opt_fixed_pair_cap && (uint64_t)P + P / 4 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 2 + 4096, 0xFFFFFF00ull);
-    if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH && sl.hc[0] + sl.hc[0] / 4 > c->emit_cap)
-        c->emit_cap = (uint32_t)std::min<uint64_t>(sl.hc[0] + sl.hc[0] / 2 + 4096, 0xFFFFFF00ull);
+    if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH) {
+        if (sl.hc[0] + sl.hc[0] / 4 > c->emit_cap) c->emit_cap = (uint32_t)std::min<uint64_t>(sl.hc[0] + sl.hc[0] / 2 + 4096, 0xFFFFFF00ull);
+        const uint32_t need = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(sl.hc[2], 1ull), 4ull);
+        if (need < c->depth_passes && sl.depth_passes == c->depth_passes) {
+            c->depth_passes_low_max = c->depth_passes_low_run ? std::max(c->depth_passes_low_max, need) : need;
+            if (++c->depth_passes_low_run >= 32u) { c->depth_passes = c->depth_passes_low_max; c->depth_passes_low_run = 0; }
+        } else if (need >= c->depth_passes) c->depth_passes_low_run = 0;
+    }
     gswt_timings& t = c->timings;
     memset(&t, 0, sizeof(t));
     hipEvent_t* ev = sl.ev;

@@ -1190,8 +1190,10 @@ __device__ __forceinline__ void load_krange(const uint32_t* __restrict__ krange,
     kmin = ~krange[0]; kmax = krange[1];
     if (kmax < kmin) { kmin = 0u; kmax = 0u; }
 }
-// Number of radix passes that really ran for keys in [kmin, kmax] (see k_radix_hist): pass p covers bits 8p .. 8p+7 of key - kmin.
-__device__ __forceinline__ uint32_t sort_passes_run(const uint32_t* __restrict__ krange)
+// Number of radix passes the keys in [kmin, kmax] need (see k_radix_hist): pass p covers bits 8p .. 8p+7 of key - kmin.  The host
+// launches as many passes as the previous frames needed (three at c3: visible depths of one frame span ~2^21 ulps); a frame that needs
+// more is flagged by k_perm_scan and re-run, like a capacity overflow.  Passes run = min(needed, launched).
+__device__ __forceinline__ uint32_t sort_passes_needed(const uint32_t* __restrict__ krange)
 {
     uint32_t kmin, kmax;
     load_krange(krange, kmin, kmax);
@@ -1579,14 +1581,14 @@ __device__ __forceinline__ uint32_t rect_pairs(const Frame& f, uint2 rc)
 // workgroup; k_perm_scan turns them into exclusive prefixes.  (Round-4 first version: 256-position blocks adding their counts to per-65 536
 // sums with atomics -- neighbouring workgroups then hit the same word at the same time: 58 us for 7.4 k atomics at c3.)
 __global__ __launch_bounds__(1024) void k_perm_counts(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
-                                                      const uint32_t* __restrict__ krange,
+                                                      const uint32_t* __restrict__ krange, uint32_t n_launched,
                                                       const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
                                                       uint32_t* __restrict__ group_cnt)
 {
     __shared__ uint32_t s_w[16];
     const uint32_t n = clamped_count(n_ptr, emit_cap);
     if (blockIdx.x * 1024u >= n) return;
-    const uint2* rect = (sort_passes_run(krange) & 1u) ? rect_b : rect_a;
+    const uint2* rect = (min(sort_passes_needed(krange), n_launched) & 1u) ? rect_b : rect_a;
     const uint32_t pos = blockIdx.x * 1024u + threadIdx.x;
     const uint2 rc = rect[min(pos, n - 1u)];
     uint32_t count = pos < n ? rect_pairs(f, rc) : 0u;
@@ -1602,10 +1604,18 @@ __global__ __launch_bounds__(1024) void k_perm_counts(const Frame f, const uint2
 }
 
 // single workgroup: group_cnt[0 .. ceil(n / 1024)) -> exclusive prefix, in place
-__global__ __launch_bounds__(1024) void k_perm_scan(uint32_t* __restrict__ group_cnt, const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap)
+// Also the depth sort's pass check: counters[2] = passes this frame's key range needs; more than were launched = the sorted list is not
+// sorted: the frame is flagged (counters[3]) and the host re-runs it with more passes.
+__global__ __launch_bounds__(1024) void k_perm_scan(uint32_t* __restrict__ group_cnt, const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
+                                                    const uint32_t* __restrict__ krange, uint32_t n_launched, unsigned long long* __restrict__ counters)
 {
     __shared__ uint32_t s_w[16];
     const uint32_t n = clamped_count(n_ptr, emit_cap);
+    if (threadIdx.x == 0u) {
+        const uint32_t need = sort_passes_needed(krange);
+        counters[2] = need;
+        if (need > n_launched) counters[3] = 1ull;
+    }
     const uint32_t G = (n + 1023u) >> 10;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < G; base += 4096u) {
@@ -1623,7 +1633,7 @@ __global__ __launch_bounds__(1024) void k_perm_scan(uint32_t* __restrict__ group
 
 __global__ __launch_bounds__(1024) void k_emit_perm(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
                                                     const uint32_t* __restrict__ perm_a,
-                                                    const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange,
+                                                    const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange, uint32_t n_launched,
                                                     const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
                                                     const uint32_t* __restrict__ group_excl, uint32_t pair_cap,
                                                     unsigned long long* __restrict__ counters, uint32_t* __restrict__ keys,
@@ -1632,7 +1642,7 @@ __global__ __launch_bounds__(1024) void k_emit_perm(const Frame f, const uint2* 
     __shared__ uint32_t s_w[16];
     const uint32_t n = clamped_count(n_ptr, emit_cap);
     if (blockIdx.x * 1024u >= n) return;
-    const bool in_b = (sort_passes_run(krange) & 1u) != 0u;
+    const bool in_b = (min(sort_passes_needed(krange), n_launched) & 1u) != 0u;
     const uint32_t* perm = in_b ? perm_b : perm_a;
     const uint2* rect = in_b ? rect_b : rect_a;
     const uint32_t pos = blockIdx.x * 1024u + threadIdx.x;
@@ -2535,25 +2545,24 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
 
 // GSWT_ORDER_DEPTH front end (after k_project / k_totals): compaction of the emitting slots -> radix sort on the depth bits in use ->
 // per-block pair counts -> emission in depth order.  dk_a/dv_a/dk_b/dv_b: emit_cap u32 each; rect_a / rect_b: emit_cap uint2 each; radix_ws: radix_ws_words(emit_cap, 32)
-// words whose radix_ws_zero_words(emit_cap, 32) first are zero; krange = (~0, 0) and super_cnt zero on entry (k_cull's zero region);
+// words whose radix_ws_zero_words(emit_cap, 32) first are zero; krange zero on entry (k_cull's zero region); n_passes: radix passes to launch;
 // counters[4] = number of emitting slots (k_totals).  Every launch goes through GSWT_LAUNCH: the frame is graph-able.
 void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_chunks, uint32_t emit_cap, const uint2* rects,
                        const float* depths, const uint32_t* block_sums, const uint32_t* block_emit, const uint32_t* emit_excl,
                        uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b, uint2* rect_a, uint2* rect_b,
-                       uint32_t* radix_ws, uint32_t* krange, uint32_t* block_cnt, uint32_t* super_cnt, uint32_t pair_cap,
+                       uint32_t* radix_ws, uint32_t* krange, uint32_t* block_cnt, uint32_t n_passes, uint32_t pair_cap,
                        unsigned long long* counters, uint32_t* keys, uint32_t* vals)
 {
     if (n_chunks == 0 || emit_cap == 0) return;
     GSWT_LAUNCH(k_depth_keys, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), s, rects, depths, block_sums, block_emit, emit_excl, n_chunks,
                 emit_cap, (const unsigned long long*)counters, dk_a, dv_a, rect_a, krange);
-    (void)launch_sort(s, dk_a, dv_a, dk_b, dv_b, emit_cap, counters + 4, 32, radix_ws, nullptr, krange, rect_a, rect_b);
+    (void)launch_sort(s, dk_a, dv_a, dk_b, dv_b, emit_cap, counters + 4, 8 * (int)n_passes, radix_ws, nullptr, krange, rect_a, rect_b);
     const uint32_t ng = (emit_cap + 1023u) / 1024u;
-    (void)super_cnt;
-    GSWT_LAUNCH(k_perm_counts, dim3(ng), dim3(1024), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)krange,
+    GSWT_LAUNCH(k_perm_counts, dim3(ng), dim3(1024), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)krange, n_passes,
                 (const unsigned long long*)(counters + 4), emit_cap, block_cnt);
-    GSWT_LAUNCH(k_perm_scan, dim3(1), dim3(1024), s, block_cnt, (const unsigned long long*)(counters + 4), emit_cap);
+    GSWT_LAUNCH(k_perm_scan, dim3(1), dim3(1024), s, block_cnt, (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)krange, n_passes, counters);
     GSWT_LAUNCH(k_emit_perm, dim3(ng), dim3(1024), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
-                (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)block_cnt, pair_cap, counters, keys, vals);
+                n_passes, (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)block_cnt, pair_cap, counters, keys, vals);
 }
 
 // Builds every merged group's (gs_index | lod, map_id) list on the device.  keys/vals a,b: n_total u32 each;

@@ -194,7 +194,9 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                   (fma chains, one reciprocal per quotient: also legal WGSL, ~25 % fewer instructions, the default until
                                   round 3); the two differ by up to 5e-4 in the image on thin ellipses */,
        GSWT_OPT_EMIT_CAP = 11 /* test hook: start the GSWT_ORDER_DEPTH sort capacity (splats that emit pairs) at `value`; a frame that
-                                 outgrows it is re-run with more room, like a pair overflow (0: sized from the next draw list) */ };
+                                 outgrows it is re-run with more room, like a pair overflow (0: sized from the next draw list) */,
+       GSWT_OPT_DEPTH_PASSES = 12 /* test hook: 8-bit radix passes the next GSWT_ORDER_DEPTH frame launches (1..4; default 3, then as many as
+                                     the key ranges of the recent frames needed); a frame whose depths span more bits is re-run with more */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

@@ -132,3 +132,11 @@ def test_depth_sort_capacity_overflow_is_rerun(renderer):
     assert H.max_abs_diff(img, ref_d) <= TOL
     img2 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)       # capacity sized from the draw list again
     assert np.array_equal(img, img2)
+    # ... and the number of radix passes: launched with one 8-bit pass, the frame's depth range needs more -> flagged, re-run
+    renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 1)
+    img3 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+    assert np.array_equal(img, img3)
+    renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 4)                                        # more passes than needed: the extra ones leave at once
+    img4 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+    assert np.array_equal(img, img4)
+    renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 3)
