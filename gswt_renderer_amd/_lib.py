@@ -34,6 +34,7 @@ GSWT_OPT_GRAPH = 9
 GSWT_OPT_STRICT_VS = 10
 GSWT_OPT_EMIT_CAP = 11
 GSWT_OPT_DEPTH_PASSES = 12
+GSWT_OPT_COMPOSITE = 13
 GSWT_SHARD_ROWS = 0
 GSWT_SHARD_COLUMNS = 1
 

@@ -48,7 +48,7 @@ void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr,
                 const uint32_t* = nullptr, uint2* = nullptr, uint2* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, const unsigned long long*, unsigned long long*);
+                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, const unsigned long long*, unsigned long long*, int);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
 void launch_proxy(hipStream_t, const ProxyArgs&, const float*, const float4*, float4*, float*);
@@ -309,6 +309,7 @@ struct gswt_ctx {
     // GSWT_OPT_STRICT_VS (default ON since round 4: k_project<.,.,STRICT> costs +1 us of 71 at c3 and nothing in frames/s): vs_main is
     // evaluated operator by operator as gswt.wgsl:152-258 writes it; 0 selects the fma-chain / single-reciprocal sequence v2
     int opt_strict_vs = 1;
+    int opt_composite = 0;                 // GSWT_OPT_COMPOSITE: 0 = k_composite (two barriers per 256-pair batch), 1 = k_composite_dw (decoupled waves)
     unsigned long long stat_graph_launches = 0, stat_graph_rebuilds = 0, stat_graph_node_updates = 0;
     int pending_frames = 0;                // GSWT_OPT_DEFER_SWAP >= 2: frames still to be submitted on the old set
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
@@ -631,6 +632,9 @@ try {
         if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "depth-sort capacity must be >= 0");
         c->emit_cap = (uint32_t)value;              // 0: sized from the next draw list
         return GSWT_OK;
+    case GSWT_OPT_COMPOSITE:
+        if (value != 0 && value != 1) return fail(c, GSWT_ERR_BAD_ARG, "unknown compositor variant %d", value);
+        c->opt_composite = value; return GSWT_OK;
     case GSWT_OPT_DEPTH_PASSES:
         if (value < 1 || value > 4) return fail(c, GSWT_ERR_BAD_ARG, "depth-sort passes must be 1..4");
         c->depth_passes = (uint32_t)value; c->depth_passes_low_run = 0;
@@ -1470,7 +1474,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // ---- composite
     launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.depths.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
                      sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr,
-                     d_counters, sl.hc_dev);
+                     d_counters, sl.hc_dev, c->opt_composite);
     c->last_n_tiles = (uint32_t)n_tiles;
     c->last_slot = (int)(&sl - c->slots);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));

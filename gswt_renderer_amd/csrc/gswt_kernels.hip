@@ -1932,18 +1932,21 @@ constexpr uint32_t kNullRec = 256u;        // LDS record no pixel is ever inside
 // longest one -- which paces the wave -- is close to their mean: 1.98 M wave-steps against 2.28 M on the c3 frame).
 // List entries are LDS byte offsets of the records (u16), padded to an even length with the offset of a null record
 // whose r^2 is +inf: the walk needs neither a shift nor an `i < n` test nor a mid-pair exit.
-template <bool EARLY, bool DEPTH, bool COLF, bool PK, bool DPPW>
+// BATCH: pairs per staged batch (256 in k_composite, 128 in k_composite_dw); the list stride and the null record's index follow it.
+template <bool EARLY, bool DEPTH, bool COLF, bool PK, bool DPPW, uint32_t BATCH = 256u>
 __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLane& g, uint32_t n, const float4* s_q0, const float4* s_q1,
                                                    const float4* s_q2, const uint32_t* s_bb, const float* s_dep, uint16_t* wlist,
                                                    float dbuf, float t_eps, float& T, float& ar, float& ag, float& ab, bool& wave_live)
 {
     const uint32_t lane = g.lane, grp = g.grp;
     const float lx = g.lx, ly = g.ly;
-    uint16_t* const my_list = wlist + grp * kListStride;
+    constexpr uint32_t kStride = BATCH == 256u ? kListStride : BATCH + 8u;     // u16 entries per sub-block list
+    constexpr uint32_t kNull = BATCH == 256u ? kNullRec : BATCH;               // index of the null record behind the batch
+    uint16_t* const my_list = wlist + grp * kStride;
     // bin: append this batch's hits to the four sub-block lists (list order preserved)
     uint32_t cnt0 = 0, cnt1 = 0, cnt2 = 0, cnt3 = 0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < (int)(BATCH / 64u); c++) {
         const uint32_t idx = (uint32_t)c * 64u + lane;
         bool h0 = false, h1 = false, h2 = false, h3 = false;
         if (idx < n) {
@@ -1954,7 +1957,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
         const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
 #define GSWT_APPEND(H, M, CNT, G)                                                                                         \
         if (M) {                                                                                                            \
-            if (H) wlist[(G) * kListStride + (CNT) + __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))] = (uint16_t)(idx * 16u); \
+            if (H) wlist[(G) * kStride + (CNT) + __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))] = (uint16_t)(idx * 16u); \
             CNT += (uint32_t)__popcll(M);                                                                                   \
         }
         GSWT_APPEND(h0, m0, cnt0, 0u) GSWT_APPEND(h1, m1, cnt1, 1u) GSWT_APPEND(h2, m2, cnt2, 2u) GSWT_APPEND(h3, m3, cnt3, 3u)
@@ -1975,7 +1978,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
         const uint32_t gi = lane & 15u;
         const uint32_t n_steps = (n_max + 1u) & ~1u;
         const uint32_t n_pad = ((n_max + 15u) & ~15u) + 16u;                 // whole rounds + the prefetched one
-        for (uint32_t p = n_mine + gi; p < n_pad; p += 16u) my_list[p] = (uint16_t)(kNullRec * 16u);
+        for (uint32_t p = n_mine + gi; p < n_pad; p += 16u) my_list[p] = (uint16_t)(kNull * 16u);
         const char* const q0b = reinterpret_cast<const char*>(s_q0);
         const char* const q1b = reinterpret_cast<const char*>(s_q1);
         uint32_t e = my_list[gi];
@@ -2033,7 +2036,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
     }
     // pad this group's list with the null record up to the wave's even step count (+2: the walk reads two entries ahead)
     const uint32_t n_steps = (n_max + 1u) & ~1u;
-    for (uint32_t p = n_mine + (lane & 15u); p < n_steps + 2u; p += 16u) my_list[p] = (uint16_t)(kNullRec * 16u);
+    for (uint32_t p = n_mine + (lane & 15u); p < n_steps + 2u; p += 16u) my_list[p] = (uint16_t)(kNull * 16u);
     // walk: one splat per 16-lane group per step.  Two-deep software pipeline, unrolled x2 so the two record register
     // sets (A, B) never need copying: the list entry is fetched two steps ahead, the record one step ahead.
     const char* const q0b = reinterpret_cast<const char*>(s_q0);
@@ -2351,6 +2354,194 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
 // 50 us walk), but hiding the gathers behind another item's walk inside a workgroup is not what makes them overlap: the
 // dispatcher's dynamic hand-out of ~16 k short workgroups does that better than a static stride over them.
 
+// ------------------------------------------------------------------------------------
+// k_composite_dw: the compositor with DECOUPLED waves (round 4; GSWT_OPT_COMPOSITE = 1).  Same work items, same lane -> pixel map, same
+// F3 / F4 / blend order (bit-identical image), but no workgroup barrier inside an item:
+//   * batches of 128 pairs go through a ring of three LDS buffers;
+//   * batch k is staged by two waves (waves 0, 1 stage the even batches, waves 2, 3 the odd ones: 64 pairs each, the record gathered
+//     into registers two batches of its own earlier, as k_composite's staging lane does);
+//   * per buffer two monotonic LDS counters: `staged` (half batches written into it, ever) and `done` (wave walks finished on it, ever).
+//     A wave walks batch k once staged[k % 3] >= 2 (k / 3 + 1); a buffer is refilled with batch k once done[k % 3] >= 4 (k / 3), i.e.
+//     once all four waves have walked batch k - 3.  A wave stages up to two batches ahead of its own walk without waiting (and waits only
+//     for a batch it is about to walk itself), so the four waves of an item run up to two batches apart instead of meeting at two
+//     s_barriers per 256 pairs -- k_composite idles 41 % of its wave-slots there, a batch lasting as long as its longest sub-block list.
+//   Waiting = polling an LDS word with s_sleep between reads.  EARLY: a wave whose strip is saturated keeps staging and counting, skips
+//   its walks; when all four are, every wave leaves at its next poll.
+// LDS 18.4 KB (k_composite: 17.9 KB): 8 workgroups per CU.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return *reinterpret_cast<const volatile uint32_t*>(p); }
+
+template <bool EARLY, bool DEPTH, bool COLF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COLF ? 6 : DEPTH ? 7 : 8, 8))) void k_composite_dw(const Frame f,
+                                                   const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
+                                                   const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
+                                                   const float* __restrict__ depths, const float4* __restrict__ col_f,
+                                                   const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
+                                                   float4* __restrict__ out, float4* __restrict__ partials,
+                                                   int n_tiles, int out_rows)
+{
+    constexpr uint32_t B = 128u, NBUF = 3u, BS = B + 1u;        // pairs per batch, ring depth, records per buffer (the last one = the null record)
+    __shared__ float4 s_q0[NBUF * BS], s_q1[NBUF * BS];
+    __shared__ uint32_t s_bb[NBUF * B];
+    __shared__ float4 s_q2[COLF ? NBUF * BS : 1];
+    __shared__ float s_dep[DEPTH ? NBUF * BS : 1];
+    __shared__ uint16_t s_list[4][4][B + 8u];
+    __shared__ uint32_t s_staged[NBUF], s_done[NBUF], s_dead;
+    const uint32_t item = blockIdx.x;
+    const uint32_t n_items = item_base[n_tiles];
+    const uint4 it = item_tab[item];
+    if (item >= n_items) return;
+    const int tile = (int)it.x;
+    const bool multi_seg = (it.y & 1u) != 0u;
+    int tx, tyl;
+    tile_xy(f, (uint32_t)tile, tx, tyl);
+    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
+    const int ty = tyl * sc + (sc > 1 ? f.shard_index : 0);
+    const int bx = (tx + f.col0) * kTile, by = ty * kTile;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t grp = lane >> 4, gi = lane & 15u;
+    const int lxi = (int)grp * 4 + (int)(gi & 3u), lyi = (int)wave * 4 + (int)(gi >> 2);
+    const int px = bx + lxi, py = by + lyi;
+    const bool inside = px < f.width && py < f.height;
+    const float lx = (float)lxi + 0.5f, ly = (float)lyi + 0.5f;
+    const float fbx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)bx)));
+    const float fby = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)by)));
+    const float hW = 0.5f * f.W, hHn = -0.5f * f.H;
+    const float c0x = hW - fbx, c0y = 0.5f * f.H - fby;
+    uint16_t* const wlist = &s_list[wave][0][0];
+    const CompLane cl = {lx, ly, (int)(wave * 4u), lane, grp};
+    const uint2 rg = make_uint2(it.z, it.w);
+    float T = (EARLY && !inside) ? 0.0f : 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f;
+    float dbuf = 1.0f;
+    if (DEPTH && inside) dbuf = bg_depth[(size_t)py * f.width + px];
+    const float t_eps = f.t_eps;
+    bool wave_live = true, counted_dead = false;
+    if (tid < NBUF) {
+        s_staged[tid] = 0u; s_done[tid] = 0u;
+        s_q0[tid * BS + B] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);      // the null record of buffer tid: r^2 = +inf for every pixel
+        s_q1[tid * BS + B] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (DEPTH) s_dep[DEPTH ? tid * BS + B : 0u] = 0.0f;
+        if (COLF) s_q2[COLF ? tid * BS + B : 0u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid == 0) s_dead = 0u;
+    const uint32_t n_pairs = rg.y - rg.x;
+    const uint32_t nb = (n_pairs + B - 1u) / B;
+    const uint32_t last_pair = rg.y - 1u;
+    const uint32_t half = wave & 1u;
+    // the batch this wave stages next: ks = (wave >> 1), + 2, + 2, ...; (sb, su) = (ks % 3, ks / 3) kept incrementally
+    uint32_t ks = wave >> 1, sb = wave >> 1, su = 0u;
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rd = ra;
+    float rbw = 0.f;
+    uint32_t slot_nxt = 0;
+#define GSWT_DW_PAIR(KB) min(rg.x + (KB) * B + half * 64u + lane, last_pair)
+#define GSWT_DW_LOAD(SLOT)                                                                           \
+        {                                                                                           \
+            const float4* rp = reinterpret_cast<const float4*>(recs + (SLOT));                      \
+            ra = rp[0];                                                                             \
+            rb = rp[1];                                                                             \
+            if (DEPTH) rbw = depths[(SLOT)];                                                        \
+            if (COLF) rd = col_f[(SLOT)];                                                           \
+        }
+    if (n_pairs) {
+        const uint32_t slot0 = vals[GSWT_DW_PAIR(ks)];
+        GSWT_DW_LOAD(slot0)
+        slot_nxt = vals[GSWT_DW_PAIR(ks + 2u)];
+    }
+    __syncthreads();                                    // the counters and the null records are in place: the only barrier of the item
+    uint32_t kb = 0u, ku = 0u;                           // (k % 3, k / 3) of the batch this wave walks next
+    bool all_dead = false;
+    for (uint32_t k = 0; k < nb && !all_dead; k++) {
+        // ---- staging duties: everything up to two batches ahead of my walk whose buffer is free; a batch I am about to walk is waited for
+        while (ks < nb && ks <= k + 2u) {
+            const uint32_t need = 4u * su;
+            if (lds_peek(&s_done[sb]) < need) {
+                if (ks > k) break;                      // not needed yet: try again after the next walk
+                while (lds_peek(&s_done[sb]) < need) {
+                    if (EARLY && lds_peek(&s_dead) == 4u) { all_dead = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (all_dead) break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t li = half * 64u + lane;      // my pair inside the batch
+            if (ks * B + li < n_pairs) {
+                const uint32_t at = sb * BS + li;
+                const float ox = fmaf(hW, rb.x, c0x), oy = fmaf(hHn, rb.y, c0y);
+                const float nku = -fmaf(ra.x, ox, ra.y * oy);
+                const float nkv = -fmaf(ra.z, ox, ra.w * oy);
+                const float l2a = __builtin_amdgcn_logf(rb.z);
+                s_q0[at] = make_float4(ra.x, ra.y, nku, l2a);
+                s_q1[at] = make_float4(ra.z, ra.w, nkv, rb.w);
+                const float ria = __builtin_amdgcn_rcpf(fmaf(ra.y, ra.y, ra.x * ra.x)), rib = __builtin_amdgcn_rcpf(fmaf(ra.w, ra.w, ra.z * ra.z));
+                const float qux = ra.x * ria, quy = ra.y * ria, qwx = ra.z * rib, qwy = ra.w * rib;
+                const float bhx = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwx, qwx, qux * qux)), 1.0001f, 0.002f);
+                const float bhy = fmaf(2.0f * __builtin_amdgcn_sqrtf(fmaf(qwy, qwy, quy * quy)), 1.0001f, 0.002f);
+                const int xa = min(max((int)ceilf((ox - bhx) - 0.5f), -2), 17), xb = min(max((int)floorf((ox + bhx) - 0.5f), -2), 17);
+                const int ya = min(max((int)ceilf((oy - bhy) - 0.5f), -2), 17), yb = min(max((int)floorf((oy + bhy) - 0.5f), -2), 17);
+                const int gx0 = max(xa >> 2, 0), gx1 = min(xb >> 2, 3), gy0 = max(ya >> 2, 0), gy1 = min(yb >> 2, 3);
+                const uint32_t cx = gx1 >= gx0 ? (2u << gx1) - (1u << gx0) : 0u;
+                const uint32_t ry = gy1 >= gy0 ? (2u << gy1) - (1u << gy0) : 0u;
+                const uint32_t spread = (ry & 1u) | ((ry & 2u) << 3) | ((ry & 4u) << 6) | ((ry & 8u) << 9);
+                s_bb[sb * B + li] = cx * spread;
+                if (DEPTH) s_dep[DEPTH ? at : 0u] = rbw;
+                if (COLF) s_q2[COLF ? at : 0u] = rd;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0u) atomicAdd(&s_staged[sb], 1u);
+            ks += 2u; sb += 2u; if (sb >= 3u) { sb -= 3u; su += 1u; }
+            GSWT_DW_LOAD(slot_nxt)                       // the record of my next staging batch, the slot index of the one after it
+            slot_nxt = vals[GSWT_DW_PAIR(ks + 2u)];
+        }
+        if (all_dead) break;
+        // ---- wait for batch k, walk it
+        {
+            const uint32_t target = 2u * (ku + 1u);
+            while (lds_peek(&s_staged[kb]) < target) {
+                if (EARLY && lds_peek(&s_dead) == 4u) { all_dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (all_dead) break;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        const uint32_t n = min(B, n_pairs - k * B);
+        if (wave_live)
+            composite_bin_walk<EARLY, DEPTH, COLF, false, false, B>(f, cl, n, s_q0 + kb * BS, s_q1 + kb * BS, s_q2 + (COLF ? kb * BS : 0u), s_bb + kb * B,
+                                                                    s_dep + (DEPTH ? kb * BS : 0u), wlist, dbuf, t_eps, T, ar, ag, ab, wave_live);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0u) {
+            atomicAdd(&s_done[kb], 1u);
+            if (EARLY && !wave_live && !counted_dead) atomicAdd(&s_dead, 1u);
+        }
+        if (EARLY && !wave_live) counted_dead = true;
+        kb += 1u; if (kb >= 3u) { kb = 0u; ku += 1u; }
+        if (EARLY && lds_peek(&s_dead) == 4u) all_dead = true;
+    }
+#undef GSWT_DW_PAIR
+#undef GSWT_DW_LOAD
+    const float k255 = 1.0f / 255.0f;
+    if (!COLF) { ar *= k255; ag *= k255; ab *= k255; }
+    if (multi_seg) {
+        partials[(size_t)item * 256u + tid] = make_float4(ar, ag, ab, T);
+        return;
+    }
+    uint32_t tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int lxi2 = (int)(((tid2 & 63u) >> 4) * 4u + (tid2 & 3u)), lyi2 = (int)((tid2 >> 6) * 4u + ((tid2 & 15u) >> 2));
+    const int px2 = bx + lxi2, py2 = by + lyi2;
+    if (px2 < f.width && py2 < f.height) {
+        float4 bg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bg_rgba) bg = bg_rgba[(size_t)py2 * f.width + px2];
+        float4 o;
+        o.x = fmaf(T, bg.x, ar);
+        o.y = fmaf(T, bg.y, ag);
+        o.z = fmaf(T, bg.z, ab);
+        o.w = fmaf(T, bg.w, 1.0f - T);
+        const int orow = tyl * kTile + lyi2;
+        if (orow < out_rows) out[(size_t)orow * f.out_w + (px2 - f.out_x0)] = o;
+    }
+}
+
 #ifdef GSWT_EXPERIMENTS
 #include "gswt_composite_exp.hip"      // compositor variants of round 3 (measured, not shipped)
 #endif
@@ -2593,7 +2784,7 @@ void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs, const float* depths,
                       const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
-                      hipEvent_t ev_begin, hipEvent_t ev_end, const unsigned long long* counters, unsigned long long* host_counters)
+                      hipEvent_t ev_begin, hipEvent_t ev_end, const unsigned long long* counters, unsigned long long* host_counters, int variant)
 {
     if (n_tiles == 0) {                 // a shard without screen tiles (more ranks than tile columns): the events still exist
         if (ev_begin) hipEventRecord(ev_begin, s);
@@ -2666,6 +2857,20 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         return;
     }
 #endif
+    if (variant == 1) {                  // GSWT_OPT_COMPOSITE = 1: decoupled waves (k_composite_dw), same image bit for bit
+#define GSWT_LAUNCH_COMPOSITE_DW(E, D, C)                                                                                      \
+        GSWT_LAUNCH((k_composite_dw<E, D, C>), dim3(max_items), dim3(256), s, f, item_base, item_tab, vals, recs,              \
+                           depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
+        if (colf) { if (depth) GSWT_LAUNCH_COMPOSITE_DW(false, true, true); else GSWT_LAUNCH_COMPOSITE_DW(false, false, true); }
+        else if (early && depth) GSWT_LAUNCH_COMPOSITE_DW(true, true, false);
+        else if (early) GSWT_LAUNCH_COMPOSITE_DW(true, false, false);
+        else if (depth) GSWT_LAUNCH_COMPOSITE_DW(false, true, false);
+        else GSWT_LAUNCH_COMPOSITE_DW(false, false, false);
+#undef GSWT_LAUNCH_COMPOSITE_DW
+        if (ev_end) hipEventRecord(ev_end, s);
+        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+        return;
+    }
 #define GSWT_LAUNCH_COMPOSITE_K(E, D, C, PK, DW)                                                                               \
     GSWT_LAUNCH((k_composite<E, D, C, PK, DW>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
