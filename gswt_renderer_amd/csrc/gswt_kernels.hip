@@ -479,8 +479,12 @@ __device__ unsigned long long g_trace[kTraceItems * 8];
 // the same operations, in the same order, as the CPU checker's strict mode, per splat bit for bit.  The default (sequence v2, DESIGN.md
 // section 4) evaluates the same expressions with fma chains and one reciprocal per quotient -- also legal WGSL, ~25 % fewer instructions,
 // and up to 5e-4 away from this one on thin ellipses (lambda2 = mid - radius cancels).
-template <bool DEBUG, bool FULL, bool STRICT>
-__global__ __launch_bounds__(256) void k_project(
+// HALVES = 2 (round 4): a 512-thread workgroup takes TWO consecutive entries of its XCD's launch list, one per half (waves 0-3 / 4-7), side by
+// side: the same body at the same 64 VGPRs, half the workgroups for the dispatcher to hand out (k_project is dispatch-bound: 13.7 k
+// workgroups of ~5 us started at ~260 per us keep ~1 300 of the chip's 2 048 workgroup slots filled; chunks IN SEQUENCE in one workgroup
+// were slower: more registers, longer lifetime).  The halves meet only at the barrier in front of the per-chunk sums.
+template <bool DEBUG, bool FULL, bool STRICT, int HALVES = 1>
+__global__ __launch_bounds__(256 * HALVES) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
     const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ merged_list,
     const uint32_t* __restrict__ merged_map, const uint4* __restrict__ tex,
@@ -489,7 +493,8 @@ __global__ __launch_bounds__(256) void k_project(
     Rec* __restrict__ recs, float* __restrict__ depths, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
     Varyings* __restrict__ dbg, float4* __restrict__ col_f, uint32_t* __restrict__ block_emit)
 {
-    __shared__ uint32_t s_wsum[4], s_wvis[4], s_wemit[4];
+    static_assert(HALVES == 1 || !DEBUG, "the debug-varyings build visits the static chunk table one entry per workgroup");
+    __shared__ uint32_t s_wsum[4 * HALVES], s_wvis[4 * HALVES], s_wemit[4 * HALVES];
     // chunk_tab is in LAUNCH order, which is not slot order: workgroup b runs on XCD b % 8, and the table is laid out so
     // that all chunks of a draw land on one XCD (draw % 8) -- a draw's gathers stay inside one tile type's 313 KB of the
     // record table, so an XCD's 4 MB L2 then holds the few tile types it is working on instead of all 48 (6.6 MB).
@@ -497,6 +502,8 @@ __global__ __launch_bounds__(256) void k_project(
     // live count exit after one cached scalar load); the debug-varyings build visits every chunk through the static table.
     uint2 ct;
     uint32_t list_top = 0, list_cnt = 0;      // non-DEBUG: list index of this chunk's lane 0, list length | merged << 31 (from k_cull)
+    const uint32_t half = HALVES == 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0u;
+    bool active = true;                        // HALVES == 2: the upper half of the last workgroup of an odd list has no entry
 #ifdef GSWT_TRACE
     const bool tr_on = threadIdx.x == 0 && blockIdx.x < 49152u;
     const uint32_t tr_item = 8192u + blockIdx.x;
@@ -506,8 +513,11 @@ __global__ __launch_bounds__(256) void k_project(
         ct = chunk_tab[blockIdx.x];
         if (ct.y == 0xFFFFFFFFu) return;    // padding of a short per-XCD list
     } else {
-        if ((blockIdx.x >> 3) >= live_cnt[blockIdx.x & 7u]) return;
-        const uint4 lt = live_tab[blockIdx.x];
+        const uint32_t x = blockIdx.x & 7u, k0 = (blockIdx.x >> 3) * (uint32_t)HALVES;
+        const uint32_t n_live = live_cnt[x];
+        if (k0 >= n_live) return;
+        active = k0 + half < n_live;
+        const uint4 lt = live_tab[(size_t)min(k0 + half, n_live - 1u) * 8u + x];
         ct = make_uint2(lt.x, lt.y);
         list_top = lt.z; list_cnt = lt.w;
         if (GSWT_ABL(f, 256)) return;      // ablation: nothing behind the launch-table entry
@@ -517,13 +527,13 @@ __global__ __launch_bounds__(256) void k_project(
 #endif
     }
     const DrawDev& d = draws[ct.x];
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = HALVES == 2 ? (threadIdx.x & 255u) : threadIdx.x;
     const uint32_t cid = (d.slot_base + ct.y) >> 8;      // chunk id in slot space
     const bool s_culled = DEBUG ? draw_culled[ct.x] != 0u : false;
 
     const uint32_t r = ct.y + tid;
     const uint32_t slot = d.slot_base + r;
-    const bool in_list = DEBUG ? r < d.count : r < (list_cnt & 0x7FFFFFFFu);
+    const bool in_list = DEBUG ? r < d.count : (active && r < (list_cnt & 0x7FFFFFFFu));
     uint32_t count = 0;
     bool visible = false;
     uint2 my_rect = make_uint2(1u, 0u);     // empty: tx0 = 1 > tx1 = 0
@@ -919,12 +929,14 @@ __global__ __launch_bounds__(256) void k_project(
         wsum += __shfl_down(wsum, off, 64);
         wvis += __shfl_down(wvis, off, 64);
     }
-    if ((tid & 63u) == 0) { s_wsum[tid >> 6] = wsum; s_wvis[tid >> 6] = wvis; }
+    const uint32_t w0 = 4u * half;             // first wave of this half in the workgroup's tables
+    if ((tid & 63u) == 0) { s_wsum[w0 + (tid >> 6)] = wsum; s_wvis[w0 + (tid >> 6)] = wvis; }
     // GSWT_ORDER_DEPTH: slots of this chunk that emit pairs = what the global depth sort has to order (one ballot per wave; null otherwise)
-    if (block_emit) { const uint32_t we = (uint32_t)__popcll(__ballot(count != 0u)); if ((tid & 63u) == 0) s_wemit[tid >> 6] = we; }
+    if (block_emit) { const uint32_t we = (uint32_t)__popcll(__ballot(count != 0u)); if ((tid & 63u) == 0) s_wemit[w0 + (tid >> 6)] = we; }
     __syncthreads();
     GSWT_TR(5, GSWT_NOW())
-    const uint32_t bsum = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    if (!active) return;
+    const uint32_t bsum = s_wsum[w0] + s_wsum[w0 + 1u] + s_wsum[w0 + 2u] + s_wsum[w0 + 3u];
 #ifdef GSWT_TRACE
     { unsigned hwid, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       GSWT_TR(7, (unsigned long long)hwid | ((unsigned long long)(xcc & 0xFFu) << 32) | ((unsigned long long)(bsum ? 1u : 0u) << 63)) }
@@ -936,10 +948,10 @@ __global__ __launch_bounds__(256) void k_project(
         // two-level sums, spread over n_chunks / 256 addresses (a single hot counter serialises the whole grid);
         // k_totals folds them into counters[0] (visible splats) and counters[1] (pairs)
         if (bsum) atomicAdd(&super_sums[cid >> 8], bsum);
-        uint32_t v = s_wvis[0] + s_wvis[1] + s_wvis[2] + s_wvis[3];
+        uint32_t v = s_wvis[w0] + s_wvis[w0 + 1u] + s_wvis[w0 + 2u] + s_wvis[w0 + 3u];
         if (v) atomicAdd(&super_sums[n_super + (cid >> 8)], v);
         if (block_emit) {
-            const uint32_t e = s_wemit[0] + s_wemit[1] + s_wemit[2] + s_wemit[3];
+            const uint32_t e = s_wemit[w0] + s_wemit[w0 + 1u] + s_wemit[w0 + 2u] + s_wemit[w0 + 3u];
             block_emit[cid] = e;
             if (e) atomicAdd(&super_sums[3u * n_super + (cid >> 8)], e);       // [pairs][visible][pair prefix][emitting slots][their prefix]
         }
@@ -2653,8 +2665,12 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     // rows: [emitting slots][their exclusive prefix]
     const uint32_t n_super = n_chunks / 256u + 1u;
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
+    // non-debug frames: 512-thread workgroups, two launch-list entries each (GSWT_PROJECT_HALVES=1: the 256-thread build, tuning only)
+    static const bool wide = [] { const char* e = getenv("GSWT_PROJECT_HALVES"); return !(e && atoi(e) == 1); }();
 #define GSWT_LAUNCH_PROJECT_S(D, F, S)                                                                                         \
-    GSWT_LAUNCH((k_project<D, F, S>), dim3(n_launch), dim3(256), s, f, draws, chunk_tab, static_list, merged_list,        \
+    if (!D && wide) GSWT_LAUNCH((k_project<false, F, S, 2>), dim3(((n_launch / 8u + 1u) / 2u) * 8u), dim3(512), s, f, draws, chunk_tab, static_list, merged_list, \
+                       merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f, block_emit); \
+    else GSWT_LAUNCH((k_project<D, F, S>), dim3(n_launch), dim3(256), s, f, draws, chunk_tab, static_list, merged_list,        \
                        merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f, block_emit)
 #define GSWT_LAUNCH_PROJECT(D, F) do { if (strict) GSWT_LAUNCH_PROJECT_S(D, F, true); else GSWT_LAUNCH_PROJECT_S(D, F, false); } while (0)
     if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
