@@ -199,6 +199,7 @@ SYMBOLS = {
     "gswt_last_timings": (C.c_int, [_P, _P]),
     "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gswt_debug_read_ranges": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "gswt_debug_frame_times": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "gswt_debug_merge_stats": (C.c_int, [_P, _P]),
     "gswt_debug_merge_stats_deep": (C.c_int, [_P, _P]),
     "gswt_debug_totals": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),

@@ -220,6 +220,8 @@ struct FrameSlot {
     hipStream_t stream = nullptr;
     hipEvent_t ev[10] = {};
     hipEvent_t ev_in = nullptr;            // recorded on the ctx stream at enqueue: the frame starts after it
+    hipEvent_t ev_gather = nullptr;        // recorded on the ctx stream behind the frame's gather + re-assembly (gswt_render_gather / gswt_group_render_gather)
+    bool gather_recorded = false;
     unsigned long long seq = 0;            // submission order of the frame in this slot
     unsigned long long* hc = nullptr;      // pinned host: [0] visible [1] pairs [2] scratch [3] overflow ... [7] staging
     unsigned long long* hc_dev = nullptr;  // the same words as the device sees them (k_combine writes [0..3] at the end of a frame)
@@ -558,6 +560,7 @@ try {
     if (!c->set_stream && hipStreamCreateWithFlags(&c->set_stream, hipStreamNonBlocking) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
     for (auto& sl : c->slots) {
         if (hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
+        if (hipEventCreate(&sl.ev_gather) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         for (auto& e : sl.ev)
             if (hipEventCreate(&e) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
         if (hipHostMalloc(reinterpret_cast<void**>(&sl.hc), 8 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) { delete c; return GSWT_ERR_HIP; }
@@ -588,6 +591,7 @@ void gswt_destroy(gswt_ctx* c)
         sl.release_buffers();
         for (auto& e : sl.ev) if (e) hipEventDestroy(e);
         if (sl.ev_in) hipEventDestroy(sl.ev_in);
+        if (sl.ev_gather) hipEventDestroy(sl.ev_gather);
         if (sl.hc) hipHostFree(sl.hc);
         if (sl.stream) hipStreamDestroy(sl.stream);
     }
@@ -1617,6 +1621,7 @@ try {
     activate_pending(c, false);
     sl.set = c->cur_set;
     sl.strict_vs = c->opt_strict_vs != 0;
+    sl.gather_recorded = false;
     fill_args(sl.args, cam, su, cfg, width, height, reinterpret_cast<const float4*>(bg_rgba_dev), bg_depth_dev,
               reinterpret_cast<float4*>(out_rgba_dev));
     rc = enqueue_frame(c, sl);
@@ -1856,6 +1861,8 @@ try {
     launch_unshard(c->stream, c->gather_buf.p, reinterpret_cast<float4*>(frame_out_dev), sl.args.width, sl.args.height, g.world,
                    gswt_shard_rows_padded(sl.args.height, g.world), g.mode == GSWT_SHARD_COLUMNS ? g.out_w : 0);
     HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(sl.ev_gather, c->stream));
+    sl.gather_recorded = true;
     return GSWT_OK;
 } GSWT_CATCH("gswt_render_gather")
 
@@ -1906,6 +1913,9 @@ try {
         }
         HIP_TRY(c, hipEventRecord(c->ev_unshard, c->stream));
         c->unshard_pending = true;
+        FrameSlot& slw = c->slots[tickets[p]];
+        HIP_TRY(c, hipEventRecord(slw.ev_gather, c->stream));
+        slw.gather_recorded = true;
     }
     return GSWT_OK;
 } catch (...) { return GSWT_ERR_HIP; }
@@ -1989,6 +1999,24 @@ int gswt_debug_merge_stats_deep(const gswt_ctx* c, unsigned long long* out)
     *out = c->stat_groups_reused_deep;
     return GSWT_OK;
 }
+
+// Device timeline of frame slots (tests of the overlap claims): out_ms[0] = start of slot `ticket`'s frame kernels, [1] = their end,
+// [2] = end of its gather + re-assembly on the ctx stream (NaN when the frame was not gathered), all in milliseconds after the START of
+// slot `ticket_ref`'s frame.  Both frames must have been submitted with GSWT_OPT_TIMING >= 1 and have completed.
+int gswt_debug_frame_times(gswt_ctx* c, int ticket_ref, int ticket, float out_ms[3])
+try {
+    if (!c || !out_ms || ticket_ref < 0 || ticket_ref >= kFrameSlots || ticket < 0 || ticket >= kFrameSlots) return GSWT_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    HIP_TRY(c, sync_all(c));
+    FrameSlot& a = c->slots[ticket_ref];
+    FrameSlot& b = c->slots[ticket];
+    if (a.timing_level < 1 || b.timing_level < 1) return fail(c, GSWT_ERR_STATE, "gswt_debug_frame_times: frames without timing events");
+    HIP_TRY(c, hipEventElapsedTime(&out_ms[0], a.ev[0], b.ev[0]));
+    HIP_TRY(c, hipEventElapsedTime(&out_ms[1], a.ev[0], b.ev[6]));
+    out_ms[2] = __builtin_nanf("");
+    if (b.gather_recorded) HIP_TRY(c, hipEventElapsedTime(&out_ms[2], a.ev[0], b.ev_gather));
+    return GSWT_OK;
+} GSWT_CATCH("gswt_debug_frame_times")
 
 int gswt_debug_read_ranges(gswt_ctx* c, uint32_t* out, size_t capacity_tiles, size_t* n_tiles)
 try {

@@ -479,10 +479,11 @@ __device__ unsigned long long g_trace[kTraceItems * 8];
 // the same operations, in the same order, as the CPU checker's strict mode, per splat bit for bit.  The default (sequence v2, DESIGN.md
 // section 4) evaluates the same expressions with fma chains and one reciprocal per quotient -- also legal WGSL, ~25 % fewer instructions,
 // and up to 5e-4 away from this one on thin ellipses (lambda2 = mid - radius cancels).
-// HALVES = 2 (round 4): a 512-thread workgroup takes TWO consecutive entries of its XCD's launch list, one per half (waves 0-3 / 4-7), side by
-// side: the same body at the same 64 VGPRs, half the workgroups for the dispatcher to hand out (k_project is dispatch-bound: 13.7 k
-// workgroups of ~5 us started at ~260 per us keep ~1 300 of the chip's 2 048 workgroup slots filled; chunks IN SEQUENCE in one workgroup
-// were slower: more registers, longer lifetime).  The halves meet only at the barrier in front of the per-chunk sums.
+// HALVES = 2 (round 4, measured and NOT the default: see launch_project): a 512-thread workgroup takes TWO consecutive entries of its XCD's
+// launch list, one per half (waves 0-3 / 4-7), side by side: the same body at the same 64 VGPRs, half the workgroups for the dispatcher
+// to hand out (the trace reads as dispatch-bound: 13.7 k workgroups of ~5 us started at ~260 per us keep ~1 300 of the chip's 2 048
+// workgroup slots filled; chunks IN SEQUENCE in one workgroup were slower: more registers, longer lifetime).  The halves meet only at
+// the barrier in front of the per-chunk sums.
 template <bool DEBUG, bool FULL, bool STRICT, int HALVES = 1>
 __global__ __launch_bounds__(256 * HALVES) void k_project(
     const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab,
@@ -1216,9 +1217,16 @@ __device__ __forceinline__ uint32_t sort_passes_needed(const uint32_t* __restric
 }
 
 // Lanes of the wave that hold the same digit as this one (match-any on `nbits` bits), restricted to valid lanes.
-__device__ __forceinline__ unsigned long long match_digit(uint32_t dgt, bool valid, uint32_t nbits)
+// `runs`: the caller expects whole rounds of one digit (every pass after the first: the passes before ordered the input by the lower
+// digits, stably, and the pairs of one screen tile are neighbours from then on): one broadcast + one ballot settle such a round instead
+// of nbits ballots; a mixed round pays the two on top.
+__device__ __forceinline__ unsigned long long match_digit(uint32_t dgt, bool valid, uint32_t nbits, bool runs = false)
 {
     unsigned long long peers = __ballot(valid);
+    if (runs && peers != 0ull) {                        // (wave-uniform)
+        const uint32_t d0 = (uint32_t)__shfl((int)dgt, (int)__ffsll((long long)peers) - 1, 64);
+        if (__ballot(valid && dgt != d0) == 0ull) return peers;
+    }
     for (uint32_t b = 0; b < nbits; b++) {
         const bool bit = (dgt >> b) & 1u;
         const unsigned long long m = __ballot(valid && bit);
@@ -1406,7 +1414,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     for (int k = 0; k < kSortItems; k++) {
         const bool valid = base + (uint32_t)k * 64u + lane < n;
         const uint32_t dgt = ((key[k] - kmin) >> shift) & mask;
-        const unsigned long long peers = match_digit(dgt, valid, nbits);
+        const unsigned long long peers = match_digit(dgt, valid, nbits, shift != 0u && ranges != nullptr);
         if (kCachePeers) pm[k] = peers;
         if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
     }
@@ -1451,7 +1459,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         uint32_t i = base + k * 64 + lane;
         bool valid = i < n;
         uint32_t dgt = valid ? (((key[k] - kmin) >> shift) & mask) : 0u;
-        const unsigned long long peers = kCachePeers ? pm[kCachePeers ? k : 0] : match_digit(dgt, valid, nbits);
+        const unsigned long long peers = kCachePeers ? pm[kCachePeers ? k : 0] : match_digit(dgt, valid, nbits, shift != 0u && ranges != nullptr);
         const uint32_t rank = __popcll(peers & lt);
         uint32_t pos = 0;
         if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
@@ -2382,6 +2390,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
 // LDS 18.4 KB (k_composite: 17.9 KB): 8 workgroups per CU.
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return *reinterpret_cast<const volatile uint32_t*>(p); }
+#ifndef GSWT_DW_SLEEP
+#define GSWT_DW_SLEEP 1        // s_sleep units (64 clocks) between two polls of a counter
+#endif
 
 template <bool EARLY, bool DEPTH, bool COLF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COLF ? 6 : DEPTH ? 7 : 8, 8))) void k_composite_dw(const Frame f,
@@ -2471,7 +2482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COLF ? 6 : 
                 if (ks > k) break;                      // not needed yet: try again after the next walk
                 while (lds_peek(&s_done[sb]) < need) {
                     if (EARLY && lds_peek(&s_dead) == 4u) { all_dead = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(GSWT_DW_SLEEP);
                 }
                 if (all_dead) break;
             }
@@ -2511,7 +2522,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COLF ? 6 : 
             const uint32_t target = 2u * (ku + 1u);
             while (lds_peek(&s_staged[kb]) < target) {
                 if (EARLY && lds_peek(&s_dead) == 4u) { all_dead = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(GSWT_DW_SLEEP);
             }
             if (all_dead) break;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2665,8 +2676,11 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     // rows: [emitting slots][their exclusive prefix]
     const uint32_t n_super = n_chunks / 256u + 1u;
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
-    // non-debug frames: 512-thread workgroups, two launch-list entries each (GSWT_PROJECT_HALVES=1: the 256-thread build, tuning only)
-    static const bool wide = [] { const char* e = getenv("GSWT_PROJECT_HALVES"); return !(e && atoi(e) == 1); }();
+    // GSWT_PROJECT_HALVES=2 (measurement only): 512-thread workgroups, two launch-list entries each.  Built in round 4 against the
+    // "dispatch-bound" reading of the kernel's trace and LOST at every size, same bits: c3 83.4 us against 76.2, c3h 101.5 / 97.2,
+    // c5 530 / 464 (profiles/r04_project_halves.txt) -- a workgroup now lives as long as the slower of its two chunks and holds 8 wave
+    // slots until then; halving what the dispatcher hands out does not pay for that.
+    static const bool wide = [] { const char* e = getenv("GSWT_PROJECT_HALVES"); return e && atoi(e) == 2; }();
 #define GSWT_LAUNCH_PROJECT_S(D, F, S)                                                                                         \
     if (!D && wide) GSWT_LAUNCH((k_project<false, F, S, 2>), dim3(((n_launch / 8u + 1u) / 2u) * 8u), dim3(512), s, f, draws, chunk_tab, static_list, merged_list, \
                        merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f, block_emit); \

@@ -312,6 +312,12 @@ class GSWTRenderer:
         self._check(self._lib.gswt_debug_read_projected(self._h, _ptr(out), out.shape[0], C.byref(n)))
         return out[:n.value]
 
+    def frame_times(self, ticket_ref: int, ticket: int):
+        """(start, end, gather end) of slot `ticket`'s frame in ms after the start of slot `ticket_ref`'s frame (device timeline)."""
+        out = (C.c_float * 3)()
+        self._check(self._lib.gswt_debug_frame_times(self._h, ticket_ref, ticket, out))
+        return float(out[0]), float(out[1]), float(out[2])
+
     def read_ranges(self) -> np.ndarray:
         """[n_tiles, 2] (start, end) of each screen tile's slice of the sorted pair list."""
         n = C.c_size_t(0)

@@ -507,6 +507,10 @@ GSWT_API int gswt_debug_merge_stats_deep(const gswt_ctx *ctx, unsigned long long
 /* Test / profiling hook: [start, end) of every screen tile in the sorted pair list of the last
  * gswt_render (2 u32 per tile, shard-local tile order). Host pointer. */
 GSWT_API int gswt_debug_read_ranges(gswt_ctx *ctx, uint32_t *out, size_t capacity_tiles, size_t *n_tiles);
+/* Device timeline of two frame slots (tests of the frame / gather overlap): out_ms[0] = start of slot `ticket`'s frame kernels, [1] = their
+ * end, [2] = end of its gather + re-assembly (NaN if it was not gathered), in ms after the START of slot `ticket_ref`'s frame.  Both frames
+ * submitted with GSWT_OPT_TIMING >= 1 and complete (the call synchronises). */
+GSWT_API int gswt_debug_frame_times(gswt_ctx *ctx, int ticket_ref, int ticket, float out_ms[3]);
 
 #ifdef __cplusplus
 }

@@ -125,3 +125,64 @@ def test_back_to_back_group_gathers_without_a_sync():
         for r in rs:
             r.comm_destroy()
             r.close()
+
+
+def test_frames_overlap_the_previous_frames_gather():
+    """frame i + 1 is submitted before frame i is gathered, so its kernels run while frame i's fence, peer copies and
+    re-assembly are in flight.  Three ranks (contexts) on one device, c3-sized column bands, three frames in flight per rank, event
+    timestamps from the device (gswt_debug_frame_times): on every rank frame i + 1 STARTS before gather i has finished, for every i,
+    and the gathered frames are the unsharded renders bit for bit."""
+    import torch
+    import bench
+    from gswt_renderer_amd import host, workloads
+    w, wang, cu0, vp0, sort = bench.build_workload("c3")
+    W, Hh = w["width"], w["height"]
+    su = wang.scene_uniforms()
+    cam = workloads.camera_for("c3")
+    n, n_frames = 3, 6
+    cams = [host.camera_uniforms((cam["pos"][0] + 0.2 * k, cam["pos"][1] + 0.3 * k, cam["pos"][2]),
+                                 (cam["target"][0] + 0.2 * k, cam["target"][1] + 0.3 * k, cam["target"][2]), cam["up"], cam["fovy"], cam["near"], cam["far"], W, Hh)[0]
+            for k in range(n_frames)]
+    rs = [GSWTRenderer(0) for _ in range(n)]
+    try:
+        for r in rs:
+            wang.upload_to(r)
+            r.configure(None)
+            r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
+            r.set_option(L.GSWT_OPT_TIMING, 1)
+        wants = [rs[0].render(c, su, W, Hh, transmittance_eps=1e-5) for c in cams]
+        GSWTRenderer.group_init(rs)
+        bw = rs[0].shard_cols_padded(W, n)
+        outs = [[torch.zeros((Hh, bw, 4), dtype=torch.float32, device="cuda") for _ in range(n)] for _ in cams]
+        frames = [[torch.zeros((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in range(n)] for _ in cams]
+        torch.cuda.synchronize()
+        depth = 3                                                    # frames in flight per rank
+        tickets = {}
+
+        def submit(i):
+            tickets[i] = [r.render_async(cams[i], su, W, Hh, o.data_ptr(), shard=(k, n, "cols"), transmittance_eps=1e-5) for k, (r, o) in enumerate(zip(rs, outs[i]))]
+
+        for i in range(depth):
+            submit(i)
+        times = {}
+        for i in range(n_frames):
+            GSWTRenderer.group_render_gather(rs, tickets[i], [f.data_ptr() for f in frames[i]])
+            if i + 1 < n_frames:
+                # device timeline of rank 0: frame i + 1 (already submitted) against the gather of frame i (just issued); both complete at the sync
+                times[i] = rs[0].frame_times(tickets[i][0], tickets[i + 1][0]), rs[0].frame_times(tickets[i][0], tickets[i][0])
+            for r, t in zip(rs, tickets[i]):
+                r.render_wait(t)
+            if i + depth < n_frames:
+                submit(i + depth)
+        for r in rs:
+            r.synchronize()
+        for i in range(n_frames):
+            for f in frames[i]:
+                assert np.array_equal(f.cpu().numpy(), wants[i]), i
+        for i, ((s_next, e_next, _), (_, e_this, g_this)) in times.items():
+            print(f"frame {i}: kernels end {e_this * 1e3:7.1f} us, gather done {g_this * 1e3:7.1f} us; frame {i + 1}: kernels {s_next * 1e3:7.1f} .. {e_next * 1e3:7.1f} us")
+            assert g_this == g_this and s_next < g_this, (i, s_next, g_this)           # frame i + 1 was running before gather i finished
+    finally:
+        for r in rs:
+            r.comm_destroy()
+            r.close()
