@@ -1217,16 +1217,12 @@ __device__ __forceinline__ uint32_t sort_passes_needed(const uint32_t* __restric
 }
 
 // Lanes of the wave that hold the same digit as this one (match-any on `nbits` bits), restricted to valid lanes.
-// `runs`: the caller expects whole rounds of one digit (every pass after the first: the passes before ordered the input by the lower
-// digits, stably, and the pairs of one screen tile are neighbours from then on): one broadcast + one ballot settle such a round instead
-// of nbits ballots; a mixed round pays the two on top.
-__device__ __forceinline__ unsigned long long match_digit(uint32_t dgt, bool valid, uint32_t nbits, bool runs = false)
+// (Round 4, measured and dropped: a fast path for rounds whose 64 items share one digit -- one broadcast + one ballot instead of nbits
+// ballots, taken in the passes after the first, where the pairs of one screen tile are neighbours: the last pass of the c3 pair sort went
+// from 18.5 to 21.8 us.  Too few rounds are uniform, and the mixed ones pay the two extra wave-wide operations.)
+__device__ __forceinline__ unsigned long long match_digit(uint32_t dgt, bool valid, uint32_t nbits)
 {
     unsigned long long peers = __ballot(valid);
-    if (runs && peers != 0ull) {                        // (wave-uniform)
-        const uint32_t d0 = (uint32_t)__shfl((int)dgt, (int)__ffsll((long long)peers) - 1, 64);
-        if (__ballot(valid && dgt != d0) == 0ull) return peers;
-    }
     for (uint32_t b = 0; b < nbits; b++) {
         const bool bit = (dgt >> b) & 1u;
         const unsigned long long m = __ballot(valid && bit);
@@ -1414,7 +1410,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     for (int k = 0; k < kSortItems; k++) {
         const bool valid = base + (uint32_t)k * 64u + lane < n;
         const uint32_t dgt = ((key[k] - kmin) >> shift) & mask;
-        const unsigned long long peers = match_digit(dgt, valid, nbits, shift != 0u && ranges != nullptr);
+        const unsigned long long peers = match_digit(dgt, valid, nbits);
         if (kCachePeers) pm[k] = peers;
         if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
     }
@@ -1459,7 +1455,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         uint32_t i = base + k * 64 + lane;
         bool valid = i < n;
         uint32_t dgt = valid ? (((key[k] - kmin) >> shift) & mask) : 0u;
-        const unsigned long long peers = kCachePeers ? pm[kCachePeers ? k : 0] : match_digit(dgt, valid, nbits, shift != 0u && ranges != nullptr);
+        const unsigned long long peers = kCachePeers ? pm[kCachePeers ? k : 0] : match_digit(dgt, valid, nbits);
         const uint32_t rank = __popcll(peers & lt);
         uint32_t pos = 0;
         if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
