@@ -32,7 +32,6 @@ GSWT_OPT_NO_MERGE_REUSE = 7
 GSWT_OPT_DEFER_SWAP = 8
 GSWT_OPT_GRAPH = 9
 GSWT_OPT_STRICT_VS = 10
-GSWT_OPT_EMIT_CAP = 11
 GSWT_OPT_DEPTH_PASSES = 12
 GSWT_OPT_COMPOSITE = 13
 GSWT_SHARD_ROWS = 0

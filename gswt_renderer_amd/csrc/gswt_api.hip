@@ -34,21 +34,18 @@ void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, co
 void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
 size_t radix_ws_zero_words(uint32_t, int);
-void launch_emit_depth(hipStream_t, const Frame&, uint32_t, uint32_t, const uint2*, const float*, const uint32_t*, const uint32_t*, const uint32_t*,
-                       uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint2*, uint2*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t,
-                       unsigned long long*, uint32_t*, uint32_t*);
 void launch_merge_build(hipStream_t, const MergeSeg*, uint32_t, const uint2*, uint32_t, MergeGroup*, uint32_t, const int32_t*, uint32_t, const unsigned long long*,
                         uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, uint32_t*);
 void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2*, uint32_t, uint32_t, const uint32_t*, const uint32_t*,
                     const uint32_t*, const uint4*, const float*, const uint32_t*, const uint32_t*, uint32_t*, const uint4*, uint2*, Rec*, float*, uint32_t*, uint32_t*,
-                    unsigned long long*, Varyings*, float4*, uint32_t, uint32_t*, uint32_t, bool);
+                    unsigned long long*, Varyings*, float4*, uint32_t, bool);
 void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
-                 uint32_t*, uint32_t*);
+                 uint32_t*, uint32_t*, const float*, uint32_t*, uint32_t*);
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr,
-                const uint32_t* = nullptr, uint2* = nullptr, uint2* = nullptr);
+                const uint32_t* = nullptr, uint32_t* = nullptr, uint32_t* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, const unsigned long long*, unsigned long long*, int);
+                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
 void launch_proxy(hipStream_t, const ProxyArgs&, const float*, const float4*, float4*, float*);
@@ -244,8 +241,7 @@ struct FrameSlot {
     DevBuf<uint2> ranges;
     DevBuf<uint32_t> item_base;
     DevBuf<uint4> item_tab;
-    DevBuf<uint32_t> depth_ws;             // GSWT_ORDER_DEPTH: 4 x emit_cap key / slot ping-pong + per-block pair counts + per-chunk emitting-slot counts
-    uint32_t emit_cap = 0;                 // ... and the capacity (emitting slots) that frame was launched for
+    DevBuf<uint32_t> aux_a, aux_b;         // GSWT_ORDER_DEPTH: the pairs' tile ids, carried through the depth passes as the sort's payload
     bool strict_vs = false;                // GSWT_OPT_STRICT_VS as it stood when the frame was submitted (a re-run keeps it)
     uint32_t depth_passes = 0;             // GSWT_ORDER_DEPTH: radix passes this frame's depth sort was launched with
     DevBuf<float4> partials;
@@ -268,7 +264,7 @@ struct FrameSlot {
     {
         rects.release(); recs.release(); cell_culled.release(); live_tab.release(); live_cnt.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
         keys_b.release(); vals_a.release(); vals_b.release(); ghist.release(); ranges.release(); item_base.release();
-        depth_ws.release(); partials.release(); item_tab.release(); col_f.release(); depths.release();
+        aux_a.release(); aux_b.release(); partials.release(); item_tab.release(); col_f.release(); depths.release();
     }
 };
 
@@ -326,8 +322,7 @@ struct gswt_ctx {
     bool draws_ready = false;
     // frame (the per-frame buffers live in the slots)
     uint32_t pair_cap = 0;                 // capacity the pair buffers / grids are sized for (grows on overflow)
-    uint32_t emit_cap = 0;                 // GSWT_ORDER_DEPTH: capacity of the depth sort in emitting slots (<= visible splats; grows like pair_cap)
-    // ... and its number of 8-bit passes: as many as the key ranges of the recent frames needed (the depths of one c3 frame span ~2^21
+    // GSWT_ORDER_DEPTH: the number of 8-bit passes of the depth sort: as many as the key ranges of the recent frames needed (the depths of one c3 frame span ~2^21
     // ulps: three).  A frame that needs more is flagged on the device and re-run; 32 frames in a row that need fewer give one back.
     uint32_t depth_passes = 3;
     uint32_t depth_passes_low_run = 0, depth_passes_low_max = 0;
@@ -632,10 +627,6 @@ try {
     case GSWT_OPT_DEFER_SWAP: c->opt_defer_swap = value; return GSWT_OK;
     case GSWT_OPT_GRAPH: c->opt_graph = value; return GSWT_OK;
     case GSWT_OPT_STRICT_VS: c->opt_strict_vs = value != 0; return GSWT_OK;
-    case GSWT_OPT_EMIT_CAP:
-        if (value < 0) return fail(c, GSWT_ERR_BAD_ARG, "depth-sort capacity must be >= 0");
-        c->emit_cap = (uint32_t)value;              // 0: sized from the next draw list
-        return GSWT_OK;
     case GSWT_OPT_COMPOSITE:
         if (value != 0 && value != 1) return fail(c, GSWT_ERR_BAD_ARG, "unknown compositor variant %d", value);
         c->opt_composite = value; return GSWT_OK;
@@ -1275,9 +1266,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         const size_t n_slots_all = (size_t)D.n_chunks * kChunk;
         HIP_TRY(c, sl.rects.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
-        // (GSWT_ORDER_DEPTH: the per-chunk counts of emitting slots lie right behind the per-chunk pair counts, so that k_cull clears both
-        // with one range -- chunks of culled draws never run and must read as zero)
-        HIP_TRY(c, sl.block_sums.ensure_roomy(((size_t)D.n_chunks + 1) * (cfg->order_mode == GSWT_ORDER_DEPTH ? 2 : 1)));
+        HIP_TRY(c, sl.block_sums.ensure_roomy((size_t)D.n_chunks + 1));
         HIP_TRY(c, sl.live_tab.ensure_roomy((size_t)D.n_launch + 8));
         // (cleared ON THE SLOT'S STREAM: the slot streams are non-blocking, so a null-stream hipMemset -- asynchronous to the host for
         // device memory -- could land after this frame's k_cull had filled the counts: the slot's FIRST frame then projected nothing
@@ -1387,29 +1376,23 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     HIP_TRY(c, sl.vals_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure_roomy((size_t)cap + 1));
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
     const size_t n_super = (size_t)D.n_chunks / 256 + 1;
-    // pair sums, visible sums, exclusive pair prefix (k_totals); depth order: + emitting-slot sums and their exclusive prefix
-    const size_t n_super2 = (depth_order ? 5 : 3) * n_super;
-    const uint32_t n_slots = D.n_chunks * (uint32_t)kChunk;
-    // GSWT_ORDER_DEPTH sorts the slots that emit pairs (<= the visible splats), for a capacity that follows the running count like
-    // the pair capacity does; a frame that outgrows it is flagged by k_totals and re-run by finish_frame
-    if (depth_order && c->emit_cap == 0) c->emit_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(D.n_entries / 4, 1u << 18), n_slots);
-    const uint32_t ecap = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->emit_cap, 256u), std::max<uint32_t>(n_slots, 256u)) : 0u;
-    sl.emit_cap = ecap;
-    const size_t n_psuper = 0;
+    const size_t n_super2 = 3 * n_super;                            // pair sums, visible sums, exclusive pair prefix (k_totals)
+    // GSWT_ORDER_DEPTH: the pair list is sorted on the depth bits first, with as many 8-bit passes as the key ranges of the recent frames
+    // needed (k_items flags a frame that needs more: finish_frame re-runs it); the tile ids travel as the payload of those passes
     sl.depth_passes = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->depth_passes, 1u), 4u) : 0u;
-    // radix workspaces: the zeroed parts of BOTH sorts first (group rows, digit totals), the per-workgroup rows (written in full) behind
-    const size_t rz_pair = radix_ws_zero_words(cap, key_bits), rz_depth = depth_order ? radix_ws_zero_words(ecap, 32) : 0;
-    const size_t rw_pair = radix_ws_words(cap, key_bits), rw_depth = depth_order ? radix_ws_words(ecap, 32) : 0;
-    // depth sort: tile-rect payload ping-pong (2 x 2 x ecap words, 8-byte aligned at the front), key / slot ping-pong (4 x ecap), block counts
-    if (depth_order) HIP_TRY(c, sl.depth_ws.ensure_roomy(8 * (size_t)ecap + ((size_t)ecap / 256 + 2) + 64));
-    // one contiguous u32 region whose head k_cull clears: [counters: 16][super_sums: n_super2][psuper][pair sort: zeroed part .. rows][depth sort likewise]
-    HIP_TRY(c, sl.ghist.ensure_roomy(16 + n_super2 + n_psuper + rw_pair + rw_depth + 16));
+    const int depth_bits = 8 * (int)sl.depth_passes;
+    if (depth_order) { HIP_TRY(c, sl.aux_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.aux_b.ensure_roomy((size_t)cap + 1)); }
+    // radix workspaces: per sort the zeroed part (group rows, digit totals) in front of its per-workgroup rows (written in full)
+    const size_t rz_pair = radix_ws_zero_words(cap, key_bits), rz_depth = depth_order ? radix_ws_zero_words(cap, depth_bits) : 0;
+    const size_t rw_pair = radix_ws_words(cap, key_bits), rw_depth = depth_order ? radix_ws_words(cap, depth_bits) : 0;
+    // one contiguous u32 region whose head k_cull clears: [counters: 16][super_sums: n_super2][pair sort: zeroed part .. rows][depth sort likewise]
+    HIP_TRY(c, sl.ghist.ensure_roomy(16 + n_super2 + rw_pair + rw_depth + 16));
     uint32_t* const zero_a = sl.ghist.p;
     unsigned long long* const d_counters = reinterpret_cast<unsigned long long*>(zero_a);
     uint32_t* const d_super = zero_a + 16;
-    uint32_t* const d_psuper = d_super + n_super2;
-    uint32_t* const d_radix = d_psuper + n_psuper;
+    uint32_t* const d_radix = d_super + n_super2;
     uint32_t* const d_radix_depth = d_radix + rw_pair;
+    uint32_t* const d_krange = reinterpret_cast<uint32_t*>(d_counters + 5);     // counters[5]: (~smallest, largest) depth key of the frame (k_emit<DEPTH>)
     const uint32_t seg = (uint32_t)c->opt_segment;
     HIP_TRY(c, sl.item_base.ensure_roomy((size_t)n_tiles + 2));
     HIP_TRY(c, sl.partials.ensure_roomy(((size_t)n_tiles + cap / seg + 1) * 256));
@@ -1443,42 +1426,42 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     HIP_TRY(c, sl.cell_culled.ensure((size_t)n_cells + 1));
     // cleared per frame: counters, super-group sums and the atomically accumulated part of the sort's tables.  The pair sort's zeroed
     // part is contiguous with the head; the depth sort's (behind the pair sort's rows) is the kernel's second clear range.
-    const size_t n_zero_a = 16 + n_super2 + n_psuper + rz_pair;
-    uint32_t* const d_crect = sl.depth_ws.p;
-    uint32_t* const dw = depth_order ? d_crect + 4 * (size_t)ecap : nullptr;
-    uint32_t* const d_block_cnt = depth_order ? dw + 4 * (size_t)ecap : nullptr;
-    uint32_t* const d_block_emit = depth_order ? sl.block_sums.p + D.n_chunks : nullptr;
+    const size_t n_zero_a = 16 + n_super2 + rz_pair;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
-                reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks * (depth_order ? 2u : 1u), sl.live_cnt.p, sl.live_tab.p,
+                reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
                 d_radix_depth, (uint32_t)rz_depth);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
-                   d_counters, c->dbg.p, sl.col_f.p, cap, d_block_emit, ecap, sl.strict_vs);
+                   d_counters, c->dbg.p, sl.col_f.p, cap, sl.strict_vs);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
-    // ---- emit
+    // ---- emit + sort
+    // reference order: pairs in composite (slot) order, stably sorted on the tile bits.  Depth order: the same pairs with their depth bits,
+    // stably sorted on the depth bits in use first (payload: the tile id), then on the tile bits: inside a tile true depth order, equal
+    // depths in composite order.  The last tile pass also leaves every screen tile's [start, end) of the sorted list in sl.ranges (zeroed by k_cull).
+    const uint32_t* vals_sorted = nullptr;
     if (!depth_order) {
-        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, nullptr, nullptr, nullptr);
+        if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
+        const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p);
+        vals_sorted = where ? sl.vals_b.p : sl.vals_a.p;
     } else {
-        // counters[4] = emitting slots (k_totals; the depth sort reads its item count there, counters[6] = its overflow word stays 0),
-        // counters[5] = the key range (two u32 words, k_depth_keys)
-        launch_emit_depth(s, f, D.n_chunks, ecap, sl.rects.p, sl.depths.p, sl.block_sums.p, d_block_emit, d_super + 4 * n_super,
-                          dw, dw + ecap, dw + 2 * (size_t)ecap, dw + 3 * (size_t)ecap, reinterpret_cast<uint2*>(d_crect),
-                          reinterpret_cast<uint2*>(d_crect) + ecap, d_radix_depth,
-                          reinterpret_cast<uint32_t*>(d_counters + 5),
-                          d_block_cnt, sl.depth_passes, cap, d_counters, sl.keys_a.p, sl.vals_a.p);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.aux_a.p, sl.vals_a.p, sl.depths.p, sl.keys_a.p, d_krange);
+        if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
+        const int wd = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, depth_bits, d_radix_depth, nullptr, d_krange, sl.aux_a.p, sl.aux_b.p);
+        // (the depth keys are dead now: keys_a serves as the other half of the tile-key ping-pong)
+        uint32_t* const tiles_in = wd ? sl.aux_b.p : sl.aux_a.p;
+        uint32_t* const vals_in = wd ? sl.vals_b.p : sl.vals_a.p;
+        uint32_t* const vals_other = wd ? sl.vals_a.p : sl.vals_b.p;
+        const int where = launch_sort(s, tiles_in, vals_in, sl.keys_a.p, vals_other, cap, d_P, key_bits, d_radix, sl.ranges.p);
+        vals_sorted = where ? vals_other : vals_in;
     }
-    if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
-    // ---- stable sort on the tile bits
-    // (the last pass also leaves every screen tile's [start, end) of the sorted pair list in sl.ranges, zeroed by k_cull)
-    int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p);
-    const uint32_t* vals_sorted = where ? sl.vals_b.p : sl.vals_a.p;
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[4], s));
     // ---- ranges
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[5], s));
     // ---- composite
     launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.depths.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
                      sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr,
-                     d_counters, sl.hc_dev, c->opt_composite);
+                     d_counters, sl.hc_dev, c->opt_composite, depth_order ? d_krange : nullptr, sl.depth_passes);
     c->last_n_tiles = (uint32_t)n_tiles;
     c->last_slot = (int)(&sl - c->slots);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));
@@ -1507,10 +1490,8 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
         if (attempt >= 2) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");
         if (P64 > sl.cap || sl.args.cfg.order_mode != GSWT_ORDER_DEPTH)
             c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 2 + 4096, 0xFFFFFF00ull));
-        // depth order: the emitting slots are at most the visible splats, which the frame counted whatever overflowed
-        if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH) {
-            c->emit_cap = std::max<uint32_t>(c->emit_cap, (uint32_t)std::min<uint64_t>(sl.hc[0] + sl.hc[0] / 2 + 4096, 0xFFFFFF00ull));
-            if (sl.hc[2] > sl.depth_passes) { c->depth_passes = (uint32_t)std::min<unsigned long long>(sl.hc[2], 4ull); c->depth_passes_low_run = 0; }
+        if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH && sl.hc[2] > sl.depth_passes) {
+            c->depth_passes = (uint32_t)std::min<unsigned long long>(sl.hc[2], 4ull); c->depth_passes_low_run = 0;
         }
         int rc = enqueue_frame(c, sl);
         if (rc != GSWT_OK) return rc;
@@ -1519,7 +1500,6 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
     // keep 25-50 % headroom over the running pair count without shrinking on every small dip
     if (!c->opt_fixed_pair_cap && (uint64_t)P + P / 4 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 2 + 4096, 0xFFFFFF00ull);
     if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH) {
-        if (sl.hc[0] + sl.hc[0] / 4 > c->emit_cap) c->emit_cap = (uint32_t)std::min<uint64_t>(sl.hc[0] + sl.hc[0] / 2 + 4096, 0xFFFFFF00ull);
         const uint32_t need = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(sl.hc[2], 1ull), 4ull);
         if (need < c->depth_passes && sl.depth_passes == c->depth_passes) {
             c->depth_passes_low_max = c->depth_passes_low_run ? std::max(c->depth_passes_low_max, need) : need;

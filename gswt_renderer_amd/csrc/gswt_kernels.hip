@@ -492,10 +492,10 @@ __global__ __launch_bounds__(256 * HALVES) void k_project(
     const float* __restrict__ hmap, const uint32_t* __restrict__ draw_culled, const uint32_t* __restrict__ cell_culled,
     const uint32_t* __restrict__ live_cnt, const uint4* __restrict__ live_tab, uint2* __restrict__ rects,
     Rec* __restrict__ recs, float* __restrict__ depths, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ super_sums, uint32_t n_super,
-    Varyings* __restrict__ dbg, float4* __restrict__ col_f, uint32_t* __restrict__ block_emit)
+    Varyings* __restrict__ dbg, float4* __restrict__ col_f)
 {
     static_assert(HALVES == 1 || !DEBUG, "the debug-varyings build visits the static chunk table one entry per workgroup");
-    __shared__ uint32_t s_wsum[4 * HALVES], s_wvis[4 * HALVES], s_wemit[4 * HALVES];
+    __shared__ uint32_t s_wsum[4 * HALVES], s_wvis[4 * HALVES];
     // chunk_tab is in LAUNCH order, which is not slot order: workgroup b runs on XCD b % 8, and the table is laid out so
     // that all chunks of a draw land on one XCD (draw % 8) -- a draw's gathers stay inside one tile type's 313 KB of the
     // record table, so an XCD's 4 MB L2 then holds the few tile types it is working on instead of all 48 (6.6 MB).
@@ -932,8 +932,6 @@ __global__ __launch_bounds__(256 * HALVES) void k_project(
     }
     const uint32_t w0 = 4u * half;             // first wave of this half in the workgroup's tables
     if ((tid & 63u) == 0) { s_wsum[w0 + (tid >> 6)] = wsum; s_wvis[w0 + (tid >> 6)] = wvis; }
-    // GSWT_ORDER_DEPTH: slots of this chunk that emit pairs = what the global depth sort has to order (one ballot per wave; null otherwise)
-    if (block_emit) { const uint32_t we = (uint32_t)__popcll(__ballot(count != 0u)); if ((tid & 63u) == 0) s_wemit[w0 + (tid >> 6)] = we; }
     __syncthreads();
     GSWT_TR(5, GSWT_NOW())
     if (!active) return;
@@ -951,11 +949,6 @@ __global__ __launch_bounds__(256 * HALVES) void k_project(
         if (bsum) atomicAdd(&super_sums[cid >> 8], bsum);
         uint32_t v = s_wvis[w0] + s_wvis[w0 + 1u] + s_wvis[w0 + 2u] + s_wvis[w0 + 3u];
         if (v) atomicAdd(&super_sums[n_super + (cid >> 8)], v);
-        if (block_emit) {
-            const uint32_t e = s_wemit[w0] + s_wemit[w0 + 1u] + s_wemit[w0 + 2u] + s_wemit[w0 + 3u];
-            block_emit[cid] = e;
-            if (e) atomicAdd(&super_sums[3u * n_super + (cid >> 8)], e);       // [pairs][visible][pair prefix][emitting slots][their prefix]
-        }
     }
     GSWT_TR(6, GSWT_NOW())
 }
@@ -966,13 +959,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 // scan of the pair half of super_sums), so that k_emit reads one word instead of summing up to n_chunks / 256 of them
 // (c5: 1 430 per workgroup).  Single workgroup.  (Folding it into k_emit -- every workgroup sums the super-group counts
 // in front of it, workgroup 0 leaves the totals -- was measured: k_emit +6 us for the 4.6 us saved, 4015 -> 3881 frames/s.)
-// GSWT_ORDER_DEPTH (emit_sums != nullptr): the same for the per-super-group counts of EMITTING slots -- their exclusive prefix goes to
-// emit_excl, their total to counters[4] (the item count of the depth sort, read on the device; counters[6], its overflow word, stays 0)
-// and a total beyond the depth sort's capacity flags the frame like a pair overflow (the host grows the capacity and re-runs it).
 __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ super_sums, uint32_t n_super,
                                                 unsigned long long* __restrict__ counters, uint32_t* __restrict__ super_excl, uint32_t pair_cap,
-                                                uint32_t* __restrict__ live_cnt, const uint32_t* __restrict__ emit_sums,
-                                                uint32_t* __restrict__ emit_excl, uint32_t emit_cap)
+                                                uint32_t* __restrict__ live_cnt)
 {
     // k_project is done with this frame's live-chunk counts: cleared here for the slot's next frame (k_cull both clears
     // buffers and adds to these counters, so it cannot clear them itself)
@@ -1015,24 +1004,6 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ sup
     if (threadIdx.x == 0) {
         counters[1] = carry; counters[0] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
         if (carry > (unsigned long long)pair_cap) counters[3] = 1ull;       // pair buffers too small: the host re-runs the frame
-    }
-    if (emit_sums) {                                                        // uniform
-        uint32_t ecarry = 0;                                                // (slots: < 2^32 in total)
-        for (uint32_t base = 0; base < n_super; base += 1024u) {
-            const uint32_t i = base + threadIdx.x * 4u;
-            uint32_t p[4], sum = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const uint32_t pv = emit_sums[min(i + (uint32_t)k, n_super - 1u)]; p[k] = i + k < n_super ? pv : 0u; sum += p[k]; }
-            uint32_t tot32;
-            uint32_t ex = block_excl_scan(sum, s_w, &tot32) + ecarry;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { if (i + k < n_super) emit_excl[i + k] = ex; ex += p[k]; }
-            ecarry += tot32;
-        }
-        if (threadIdx.x == 0) {
-            counters[4] = ecarry;
-            if (ecarry > emit_cap) counters[3] = 1ull;
-        }
     }
 }
 
@@ -1096,14 +1067,25 @@ __device__ __forceinline__ uint32_t block_scan_and_sum(uint32_t v, uint32_t r, u
     return base + inc - v;
 }
 
+// DEPTH (GSWT_ORDER_DEPTH, north_star's "global radix depth sort"): every pair also gets its splat's depth bits as a second key (dkeys), and
+// the smallest / largest depth key of the frame is left in krange.  The pair list is then sorted stably on the depth bits in use (the tile id
+// travels as the sort's payload) and after that on the tile bits as always: inside a screen tile the pairs end up in true depth order, equal
+// depths in composite order.  Round 4's first version sorted the emitting SPLATS by depth and emitted the pairs in that order (compaction,
+// three passes with the tile rect as payload, per-group pair counts, a scan, the emission: five more kernels and 111 us per c3 frame);
+// keying the PAIRS costs one more 4-byte word per pair in k_emit and in the depth passes and needs none of that.
+template <bool DEPTH>
 __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __restrict__ rects,
                                               const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ super_excl,
                                               uint32_t n_chunks, uint32_t pair_cap, unsigned long long* __restrict__ counters,
-                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                              const float* __restrict__ depths, uint32_t* __restrict__ dkeys, uint32_t* __restrict__ krange)
 {
     __shared__ uint32_t s_w[8];
+    __shared__ uint32_t s_mn[DEPTH ? 4 : 1], s_mx[DEPTH ? 4 : 1];
     uint32_t cid[kEmitGroup], sums[kEmitGroup], bs[kEmitGroup], sbase[kEmitGroup];
     uint2 rcs[kEmitGroup];
+    float dep[kEmitGroup];
+    uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
     const uint32_t c0 = blockIdx.x * kEmitGroup;
     const uint32_t n_mine = min(kEmitGroup, n_chunks - c0);
 #pragma unroll
@@ -1117,6 +1099,7 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
         bs[k] = block_sums[min((cid[k] & ~255u) + threadIdx.x, cid[k])];
         sbase[k] = super_excl[cid[k] >> 8];                          // pairs of all chunks before the chunk's super-group (k_totals)
         rcs[k] = rects[(size_t)cid[k] * 256u + threadIdx.x];         // only meaningful when sums[k] != 0 (k_project wrote it then)
+        dep[k] = DEPTH ? depths[(size_t)cid[k] * 256u + threadIdx.x] : 0.0f;      // likewise (k_project stores a slot's depth beside its record)
     }
     uint32_t any = 0;
 #pragma unroll
@@ -1142,12 +1125,15 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
             return;
         }
         if (count == 0) continue;
+        const uint32_t dkey = __float_as_uint(dep[k]);               // depth in [0, 1]: bit order = value order
+        if (DEPTH) { kmn = min(kmn, dkey); kmx = max(kmx, dkey); }
         if (sc > 1) {                                                // row shards: this rank's rows of the rect, numbered locally
             for (int ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc; ty <= ty1; ty += sc) {
                 const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
                 for (int tx = tx0; tx <= tx1; tx++) {
                     keys[off] = row + (uint32_t)(tx - f.col0);
                     vals[off] = slot;
+                    if (DEPTH) dkeys[off] = dkey;
                     off++;
                 }
             }
@@ -1159,8 +1145,25 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
                 for (int tx = tx0; tx <= tx1; tx++) {
                     keys[off] = row + (uint32_t)(tx - f.col0);
                     vals[off] = slot;
+                    if (DEPTH) dkeys[off] = dkey;
                     off++;
                 }
+            }
+        }
+    }
+    if (DEPTH) {
+        // key range of the frame: one guarded atomic pair per workgroup.  (One pair per WAVE on the two words is tens of thousands of
+        // atomics on two addresses, which the memory side serialises at ~8 ns each.)  The words only grow ([0] holds ~min), so a stale read
+        // can only cause a redundant atomic, never a missed one.
+        for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, (uint32_t)__shfl_down((int)kmn, o, 64)); kmx = max(kmx, (uint32_t)__shfl_down((int)kmx, o, 64)); }
+        if ((threadIdx.x & 63u) == 0u) { s_mn[DEPTH ? threadIdx.x >> 6 : 0u] = kmn; s_mx[DEPTH ? threadIdx.x >> 6 : 0u] = kmx; }
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            kmn = min(min(s_mn[0], s_mn[DEPTH ? 1 : 0]), min(s_mn[DEPTH ? 2 : 0], s_mn[DEPTH ? 3 : 0]));
+            kmx = max(max(s_mx[0], s_mx[DEPTH ? 1 : 0]), max(s_mx[DEPTH ? 2 : 0], s_mx[DEPTH ? 3 : 0]));
+            if (kmn <= kmx) {
+                if (~kmn > __builtin_nontemporal_load(&krange[0])) atomicMax(&krange[0], ~kmn);                     // (load_krange)
+                if (kmx > __builtin_nontemporal_load(&krange[1])) atomicMax(&krange[1], kmx);
             }
         }
     }
@@ -1205,7 +1208,8 @@ __device__ __forceinline__ void load_krange(const uint32_t* __restrict__ krange,
 }
 // Number of radix passes the keys in [kmin, kmax] need (see k_radix_hist): pass p covers bits 8p .. 8p+7 of key - kmin.  The host
 // launches as many passes as the previous frames needed (three at c3: visible depths of one frame span ~2^21 ulps); a frame that needs
-// more is flagged by k_perm_scan and re-run, like a capacity overflow.  Passes run = min(needed, launched).
+// more is flagged by k_items and re-run, like a capacity overflow; one that needs fewer is sorted all the same (the extra passes see one
+// digit and move nothing) and the host gives the pass back after a while.
 __device__ __forceinline__ uint32_t sort_passes_needed(const uint32_t* __restrict__ krange)
 {
     uint32_t kmin, kmax;
@@ -1238,11 +1242,11 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
                                                     uint32_t nsup, const uint32_t* __restrict__ krange)
 {
     constexpr int kSortItems = kSortBlock / kSortThreads;
-    // krange (the depth sort only): [0] = smallest key, [1] = largest.  Digits are taken from key - smallest, and a pass whose shift is
-    // beyond the bits of (largest - smallest) would move nothing: its two kernels leave at once and the consumer of the sorted list picks
-    // the buffer by the same rule (sort_passes_run).  Visible depths of one frame span ~2^21 ulps at c3: three passes, not four.
+    // krange (the depth passes only): the frame's smallest / largest depth key.  Digits are taken from key - smallest, so the passes the host
+    // launches cover the bits of (largest - smallest): visible depths of one c3 frame span ~2^21 ulps -- three 8-bit passes, not four
+    // (sort_passes_needed; a frame that needs more than were launched is flagged by k_items and re-run).
     uint32_t kmin = 0;
-    if (krange) { uint32_t kmax; load_krange(krange, kmin, kmax); if (shift != 0u && ((kmax - kmin) >> shift) == 0u) return; }
+    if (krange) { uint32_t kmax; load_krange(krange, kmin, kmax); }
     const uint32_t n = clamped_count(n_ptr, n_cap);
     __shared__ uint32_t s_h[256];
     if (threadIdx.x < 256u) s_h[threadIdx.x] = 0;
@@ -1317,11 +1321,10 @@ __global__ __launch_bounds__(256) void k_radix_supscan(uint32_t* __restrict__ gs
 // The block's 4096 items are first ranked INTO LDS (sorted by digit inside the block), then copied out: consecutive threads
 // write consecutive addresses of a digit's run instead of every lane storing two separate words to its own rank position
 // (a wave's store instruction used to touch as many regions as it held distinct digits).
-// AUX (the depth sort): an 8-byte payload per item travels with it.  It is NOT staged through LDS with the (key, value) pair (12 more bytes
-// per item would cost a workgroup per CU): the ranking leaves each sorted item's source position inside the block (u16), and the copy-out
-// fetches the payload from there -- a gather confined to the block's own 32 KB window of the input, every sector of which this workgroup
-// consumes -- and stores it at the item's global position beside the value.  What this replaces: gathering the payload AFTER the sort
-// through the sorted index (1.9 M random 8-byte reads at c3, 64-byte sectors: 60 us cold).
+// AUX (the depth passes of GSWT_ORDER_DEPTH): a second 4-byte payload per item -- the pair's tile id -- travels with it.  It is NOT staged
+// through LDS with the (key, value) pair: the ranking leaves each sorted item's source position inside the block (u16), and the copy-out
+// fetches the payload from there -- a gather confined to the block's own 16 KB window of the input, every sector of which this workgroup
+// consumes -- and stores it at the item's global position beside the value.
 template <int kSortThreads, bool AUX>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -1329,11 +1332,11 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
                                                        uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist,
                                                        const uint32_t* __restrict__ gsup, const uint32_t* __restrict__ gtot,
                                                        uint32_t nblk, uint32_t nsup, uint2* __restrict__ ranges, const uint32_t* __restrict__ krange,
-                                                       const uint2* __restrict__ aux_in, uint2* __restrict__ aux_out)
+                                                       const uint32_t* __restrict__ aux_in, uint32_t* __restrict__ aux_out)
 {
     constexpr int kSortItems = kSortBlock / kSortThreads, kSortWaves = kSortThreads / 64;
     uint32_t kmin = 0;                                  // (see k_radix_hist)
-    if (krange) { uint32_t kmax; load_krange(krange, kmin, kmax); if (shift != 0u && ((kmax - kmin) >> shift) == 0u) return; }
+    if (krange) { uint32_t kmax; load_krange(krange, kmin, kmax); }
     const uint32_t n = clamped_count(n_ptr, n_cap);
     if (blockIdx.x * kSortBlock >= n) return;
 #ifdef GSWT_TRACE
@@ -1494,209 +1497,6 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
 }
 
 // ------------------------------------------------------------------------------------
-// GSWT_ORDER_DEPTH: true global per-splat depth order (north_star's "global radix depth sort"; the reference itself orders tiles and
-// presorted lists, wangtile.rs:489-499 + scene.rs:685-695 -- that is GSWT_ORDER_REFERENCE).
-//   k_project       also leaves, per chunk, the number of slots that emit pairs (block_emit) and their per-super-group sums
-//   k_totals        scans those sums: exclusive prefix per super-group, total -> counters[4] = the depth sort's item count (on the device)
-//   k_depth_keys    compacts the emitting slots, in slot order, to (depth bits, slot) and leaves the smallest / largest key
-//   radix sort      stable LSD on the bits of (key - smallest) that are in use: equal depths keep composite order; only what can be
-//                   visible is sorted (round 3 sorted every slot of the frame: 10 M at c3 for 1.9 M that emit), and no host word enters
-//                   the chain, so the frame is one hipGraph like any other
-//   k_perm_counts   pairs of every 1024 positions of the sorted list (one plain store per workgroup)
-//   k_perm_scan     their exclusive prefix (one workgroup)
-//   k_emit_perm     emits the pairs in depth order: first pair of a workgroup = its prefix word, then a workgroup-wide scan
-// The tile-bit sort and the compositor are unchanged.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_depth_keys(const uint2* __restrict__ rects, const float* __restrict__ depths,
-                                                    const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ block_emit,
-                                                    const uint32_t* __restrict__ emit_excl, uint32_t n_chunks, uint32_t emit_cap,
-                                                    const unsigned long long* __restrict__ counters,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint2* __restrict__ crect,
-                                                    uint32_t* __restrict__ krange)
-{
-    __shared__ uint32_t s_w[8], s_mn[4], s_mx[4];
-    if (counters[4] > (unsigned long long)emit_cap) return;             // flagged by k_totals: the host re-runs the frame with more room
-    uint32_t cid[kEmitGroup], sums[kEmitGroup], be[kEmitGroup], sbase[kEmitGroup];
-    uint2 rcs[kEmitGroup];
-    float dep[kEmitGroup];
-    const uint32_t c0 = blockIdx.x * kEmitGroup;
-    const uint32_t n_mine = min(kEmitGroup, n_chunks - c0);
-#pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++) cid[k] = min(c0 + k, n_chunks - 1u);
-#pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++) {                       // (all loads up front, clamped: see k_emit)
-        sums[k] = block_sums[cid[k]];
-        be[k] = block_emit[min((cid[k] & ~255u) + threadIdx.x, cid[k])];
-        sbase[k] = emit_excl[cid[k] >> 8];
-    }
-    uint32_t any = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++) { if (k >= n_mine) sums[k] = 0u; any |= sums[k]; }
-    if (any == 0u) return;
-#pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++) {                       // rects / depths of a chunk exist only when it has pairs
-        const bool live = sums[k] != 0u;
-        rcs[k] = live ? rects[(size_t)cid[k] * 256u + threadIdx.x] : make_uint2(1u, 0u);
-        dep[k] = live ? depths[(size_t)cid[k] * 256u + threadIdx.x] : 0.0f;
-    }
-    uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++) {
-        if (sums[k] == 0u) continue;                                 // workgroup-uniform
-        const uint2 rc = rcs[k];
-        const bool emits = (rc.x >> 16) >= (rc.x & 0xFFFFu);          // k_project left an empty rect (1, 0) in slots without pairs
-        uint32_t tot, chunk_base;
-        uint32_t off = block_scan_and_sum(emits ? 1u : 0u, (cid[k] & ~255u) + threadIdx.x < cid[k] ? be[k] : 0u, s_w, &tot, &chunk_base);
-        off += chunk_base + sbase[k];
-        if (emits) {
-            const uint32_t key = __float_as_uint(dep[k]);             // depth in [0, 1]: bit order = value order
-            // the slot is the sort's value, the tile rect its 8-byte payload (k_radix_scatter<., AUX>): the depth-ordered emission then reads
-            // both in order -- gathering the rects through the sorted slots afterwards was 60 us of cold 8-byte reads at c3
-            keys[off] = key;
-            vals[off] = cid[k] * 256u + threadIdx.x;
-            crect[off] = rc;
-            kmn = min(kmn, key); kmx = max(kmx, key);
-        }
-    }
-    // key range: one guarded atomic pair per workgroup.  (One pair per WAVE on the two words was 70 k atomics on two addresses: the
-    // kernel took 189 us at c3.)  The words only grow, so a stale read can only cause a redundant atomic, never a missed one.
-    for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, (uint32_t)__shfl_down((int)kmn, o, 64)); kmx = max(kmx, (uint32_t)__shfl_down((int)kmx, o, 64)); }
-    if ((threadIdx.x & 63u) == 0u) { s_mn[threadIdx.x >> 6] = kmn; s_mx[threadIdx.x >> 6] = kmx; }
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        kmn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3])); kmx = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
-        if (kmn <= kmx) {
-            if (~kmn > __builtin_nontemporal_load(&krange[0])) atomicMax(&krange[0], ~kmn);                         // (load_krange)
-            if (kmx > __builtin_nontemporal_load(&krange[1])) atomicMax(&krange[1], kmx);
-        }
-    }
-}
-
-// 1024-thread workgroup: exclusive scan of one value per thread, *total = workgroup sum
-__device__ __forceinline__ uint32_t block1024_excl_scan(uint32_t v, uint32_t* s_w /*[16]*/, uint32_t* total)
-{
-    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const uint32_t inc = wave_incl_scan(v, lane);
-    if (lane == 63u) s_w[w] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < 16u; i++) { const uint32_t t = s_w[i]; if (i < w) base += t; tot += t; }
-    *total = tot;
-    __syncthreads();
-    return base + inc - v;
-}
-
-__device__ __forceinline__ uint32_t rect_pairs(const Frame& f, uint2 rc)
-{
-    const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
-    return (uint32_t)((tx1 - tx0 + 1) * owned_rows(ty0, ty1, f.shard_index, f.shard_count));
-}
-
-// Pairs of every 1024 positions of the depth-ordered list (the rects arrive in that order: the sort carried them).  Plain stores, one per
-// workgroup; k_perm_scan turns them into exclusive prefixes.  (Round-4 first version: 256-position blocks adding their counts to per-65 536
-// sums with atomics -- neighbouring workgroups then hit the same word at the same time: 58 us for 7.4 k atomics at c3.)
-__global__ __launch_bounds__(1024) void k_perm_counts(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
-                                                      const uint32_t* __restrict__ krange, uint32_t n_launched,
-                                                      const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
-                                                      uint32_t* __restrict__ group_cnt)
-{
-    __shared__ uint32_t s_w[16];
-    const uint32_t n = clamped_count(n_ptr, emit_cap);
-    if (blockIdx.x * 1024u >= n) return;
-    const uint2* rect = (min(sort_passes_needed(krange), n_launched) & 1u) ? rect_b : rect_a;
-    const uint32_t pos = blockIdx.x * 1024u + threadIdx.x;
-    const uint2 rc = rect[min(pos, n - 1u)];
-    uint32_t count = pos < n ? rect_pairs(f, rc) : 0u;
-    for (int o = 32; o > 0; o >>= 1) count += (uint32_t)__shfl_down((int)count, o, 64);
-    if ((threadIdx.x & 63u) == 0u) s_w[threadIdx.x >> 6] = count;
-    __syncthreads();
-    if (threadIdx.x == 0u) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) t += s_w[i];
-        group_cnt[blockIdx.x] = t;
-    }
-}
-
-// single workgroup: group_cnt[0 .. ceil(n / 1024)) -> exclusive prefix, in place
-// Also the depth sort's pass check: counters[2] = passes this frame's key range needs; more than were launched = the sorted list is not
-// sorted: the frame is flagged (counters[3]) and the host re-runs it with more passes.
-__global__ __launch_bounds__(1024) void k_perm_scan(uint32_t* __restrict__ group_cnt, const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
-                                                    const uint32_t* __restrict__ krange, uint32_t n_launched, unsigned long long* __restrict__ counters)
-{
-    __shared__ uint32_t s_w[16];
-    const uint32_t n = clamped_count(n_ptr, emit_cap);
-    if (threadIdx.x == 0u) {
-        const uint32_t need = sort_passes_needed(krange);
-        counters[2] = need;
-        if (need > n_launched) counters[3] = 1ull;
-    }
-    const uint32_t G = (n + 1023u) >> 10;
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < G; base += 4096u) {
-        const uint32_t i = base + threadIdx.x * 4u;
-        uint32_t p[4], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { const uint32_t v = group_cnt[min(i + (uint32_t)k, G - 1u)]; p[k] = i + k < G ? v : 0u; sum += p[k]; }
-        uint32_t tot;
-        uint32_t ex = block1024_excl_scan(sum, s_w, &tot) + carry;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { if (i + k < G) group_cnt[i + k] = ex; ex += p[k]; }
-        carry += tot;
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_emit_perm(const Frame f, const uint2* __restrict__ rect_a, const uint2* __restrict__ rect_b,
-                                                    const uint32_t* __restrict__ perm_a,
-                                                    const uint32_t* __restrict__ perm_b, const uint32_t* __restrict__ krange, uint32_t n_launched,
-                                                    const unsigned long long* __restrict__ n_ptr, uint32_t emit_cap,
-                                                    const uint32_t* __restrict__ group_excl, uint32_t pair_cap,
-                                                    unsigned long long* __restrict__ counters, uint32_t* __restrict__ keys,
-                                                    uint32_t* __restrict__ vals)
-{
-    __shared__ uint32_t s_w[16];
-    const uint32_t n = clamped_count(n_ptr, emit_cap);
-    if (blockIdx.x * 1024u >= n) return;
-    const bool in_b = (min(sort_passes_needed(krange), n_launched) & 1u) != 0u;
-    const uint32_t* perm = in_b ? perm_b : perm_a;
-    const uint2* rect = in_b ? rect_b : rect_a;
-    const uint32_t pos = blockIdx.x * 1024u + threadIdx.x;
-    const uint32_t chunk_base = group_excl[blockIdx.x];
-    const uint32_t slot = perm[min(pos, n - 1u)];
-    const uint2 rc = rect[min(pos, n - 1u)];
-    const int tx0 = rc.x & 0xFFFFu, tx1 = rc.x >> 16, ty0 = rc.y & 0xFFFFu, ty1 = rc.y >> 16;
-    const uint32_t count = pos < n ? rect_pairs(f, rc) : 0u;
-    uint32_t tot;
-    uint32_t off = chunk_base + block1024_excl_scan(count, s_w, &tot);
-    if ((unsigned long long)chunk_base + tot > (unsigned long long)pair_cap) {
-        if (threadIdx.x == 0 && tot) atomicOr(&counters[3], 1ull);
-        return;
-    }
-    if (count == 0) return;
-    const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
-    if (sc > 1) {
-        for (int ty = ty0 + ((f.shard_index - ty0 % sc) + sc) % sc; ty <= ty1; ty += sc) {
-            const uint32_t row = (uint32_t)(ty / sc) * (uint32_t)f.tiles_x;
-            for (int tx = tx0; tx <= tx1; tx++) {
-                keys[off] = row + (uint32_t)(tx - f.col0);
-                vals[off] = slot;
-                off++;
-            }
-        }
-    } else {
-        for (int ty = ty0; ty <= ty1; ty++) {                        // (see k_emit: no division by the shard count in the usual frame)
-            const uint32_t row = (uint32_t)ty * (uint32_t)f.tiles_x;
-            for (int tx = tx0; tx <= tx1; tx++) {
-                keys[off] = row + (uint32_t)(tx - f.col0);
-                vals[off] = slot;
-                off++;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // Merged-group lists on the device (Scene::sort_raw_depth_vec for every MergedFrom group of a sort event,
 // wangtile.rs:595-670 + scene.rs:655-698, in one segmented sort).
 //   segment  = one member's raw-depth array (plus the other LOD's when the member is Changing)
@@ -1831,9 +1631,17 @@ __global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ j
 // item_base[t] = exclusive scan of seg_count, item_base[n_tiles] = number of items; item_tab[item] =
 // (tile, segment << 1 | tile has several segments, first pair, end pair): everything k_composite needs in one load.  Single workgroup (n_tiles is a few thousand to a few
 // tens of thousands): one launch instead of count + 3 scan launches.
+// GSWT_ORDER_DEPTH (krange != nullptr): also the depth sort's pass check -- counters[2] = 8-bit passes this frame's depth range needs; more
+// than were launched = the pair list is not in depth order: the frame is flagged (counters[3]) and the host re-runs it with more passes.
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
-                                                uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items)
+                                                uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items,
+                                                const uint32_t* __restrict__ krange, uint32_t n_launched, unsigned long long* __restrict__ counters)
 {
+    if (krange && blockIdx.x == 0u && threadIdx.x == 0u) {
+        const uint32_t need = sort_passes_needed(krange);
+        counters[2] = need;
+        if (need > n_launched) counters[3] = 1ull;
+    }
     // One workgroup per 8192 tiles (c3: one workgroup, c5: four).  Thread t owns tiles base + j * 1024 + t, j = 0..7: every
     // load and store of a wave is contiguous (eight tiles per thread SIDE BY SIDE made each of them 64 separate 8-byte
     // requests: ~8 k requests through one CU's address path, the larger part of the old kernel's 14 us).  The eight block
@@ -2664,13 +2472,10 @@ void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
                     const uint32_t* static_list, const uint32_t* merged_list, const uint32_t* merged_map, const uint4* tex,
                     const float* hmap, const uint32_t* draw_culled, const uint32_t* cell_culled, uint32_t* live_cnt, const uint4* live_tab, uint2* rects, Rec* recs, float* depths, uint32_t* block_sums,
-                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap,
-                    uint32_t* block_emit, uint32_t emit_cap, bool strict)
+                    uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap, bool strict)
 {
     if (n_chunks == 0) return;
-    // super_sums = [pairs][visible][exclusive pair prefix] x n_super, zeroed by the caller; with block_emit (GSWT_ORDER_DEPTH) two more
-    // rows: [emitting slots][their exclusive prefix]
-    const uint32_t n_super = n_chunks / 256u + 1u;
+    const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs][visible][exclusive pair prefix] x n_super, zeroed by the caller
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
     // GSWT_PROJECT_HALVES=2 (measurement only): 512-thread workgroups, two launch-list entries each.  Built in round 4 against the
     // "dispatch-bound" reading of the kernel's trace and LOST at every size, same bits: c3 83.4 us against 76.2, c3h 101.5 / 97.2,
@@ -2679,9 +2484,9 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     static const bool wide = [] { const char* e = getenv("GSWT_PROJECT_HALVES"); return e && atoi(e) == 2; }();
 #define GSWT_LAUNCH_PROJECT_S(D, F, S)                                                                                         \
     if (!D && wide) GSWT_LAUNCH((k_project<false, F, S, 2>), dim3(((n_launch / 8u + 1u) / 2u) * 8u), dim3(512), s, f, draws, chunk_tab, static_list, merged_list, \
-                       merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f, block_emit); \
+                       merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f); \
     else GSWT_LAUNCH((k_project<D, F, S>), dim3(n_launch), dim3(256), s, f, draws, chunk_tab, static_list, merged_list,        \
-                       merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f, block_emit)
+                       merged_map, tex, hmap, draw_culled, cell_culled, live_cnt, live_tab, rects, recs, depths, block_sums, super_sums, n_super, dbg, col_f)
 #define GSWT_LAUNCH_PROJECT(D, F) do { if (strict) GSWT_LAUNCH_PROJECT_S(D, F, true); else GSWT_LAUNCH_PROJECT_S(D, F, false); } while (0)
     if (debug && full) { GSWT_LAUNCH_PROJECT(true, true); }
     else if (debug) { GSWT_LAUNCH_PROJECT(true, false); }
@@ -2689,17 +2494,20 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     else { GSWT_LAUNCH_PROJECT(false, false); }
 #undef GSWT_LAUNCH_PROJECT
 #undef GSWT_LAUNCH_PROJECT_S
-    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, live_cnt,
-                block_emit ? super_sums + 3u * n_super : (const uint32_t*)nullptr, super_sums + 4u * n_super, emit_cap);
+    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, live_cnt);
 }
 
+// keys: tile ids, vals: slots.  GSWT_ORDER_DEPTH (dkeys != nullptr): also each pair's depth bits -> dkeys and the frame's key range -> krange.
 void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* rects, const uint32_t* block_sums,
-                 const uint32_t* super_sums, uint32_t pair_cap, unsigned long long* counters, uint32_t* keys, uint32_t* vals)
+                 const uint32_t* super_sums, uint32_t pair_cap, unsigned long long* counters, uint32_t* keys, uint32_t* vals,
+                 const float* depths, uint32_t* dkeys, uint32_t* krange)
 {
     if (n_chunks == 0) return;
     const uint32_t n_super = n_chunks / 256u + 1u;      // [pairs x n_super][visible x n_super][exclusive pair prefix x n_super]
-    GSWT_LAUNCH(k_emit, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), s, f, rects, block_sums, super_sums + 2u * n_super,
-                       n_chunks, pair_cap, counters, keys, vals);
+    const dim3 grid((n_chunks + kEmitGroup - 1u) / kEmitGroup);
+    if (dkeys) GSWT_LAUNCH(k_emit<true>, grid, dim3(256), s, f, rects, block_sums, super_sums + 2u * n_super, n_chunks, pair_cap, counters, keys, vals, depths, dkeys, krange);
+    else GSWT_LAUNCH(k_emit<false>, grid, dim3(256), s, f, rects, block_sums, super_sums + 2u * n_super, n_chunks, pair_cap, counters, keys, vals,
+                     (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 
 // Sorts (keys, vals) by key bits [0, key_bits); the pair count is read on the device (*n_ptr), grids are
@@ -2725,7 +2533,7 @@ size_t radix_ws_zero_words(uint32_t n_cap, int key_bits)
 
 int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n_cap,
                 const unsigned long long* n_ptr, int key_bits, uint32_t* ws, uint2* ranges = nullptr, const uint32_t* krange = nullptr,
-                uint2* aux_a = nullptr, uint2* aux_b = nullptr)
+                uint32_t* aux_a = nullptr, uint32_t* aux_b = nullptr)
 {
     if (n_cap == 0) return 0;
     const uint32_t nblk = (n_cap + kSortBlock - 1) / kSortBlock, nsup = (nblk >> kSupShift) + 1;
@@ -2744,7 +2552,7 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         hist_rows += (size_t)256 * nblk;
         uint32_t* ki = cur ? keys_b : keys_a; uint32_t* vi = cur ? vals_b : vals_a;
         uint32_t* ko = cur ? keys_a : keys_b; uint32_t* vo = cur ? vals_a : vals_b;
-        const uint2* xi = cur ? aux_b : aux_a; uint2* xo = cur ? aux_a : aux_b;
+        const uint32_t* xi = cur ? aux_b : aux_a; uint32_t* xo = cur ? aux_a : aux_b;
 #define GSWT_SORT_PASS(T)                                                                                                        \
         GSWT_LAUNCH(k_radix_hist<T>, dim3(nblk), dim3(T), s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup, krange); \
         if (nsup > kSupDirect) GSWT_LAUNCH(k_radix_supscan, dim3(64), dim3(256), s, gsup, gtot, nsup);                          \
@@ -2758,28 +2566,6 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
         cur ^= 1;
     }
     return cur;
-}
-
-// GSWT_ORDER_DEPTH front end (after k_project / k_totals): compaction of the emitting slots -> radix sort on the depth bits in use ->
-// per-block pair counts -> emission in depth order.  dk_a/dv_a/dk_b/dv_b: emit_cap u32 each; rect_a / rect_b: emit_cap uint2 each; radix_ws: radix_ws_words(emit_cap, 32)
-// words whose radix_ws_zero_words(emit_cap, 32) first are zero; krange zero on entry (k_cull's zero region); n_passes: radix passes to launch;
-// counters[4] = number of emitting slots (k_totals).  Every launch goes through GSWT_LAUNCH: the frame is graph-able.
-void launch_emit_depth(hipStream_t s, const Frame& f, uint32_t n_chunks, uint32_t emit_cap, const uint2* rects,
-                       const float* depths, const uint32_t* block_sums, const uint32_t* block_emit, const uint32_t* emit_excl,
-                       uint32_t* dk_a, uint32_t* dv_a, uint32_t* dk_b, uint32_t* dv_b, uint2* rect_a, uint2* rect_b,
-                       uint32_t* radix_ws, uint32_t* krange, uint32_t* block_cnt, uint32_t n_passes, uint32_t pair_cap,
-                       unsigned long long* counters, uint32_t* keys, uint32_t* vals)
-{
-    if (n_chunks == 0 || emit_cap == 0) return;
-    GSWT_LAUNCH(k_depth_keys, dim3((n_chunks + kEmitGroup - 1u) / kEmitGroup), dim3(256), s, rects, depths, block_sums, block_emit, emit_excl, n_chunks,
-                emit_cap, (const unsigned long long*)counters, dk_a, dv_a, rect_a, krange);
-    (void)launch_sort(s, dk_a, dv_a, dk_b, dv_b, emit_cap, counters + 4, 8 * (int)n_passes, radix_ws, nullptr, krange, rect_a, rect_b);
-    const uint32_t ng = (emit_cap + 1023u) / 1024u;
-    GSWT_LAUNCH(k_perm_counts, dim3(ng), dim3(1024), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)krange, n_passes,
-                (const unsigned long long*)(counters + 4), emit_cap, block_cnt);
-    GSWT_LAUNCH(k_perm_scan, dim3(1), dim3(1024), s, block_cnt, (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)krange, n_passes, counters);
-    GSWT_LAUNCH(k_emit_perm, dim3(ng), dim3(1024), s, f, (const uint2*)rect_a, (const uint2*)rect_b, (const uint32_t*)dv_a, (const uint32_t*)dv_b, (const uint32_t*)krange,
-                n_passes, (const unsigned long long*)(counters + 4), emit_cap, (const uint32_t*)block_cnt, pair_cap, counters, keys, vals);
 }
 
 // Builds every merged group's (gs_index | lod, map_id) list on the device.  keys/vals a,b: n_total u32 each;
@@ -2810,7 +2596,8 @@ void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs, const float* depths,
                       const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
-                      hipEvent_t ev_begin, hipEvent_t ev_end, const unsigned long long* counters, unsigned long long* host_counters, int variant)
+                      hipEvent_t ev_begin, hipEvent_t ev_end, unsigned long long* counters, unsigned long long* host_counters, int variant,
+                      const uint32_t* krange, uint32_t depth_passes)
 {
     if (n_tiles == 0) {                 // a shard without screen tiles (more ranks than tile columns): the events still exist
         if (ev_begin) hipEventRecord(ev_begin, s);
@@ -2818,7 +2605,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         return;
     }
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
-    GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items);
+    GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items, krange, depth_passes, counters);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
 #ifdef GSWT_EXPERIMENTS
@@ -2839,7 +2626,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 #undef GSWT_LAUNCH_COMPOSITE_P2N
 #undef GSWT_LAUNCH_COMPOSITE_P2
         if (ev_end) hipEventRecord(ev_end, s);
-        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, (const unsigned long long*)counters, host_counters);
         return;
     }
     if (f.dbg_flags & 0x4000) {          // experiment: independent strip waves (0x8000: two strips per wave, 0x10000: four; 0x2000: 128-pair batches)
@@ -2860,7 +2647,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 #undef GSWT_LAUNCH_COMPOSITE_SN
 #undef GSWT_LAUNCH_COMPOSITE_S
         if (ev_end) hipEventRecord(ev_end, s);
-        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, (const unsigned long long*)counters, host_counters);
         return;
     }
     if (f.dbg_flags & 0x1000) {          // experiment: the one-wave-per-item packed compositor (0x2000: 64-pair batches instead of 128)
@@ -2879,7 +2666,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 #undef GSWT_LAUNCH_COMPOSITE_PN
 #undef GSWT_LAUNCH_COMPOSITE_P
         if (ev_end) hipEventRecord(ev_end, s);
-        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, (const unsigned long long*)counters, host_counters);
         return;
     }
 #endif
@@ -2894,7 +2681,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         else GSWT_LAUNCH_COMPOSITE_DW(false, false, false);
 #undef GSWT_LAUNCH_COMPOSITE_DW
         if (ev_end) hipEventRecord(ev_end, s);
-        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+        GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, (const unsigned long long*)counters, host_counters);
         return;
     }
 #define GSWT_LAUNCH_COMPOSITE_K(E, D, C, PK, DW)                                                                               \
@@ -2917,14 +2704,13 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 #undef GSWT_LAUNCH_COMPOSITE
 #undef GSWT_LAUNCH_COMPOSITE_K
     if (ev_end) hipEventRecord(ev_end, s);
-    GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, counters, host_counters);
+    GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, (const unsigned long long*)counters, host_counters);
 }
 
 // k_totals alone on caller-provided sums (unit test of the 64-bit pair count)
 void launch_totals(hipStream_t s, uint32_t* super_sums, uint32_t n_super, unsigned long long* counters, uint32_t pair_cap)
 {
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, (uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, (uint32_t*)nullptr);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded, int band_px)

@@ -27,7 +27,7 @@
 
 namespace gswt {
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr, const uint32_t* = nullptr,
-                uint2* = nullptr, uint2* = nullptr);
+                uint32_t* = nullptr, uint32_t* = nullptr);
 size_t radix_ws_words(uint32_t, int);
 int ctx_device(const gswt_ctx*);
 }  // namespace gswt

@@ -193,10 +193,9 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                   splat bit-identical to the CPU checker's restatement of the shader text.  0: the rounding sequence "v2"
                                   (fma chains, one reciprocal per quotient: also legal WGSL, ~25 % fewer instructions, the default until
                                   round 3); the two differ by up to 5e-4 in the image on thin ellipses */,
-       GSWT_OPT_EMIT_CAP = 11 /* test hook: start the GSWT_ORDER_DEPTH sort capacity (splats that emit pairs) at `value`; a frame that
-                                 outgrows it is re-run with more room, like a pair overflow (0: sized from the next draw list) */,
-       GSWT_OPT_DEPTH_PASSES = 12 /* test hook: 8-bit radix passes the next GSWT_ORDER_DEPTH frame launches (1..4; default 3, then as many as
-                                     the key ranges of the recent frames needed); a frame whose depths span more bits is re-run with more */,
+       GSWT_OPT_DEPTH_PASSES = 12 /* test hook: 8-bit radix passes on the depth bits the next GSWT_ORDER_DEPTH frame launches (1..4; default 3,
+                                     then as many as the depth ranges of the recent frames needed); a frame whose visible depths span more
+                                     bits is flagged on the device and re-run with more, like a pair-buffer overflow */,
        GSWT_OPT_COMPOSITE = 13 /* compositor kernel: 0 (default) k_composite -- 256-pair batches staged by the whole workgroup, two barriers per
                                   batch; 1 k_composite_dw -- the four waves of a work item decoupled (128-pair batches through a ring of three LDS
                                   buffers, ready / consumed counters instead of barriers).  Same image bit for bit */ };

@@ -4,7 +4,7 @@ The reference orders TILES back to front and each tile's presorted list (wangtil
 GSWT_ORDER_REFERENCE.  GSWT_ORDER_DEPTH composites every visible splat of the frame in true depth order (stable: equal depths keep
 the reference order); the CPU checker's order_mode 1 does the same with a stable merge sort (oracle/gswt_oracle.c orc_render).
 Checked here: c3 and the dense c3d at 1920x1080 against the checker (image <= 1e-4, visible / pair counts equal), with and without
-the early-out; the 8 column bands of c4's layout (bitwise union); the frame as one hipGraph; the depth sort's own capacity overflow."""
+the early-out; the 8 column bands of c4's layout (bitwise union); the frame as one hipGraph; the depth sort's adaptive pass count."""
 import numpy as np
 import pytest
 
@@ -116,27 +116,21 @@ def test_depth_order_frames_replay_as_one_graph(renderer):
     assert not np.array_equal(want[0], want[-1])
 
 
-def test_depth_sort_capacity_overflow_is_rerun(renderer):
-    """The depth sort is launched for a capacity (emitting slots); a frame that outgrows it is flagged on the device and re-run with
-    more room, like a pair overflow: the image never shows a partially sorted frame."""
+def test_depth_sort_pass_count_follows_the_depth_range(renderer):
+    """The depth sort launches as many 8-bit passes as the depth ranges of recent frames needed; a frame whose visible depths span more bits
+    is flagged on the device (k_items) and re-run with more, like a pair-buffer overflow: the image never shows a partially sorted frame.
+    More passes than needed sort all the same."""
     s = _setup(renderer, "c1")
     W, Hh = s["W"], s["H"]
     ref_d, st = orc.render(s["ocu"], s["osu"], s["tex"], s["draws"], W, Hh, order_mode=1)
-    renderer.set_option(L.GSWT_OPT_EMIT_CAP, 256)
-    try:
-        img = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
-    finally:
-        renderer.set_option(L.GSWT_OPT_EMIT_CAP, 0)
+    img = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
     t = renderer.timings()
     assert st["n_visible"] > 10000 and t["n_visible"] == st["n_visible"] and t["n_pairs"] == st["n_pairs16"]
     assert H.max_abs_diff(img, ref_d) <= TOL
-    img2 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)       # capacity sized from the draw list again
-    assert np.array_equal(img, img2)
-    # ... and the number of radix passes: launched with one 8-bit pass, the frame's depth range needs more -> flagged, re-run
-    renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 1)
-    img3 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
-    assert np.array_equal(img, img3)
-    renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 4)                                        # more passes than needed: the extra ones leave at once
-    img4 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
-    assert np.array_equal(img, img4)
-    renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 3)
+    try:
+        for passes in (1, 2, 4):
+            renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, passes)
+            img_p = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+            assert np.array_equal(img, img_p), passes
+    finally:
+        renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 3)
