@@ -282,6 +282,8 @@ def main():
                     "scene.rs:685-695); depth: GSWT_ORDER_DEPTH, every visible splat of the frame in true depth order (the global radix depth sort)")
     ap.add_argument("--vertex-stage", default="strict", choices=["strict", "v2"], help="strict (default, GSWT_OPT_STRICT_VS = 1): vs_main operator by operator as "
                     "gswt.wgsl:152-258 writes it; v2: the fma-chain / single-reciprocal rounding sequence (the default until round 3)")
+    ap.add_argument("--composite", type=int, default=-1, help="GSWT_OPT_COMPOSITE: 0 k_composite + k_combine, 1 k_composite_dw (decoupled waves) + k_combine, "
+                    "2 k_composite<FOLD> (no k_combine launch); default: the library's")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU baseline: fly-path frames are rendered by the oracle until this much time has gone (at most 24 frames)")
     args = ap.parse_args()
     if args.timing_every <= 0:
@@ -328,6 +330,8 @@ def main():
     r.set_stream(stream.cuda_stream)                    # ctx stream: fences, all-gather and unshard are ordered on it
     r.set_option(L.GSWT_OPT_TIMING, args.timing)
     r.set_option(L.GSWT_OPT_STRICT_VS, 1 if args.vertex_stage == "strict" else 0)
+    if args.composite >= 0:
+        r.set_option(L.GSWT_OPT_COMPOSITE, args.composite)
     order_mode = L.GSWT_ORDER_DEPTH if args.order == "depth" else L.GSWT_ORDER_REFERENCE
     wang.upload_to(r)
     hmap = wang.height_map() if int(wang.user.surface_type) == 1 else None

@@ -45,7 +45,7 @@ void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr,
                 const uint32_t* = nullptr, uint32_t* = nullptr, uint32_t* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t);
+                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t, uint32_t*);
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
 void launch_proxy(hipStream_t, const ProxyArgs&, const float*, const float4*, float4*, float*);
@@ -307,7 +307,9 @@ struct gswt_ctx {
     // GSWT_OPT_STRICT_VS (default ON since round 4: k_project<.,.,STRICT> costs +1 us of 71 at c3 and nothing in frames/s): vs_main is
     // evaluated operator by operator as gswt.wgsl:152-258 writes it; 0 selects the fma-chain / single-reciprocal sequence v2
     int opt_strict_vs = 1;
-    int opt_composite = 0;                 // GSWT_OPT_COMPOSITE: 0 = k_composite (two barriers per 256-pair batch), 1 = k_composite_dw (decoupled waves)
+    // GSWT_OPT_COMPOSITE: 0 = k_composite + k_combine, 1 = k_composite_dw (decoupled waves) + k_combine, 2 = k_composite<FOLD>: the last
+    // segment of a tile to finish folds the partials, empty tiles are work items, no k_combine launch
+    int opt_composite = 0;
     unsigned long long stat_graph_launches = 0, stat_graph_rebuilds = 0, stat_graph_node_updates = 0;
     int pending_frames = 0;                // GSWT_OPT_DEFER_SWAP >= 2: frames still to be submitted on the old set
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
@@ -628,7 +630,7 @@ try {
     case GSWT_OPT_GRAPH: c->opt_graph = value; return GSWT_OK;
     case GSWT_OPT_STRICT_VS: c->opt_strict_vs = value != 0; return GSWT_OK;
     case GSWT_OPT_COMPOSITE:
-        if (value != 0 && value != 1) return fail(c, GSWT_ERR_BAD_ARG, "unknown compositor variant %d", value);
+        if (value < 0 || value > 2) return fail(c, GSWT_ERR_BAD_ARG, "unknown compositor variant %d", value);
         c->opt_composite = value; return GSWT_OK;
     case GSWT_OPT_DEPTH_PASSES:
         if (value < 1 || value > 4) return fail(c, GSWT_ERR_BAD_ARG, "depth-sort passes must be 1..4");
@@ -1358,7 +1360,9 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     const size_t out_px = (size_t)out_rows * f.out_w;
     sl.n_tiles = n_tiles;
     float4* const d_out = a.d_out;
-    HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1));
+    // (behind the per-tile ranges: one ticket word per tile for GSWT_OPT_COMPOSITE = 2, cleared with them by k_cull)
+    HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1 + ((size_t)n_tiles + 1) / 2 + 1));
+    uint32_t* const d_tile_tick = reinterpret_cast<uint32_t*>(sl.ranges.p + (size_t)n_tiles + 1);
     const bool dbg = c->opt_debug_varyings != 0;
     const bool need_depths = a.d_bgd != nullptr || cfg->order_mode == GSWT_ORDER_DEPTH;
     if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)D.n_entries + 1));
@@ -1428,7 +1432,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // part is contiguous with the head; the depth sort's (behind the pair sort's rows) is the kernel's second clear range.
     const size_t n_zero_a = 16 + n_super2 + rz_pair;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
-                reinterpret_cast<uint32_t*>(sl.ranges.p), (uint32_t)n_tiles * 2u, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
+                reinterpret_cast<uint32_t*>(sl.ranges.p), ((uint32_t)n_tiles + 1u) * 2u + (uint32_t)n_tiles, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
                 d_radix_depth, (uint32_t)rz_depth);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
@@ -1461,7 +1465,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // ---- composite
     launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.depths.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
                      sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr,
-                     d_counters, sl.hc_dev, c->opt_composite, depth_order ? d_krange : nullptr, sl.depth_passes);
+                     d_counters, sl.hc_dev, c->opt_composite, depth_order ? d_krange : nullptr, sl.depth_passes, d_tile_tick);
     c->last_n_tiles = (uint32_t)n_tiles;
     c->last_slot = (int)(&sl - c->slots);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));

@@ -1635,8 +1635,11 @@ __global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ j
 // than were launched = the pair list is not in depth order: the frame is flagged (counters[3]) and the host re-runs it with more passes.
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
                                                 uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items,
-                                                const uint32_t* __restrict__ krange, uint32_t n_launched, unsigned long long* __restrict__ counters)
+                                                const uint32_t* __restrict__ krange, uint32_t n_launched, unsigned long long* __restrict__ counters,
+                                                uint32_t all_tiles)
 {
+    // all_tiles (GSWT_OPT_FOLD_COMBINE): a tile without pairs gets one EMPTY work item -- k_composite then writes its background, and no
+    // k_combine launch follows the compositor
     if (krange && blockIdx.x == 0u && threadIdx.x == 0u) {
         const uint32_t need = sort_passes_needed(krange);
         counters[2] = need;
@@ -1671,7 +1674,8 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
 #pragma unroll
             for (int j = 0; j < kPer; j++) {
                 const uint32_t len = e[j].y - e[j].x;
-                part += seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;
+                const uint32_t qq = seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;
+                part += all_tiles ? max(qq, 1u) : qq;
             }
         }
         const uint32_t pi = wave_incl_scan(part, lane);
@@ -1683,7 +1687,8 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
         const uint32_t len = r[j].y - r[j].x;
-        const uint32_t q = seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;   // (a 32-bit divide is ~40 VALU)
+        uint32_t q = seg_pow2 ? (len + seg - 1u) >> seg_sh : (len + seg - 1u) / seg;   // (a 32-bit divide is ~40 VALU)
+        if (all_tiles) q = max(q, 1u);
         cnt[j] = base + j * 1024 + (int)threadIdx.x < n_tiles ? q : 0u;
     }
 #pragma unroll
@@ -1983,15 +1988,25 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 // the gather latency was already covered by the other workgroups of the CU.  "stage-only 58 us" in the ablation is
 // what staging costs with nothing to hide behind, not a serial share of the full kernel.
 
-template <bool EARLY, bool DEPTH, bool COLF, bool PK, bool DPPW>
+// FOLD (GSWT_OPT_FOLD_COMBINE, round 4): no k_combine behind the compositor.  (a) k_items hands out an empty work item for every tile
+// without pairs: its background is written here.  (b) The segments of a long tile list are folded by whichever of their workgroups finishes
+// LAST: every segment stores its partial (C, T) with agent-scope (sc1) stores -- the L2 of an XCD is not coherent with the other seven
+// inside a kernel, and the segments of one tile run on different XCDs --, waits for them, and takes a ticket on the tile's counter; the
+// workgroup that draws the last ticket reads all partials back (sc1 loads) and folds them front to back in segment order, exactly as
+// k_combine does: the image is bit-identical whichever workgroup that is.  (c) Workgroup 0 publishes the frame's counters to the host.
+// One ticket per multi-segment work item on ITS tile's word: ~700 atomics per c3 frame on ~250 addresses (a single frame-wide ticket
+// word would serialise at ~8 ns per atomic on the memory side).
+template <bool EARLY, bool DEPTH, bool COLF, bool PK, bool DPPW, bool FOLD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || COLF) ? 7 : 8, 8))) void k_composite(const Frame f, const uint2* __restrict__ ranges,
                                                    const uint32_t* __restrict__ item_base, const uint4* __restrict__ item_tab,
                                                    uint32_t seg, const uint32_t* __restrict__ vals, const Rec* __restrict__ recs,
                                                    const float* __restrict__ depths, const float4* __restrict__ col_f,
                                                    const float4* __restrict__ bg_rgba, const float* __restrict__ bg_depth,
                                                    float4* __restrict__ out, float4* __restrict__ partials,
-                                                   int n_tiles, int out_rows)
+                                                   int n_tiles, int out_rows, uint32_t* __restrict__ tile_tick,
+                                                   const unsigned long long* __restrict__ counters, unsigned long long* __restrict__ host_counters)
 {
+    __shared__ uint32_t s_last;
     __shared__ float4 s_q0[257], s_q1[257];                     // [256] = the null record (list padding)
     __shared__ uint32_t s_bb[256];                              // the 16 sub-blocks a staged pair's pixel box touches (bit 4 strip + column group)
     __shared__ float4 s_q2[COLF ? 257 : 1];
@@ -2009,6 +2024,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
 #endif
     const uint32_t n_items = item_base[n_tiles];
     const uint4 it = item_tab[item];                 // (in flight together with n_items; garbage past n_items, unused)
+    // FOLD: this is the frame's last kernel -- the four result counters go straight into the slot's pinned host words
+    if (FOLD && item == 0u && threadIdx.x < 4u && host_counters) host_counters[threadIdx.x] = counters[threadIdx.x];
     if (item >= n_items) return;
     GSWT_TR(1, GSWT_NOW())
     GSWT_TR(4, it.w - it.z)
@@ -2145,10 +2162,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     GSWT_TR(6, tr_walk)
     const float k255 = 1.0f / 255.0f;      // colour is continuous: sum(w * byte) / 255 vs sum(w * (byte / 255)) differ in the last bits only
     if (!COLF) { ar *= k255; ag *= k255; ab *= k255; }
-    if (multi_seg) {
+    if (multi_seg && !FOLD) {
         // partial (C, T) of this segment; k_combine folds the segments front to back
         partials[(size_t)item * 256u + tid] = make_float4(ar, ag, ab, T);
         return;
+    }
+    if (multi_seg && FOLD) {
+        float* const pp = reinterpret_cast<float*>(partials + (size_t)item * 256u + tid);
+        __hip_atomic_store(pp + 0, ar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, ag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 2, ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 3, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);                   // this thread's partial has been written through
+        __syncthreads();                                 // ... and so have the other 255
+        const uint32_t i0 = item_base[tile], n_seg = item_base[tile + 1] - i0;
+        if (tid == 0) s_last = __hip_atomic_fetch_add(&tile_tick[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_seg - 1u ? 1u : 0u;
+        __syncthreads();
+        if (s_last == 0u) return;
+        // the last segment to finish folds them all, front to back: (C1, T1) o (C2, T2) = (C1 + T1 C2, T1 T2) -- k_combine's loop
+        T = 1.0f; ar = 0.0f; ag = 0.0f; ab = 0.0f;
+        for (uint32_t s0 = 0; s0 < n_seg; s0 += 4u) {
+            float4 p[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                const float* q = reinterpret_cast<const float*>(partials + (size_t)(i0 + min(s0 + k, n_seg - 1u)) * 256u + tid);
+                p[k].x = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p[k].y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p[k].z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                p[k].w = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                if (s0 + k < n_seg) {                     // workgroup-uniform
+                    ar = fmaf(T, p[k].x, ar);
+                    ag = fmaf(T, p[k].y, ag);
+                    ab = fmaf(T, p[k].z, ab);
+                    T = T * p[k].w;
+                }
+            }
+        }
     }
     // pixel coordinates again, from a copy of the thread id the compiler cannot connect to the one above: otherwise px, py
     // and the output row stay in VGPRs across the whole walk (the kernel sits exactly at the 64-VGPR / 8-wave limit)
@@ -2597,7 +2649,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
                       const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
                       hipEvent_t ev_begin, hipEvent_t ev_end, unsigned long long* counters, unsigned long long* host_counters, int variant,
-                      const uint32_t* krange, uint32_t depth_passes)
+                      const uint32_t* krange, uint32_t depth_passes, uint32_t* tile_tick)
 {
     if (n_tiles == 0) {                 // a shard without screen tiles (more ranks than tile columns): the events still exist
         if (ev_begin) hipEventRecord(ev_begin, s);
@@ -2605,7 +2657,10 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         return;
     }
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
-    GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items, krange, depth_passes, counters);
+    // variant 2 (GSWT_OPT_FOLD_COMBINE): k_composite folds the segment partials itself and writes the empty tiles: no k_combine launch
+    const bool fold = variant == 2 && tile_tick != nullptr && host_counters != nullptr;
+    GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items, krange, depth_passes, counters,
+                fold ? 1u : 0u);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
 #ifdef GSWT_EXPERIMENTS
@@ -2684,9 +2739,22 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, (const unsigned long long*)counters, host_counters);
         return;
     }
+    if (fold) {
+#define GSWT_LAUNCH_COMPOSITE_F(E, D, C)                                                                                       \
+        GSWT_LAUNCH((k_composite<E, D, C, false, false, true>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
+                           depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows, tile_tick, (const unsigned long long*)counters, host_counters)
+        if (colf) { if (depth) GSWT_LAUNCH_COMPOSITE_F(false, true, true); else GSWT_LAUNCH_COMPOSITE_F(false, false, true); }
+        else if (early && depth) GSWT_LAUNCH_COMPOSITE_F(true, true, false);
+        else if (early) GSWT_LAUNCH_COMPOSITE_F(true, false, false);
+        else if (depth) GSWT_LAUNCH_COMPOSITE_F(false, true, false);
+        else GSWT_LAUNCH_COMPOSITE_F(false, false, false);
+#undef GSWT_LAUNCH_COMPOSITE_F
+        if (ev_end) hipEventRecord(ev_end, s);
+        return;
+    }
 #define GSWT_LAUNCH_COMPOSITE_K(E, D, C, PK, DW)                                                                               \
     GSWT_LAUNCH((k_composite<E, D, C, PK, DW>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
-                       depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
+                       depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows, (uint32_t*)nullptr, (const unsigned long long*)nullptr, (unsigned long long*)nullptr)
 #ifdef GSWT_EXPERIMENTS      // measured and slower (profiles/r03_composite_variants.txt): 0x80000 the packed-coordinate step (15 VALU instead of 19), 0x100000 the register-broadcast (DPP) walk
 #define GSWT_LAUNCH_COMPOSITE(E, D, C) do { if ((f.dbg_flags & 0x180000) == 0x180000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true, true); /* 0x180000: the scalar step with the blend predicated by v_cndmask behind a ballot test (round 2's form) instead of EXEC masking */ \
         else if (f.dbg_flags & 0x80000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true, false); else if (f.dbg_flags & 0x100000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, true); else GSWT_LAUNCH_COMPOSITE_K(E, D, C, false, false); } while (0)

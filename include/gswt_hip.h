@@ -198,7 +198,9 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                      bits is flagged on the device and re-run with more, like a pair-buffer overflow */,
        GSWT_OPT_COMPOSITE = 13 /* compositor kernel: 0 (default) k_composite -- 256-pair batches staged by the whole workgroup, two barriers per
                                   batch; 1 k_composite_dw -- the four waves of a work item decoupled (128-pair batches through a ring of three LDS
-                                  buffers, ready / consumed counters instead of barriers).  Same image bit for bit */ };
+                                  buffers, ready / consumed counters instead of barriers); 2 k_composite<FOLD> -- the segments of a long tile list
+                                  are folded by whichever of their workgroups finishes last (agent-scope stores + a ticket per tile), tiles
+                                  without pairs are work items: no k_combine launch behind the compositor.  Same image bit for bit */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

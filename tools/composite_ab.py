@@ -23,12 +23,12 @@ for name in (sys.argv[1:] or ["c3", "c3d"]):
     for seg in ((512, 1536, 4096) if name != "c3" else (512, 1024, 1536, 2048)):
         r.set_option(L.GSWT_OPT_SEGMENT, seg)
         row = []
-        for variant in (0, 1):
+        for variant in (0, 1, 2):
             r.set_option(L.GSWT_OPT_COMPOSITE, variant)
             ms = []
             for i in range(14):
                 r.render_wait(r.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5))
                 ms.append(r.timings()["ms_composite_kernel"])
             row.append(1e3 * float(np.median(ms[4:])))
-        print(f"{name} seg {seg:5d}: k_composite {row[0]:7.1f} us   k_composite_dw {row[1]:7.1f} us   pairs {r.timings()['n_pairs']}")
+        print(f"{name} seg {seg:5d}: k_composite {row[0]:7.1f} us   k_composite_dw {row[1]:7.1f} us   k_composite<FOLD> {row[2]:7.1f} us   pairs {r.timings()['n_pairs']}")
     r.set_option(L.GSWT_OPT_COMPOSITE, 0)

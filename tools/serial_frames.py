@@ -21,6 +21,8 @@ if os.environ.get("GSWT_DBG_FLAGS"):
     r.set_option(L.GSWT_OPT_DEBUG_FLAGS, int(os.environ["GSWT_DBG_FLAGS"], 0))
 if os.environ.get("GSWT_VS", "") == "v2":
     r.set_option(L.GSWT_OPT_STRICT_VS, 0)
+if os.environ.get("GSWT_COMPOSITE"):
+    r.set_option(L.GSWT_OPT_COMPOSITE, int(os.environ["GSWT_COMPOSITE"]))
 order = L.GSWT_ORDER_DEPTH if os.environ.get("GSWT_ORDER", "") == "depth" else L.GSWT_ORDER_REFERENCE
 wang.upload_to(r)
 r.configure(wang.height_map() if int(wang.user.surface_type) == 1 else None)
