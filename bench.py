@@ -743,6 +743,7 @@ def main():
                                        "measured by the builder (one-GPU boxes only): this line is the first" if world > 1 else "single GPU")},
             "frames_in_flight": slots,
             "segment": segment,
+            "device_memory_in_use_GB": (lambda fr_to: round((fr_to[1] - fr_to[0]) / 1e9, 2))(torch.cuda.mem_get_info(dev)),
             "sort_events": {"swapped_in": swaps, "swap_in_ms_mean": float(np.mean(swap_ms)) if swap_ms else None,
                             "merged_groups_sorted": mg_built, "merged_groups_copied": mg_reused, "merged_groups_copied_from_older_than_previous_event": mg_deep,
                             "merged_groups_sorted_share": (mg_built / float(mg_built + mg_reused)) if (mg_built + mg_reused) else None,
