@@ -1321,10 +1321,10 @@ __global__ __launch_bounds__(256) void k_radix_supscan(uint32_t* __restrict__ gs
 // The block's 4096 items are first ranked INTO LDS (sorted by digit inside the block), then copied out: consecutive threads
 // write consecutive addresses of a digit's run instead of every lane storing two separate words to its own rank position
 // (a wave's store instruction used to touch as many regions as it held distinct digits).
-// AUX (the depth passes of GSWT_ORDER_DEPTH): a second 4-byte payload per item -- the pair's tile id -- travels with it.  It is NOT staged
-// through LDS with the (key, value) pair: the ranking leaves each sorted item's source position inside the block (u16), and the copy-out
-// fetches the payload from there -- a gather confined to the block's own 16 KB window of the input, every sector of which this workgroup
-// consumes -- and stores it at the item's global position beside the value.
+// AUX (the depth passes of GSWT_ORDER_DEPTH): a second 4-byte payload per item -- the pair's tile id -- travels with it, staged through LDS
+// like the (key, value) pair (16 KB more: 60 KB per workgroup, two workgroups per CU instead of three -- a sort pass is ~650 workgroups at c3,
+// 2.5 per CU).  A first version left each sorted item's source position in the block (u16) and let the copy-out fetch the payload from the
+// block's 16 KB window of the input: 64 scattered dwords per wave instruction, +4.5 us per pass at c3 and +70 us at c5's 21 M pairs.
 template <int kSortThreads, bool AUX>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -1350,13 +1350,13 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     __shared__ uint32_t s_w[4], s_w2[4];
     __shared__ uint32_t s_gs[2][256];                   // direct group sums: [0] earlier groups, [1] all groups (waves 4..7 -> waves 0..3)
     __shared__ uint2 s_kv[kSortBlock];
-    __shared__ uint16_t s_src[AUX ? kSortBlock : 1];    // AUX: sorted position inside the block -> source position inside the block
+    __shared__ uint32_t s_aux[AUX ? kSortBlock : 1];    // AUX: the payload, ranked beside s_kv
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (int k = 0; k < kSortWaves * 256 / kSortThreads; k++) (&s_h[0][0])[k * kSortThreads + threadIdx.x] = 0;
     __syncthreads();
     const uint32_t blk0 = blockIdx.x * kSortBlock;
     const uint32_t base = blk0 + w * (64 * kSortItems);
-    uint32_t key[kSortItems], val[kSortItems];
+    uint32_t key[kSortItems], val[kSortItems], aux[AUX ? kSortItems : 1];
     // every load of the workgroup is issued before anything is consumed: clamped indices instead of lane masks
     // (masked loads were waited for one by one: 16 + ~30 dependent round trips per wave, the whole 31 us of this kernel)
 #pragma unroll
@@ -1364,6 +1364,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         const uint32_t i = min(base + (uint32_t)k * 64u + lane, n - 1u);      // n > 0 here
         key[k] = keys_in[i];
         val[k] = vals_in[i];
+        if (AUX) aux[AUX ? k : 0] = aux_in[i];
     }
     // digit = threadIdx.x (first 256 threads): global base of this workgroup's first item with that digit = items with a
     // smaller digit + the same digit in earlier groups of 32 workgroups (gsup) + in earlier workgroups of this group (ghist)
@@ -1466,7 +1467,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         pos = (uint32_t)__shfl((int)pos, leader, 64);
         if (valid) {
             s_kv[pos + rank] = make_uint2(key[k], val[k]);
-            if (AUX) s_src[AUX ? pos + rank : 0u] = (uint16_t)(w * (64u * kSortItems) + (uint32_t)k * 64u + lane);
+            if (AUX) s_aux[AUX ? pos + rank : 0u] = aux[AUX ? k : 0];
         }
     }
     __syncthreads();
@@ -1479,7 +1480,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
             const uint2 kv = s_kv[i];
             const uint32_t gp = s_g[((kv.x - kmin) >> shift) & mask] + i;
             vals_out[gp] = kv.y;
-            if (AUX) aux_out[gp] = aux_in[blk0 + s_src[AUX ? i : 0u]];
+            if (AUX) aux_out[gp] = s_aux[AUX ? i : 0u];
             if (!ranges) keys_out[gp] = kv.x;
             else {
                 // LAST pass of the frame's pair sort: the block in LDS is sorted by the whole key (the passes before ordered the

@@ -141,6 +141,14 @@ def test_error_codes(renderer):
         renderer.render(cam, orc.scene_uniforms(num_lod=2), 64, 48, shard=(3, 2))
     with pytest.raises(GSWTError):
         renderer.set_option(L.GSWT_OPT_SEGMENT, 100)
+    # the profiling ablations (wrong images by design) are not in the product library: it cannot be switched into them
+    with pytest.raises(GSWTError) as e:
+        renderer.set_option(L.GSWT_OPT_DEBUG_FLAGS, 4)
+    assert e.value.code == L.GSWT_ERR_BAD_ARG
+    renderer.set_option(L.GSWT_OPT_DEBUG_FLAGS, 0)
+    for key, bad_value in ((L.GSWT_OPT_COMPOSITE, 3), (L.GSWT_OPT_DEPTH_PASSES, 0), (L.GSWT_OPT_DEPTH_PASSES, 5)):
+        with pytest.raises(GSWTError):
+            renderer.set_option(key, bad_value)
     # the ctx is still usable afterwards
     img = renderer.render(cam, orc.scene_uniforms(num_lod=2, map_half_wh=(1, 2)), 64, 48)
     assert img.shape == (48, 64, 4)

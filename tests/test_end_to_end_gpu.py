@@ -457,6 +457,50 @@ def test_merged_group_reuse_reaches_back_several_events(renderer):
         assert np.array_equal(img_a, img_b)
 
 
+def test_merged_group_reuse_does_not_survive_a_scene_upload(renderer):
+    """the merged lists the draw sets retain as copy sources belong to ONE scene.  Two tile sets of the same shape (same counts,
+    other splats: another seed) uploaded one after the other on one ctx -- the second scene's sort events must not copy lists sorted
+    for the first (they match by view, member tile ids and length): lists and images equal the ones built with every group re-sorted."""
+    from gswt_renderer_amd import _lib as L
+    cfg = dict(tile_map_half_wh=(4, 4), surface_type=0, lod_max_dist=22.0, tile_sort_type=3, merge_type=2, merge_topk=40)
+    W, Hh = 320, 200
+    path = [((4.2 + 0.35 * k, 1.0 + 0.5 * k, 1.5), (5.0 + 0.3 * k, 4.0 + 0.55 * k, 1.0)) for k in range(4)]
+
+    def run(seed, reuse):
+        renderer.set_option(L.GSWT_OPT_NO_MERGE_REUSE, 0 if reuse else 1)
+        verts = synth.make_tileset(n_lod=3, n_tile=16, lod0_count=900, seed_offset=seed)
+        pipe = GSWTPipeline(verts, host.user_data(**cfg), renderer=renderer, device_merge=True)      # uploads the scene + its raw depths
+        out = []
+        for pos, tgt in path:
+            cu, vp = host.camera_uniforms(pos, tgt, (0, 0, 1), 45.0, 0.1, 2400.0, W, Hh)
+            pipe.update(pos, vp, force_sort=True)
+            img = pipe.render(cu, W, Hh)
+            lst, mp = renderer.read_merged()
+            out.append((img, lst.copy(), mp.copy()))
+        return out
+
+    try:
+        want = run(7, False)                 # scene B alone, every group sorted
+        run(0, True)                         # scene A fills the retained draw sets ...
+        got = run(7, True)                   # ... then scene B of the same shape on the same ctx, reuse on
+    finally:
+        renderer.set_option(L.GSWT_OPT_NO_MERGE_REUSE, 0)
+    assert not np.array_equal(run(0, True)[0][1], want[0][1])                    # the two scenes really sort differently
+    for (img_a, l_a, m_a), (img_b, l_b, m_b) in zip(want, got):
+        assert np.array_equal(l_a, l_b) and np.array_equal(m_a, m_b)
+        assert np.array_equal(img_a, img_b)
+
+
+def test_one_row_map_with_edge_merging(renderer):
+    """a (2 N + 1) x 1 map (map_half_wh[1] == 0): the merged-member offset of gswt.wgsl:52-63 divides the map id by a map height
+    of ONE -- the multiply-high shortcut of k_project has no magic number for that (0xFFFFFFFF / 1 + 1 wraps) and must divide."""
+    cfg = dict(tile_map_half_wh=(4, 0), surface_type=0, lod_max_dist=30.0, tile_sort_type=0, merge_type=2, merge_topk=40, merge_dot_threshold=1.0)
+    cam = ((2.0, 0.5, 7.0), (2.0, 2.0, 0.0))             # from above: the three middle cells (map ids 3, 4, 5) form one merged group
+    img, ref, kinds, st = _run_case(renderer, cfg, cam, 320, 240, lod0=1500)
+    assert kinds["merged"] >= 1 and st["n_visible"] > 1000, (kinds, st)
+    assert H.max_abs_diff(img, ref) <= TOL
+
+
 def test_deferred_swap_in_takes_effect_once_built(renderer):
     """GSWT_OPT_DEFER_SWAP: a sort event is read by the first frame submitted after its device-side build has finished; until then
     frames keep the previous draw list, and the next event makes a still-pending one current.  After gswt_synchronize (which

@@ -2,6 +2,8 @@
 """k_composite alone, one frame at a time, for a list of (segment, debug flags) settings: kernel time from its own events."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the ablation / variant bits of GSWT_OPT_DEBUG_FLAGS exist only in the measurement build (`make -C gswt_renderer_amd/csrc variants`)
+os.environ.setdefault("GSWT_HIP_LIB", os.path.join(ROOT, "build_var", "libgswt_hip_exp.so"))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

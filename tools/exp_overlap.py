@@ -3,6 +3,8 @@
 stream, rendering the c3 frame concurrently; (b) k_composite ablations through GSWT_OPT_DEBUG_FLAGS."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the ablation / variant bits of GSWT_OPT_DEBUG_FLAGS exist only in the measurement build (`make -C gswt_renderer_amd/csrc variants`)
+os.environ.setdefault("GSWT_HIP_LIB", os.path.join(ROOT, "build_var", "libgswt_hip_exp.so"))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

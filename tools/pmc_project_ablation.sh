@@ -2,6 +2,7 @@
 # Where k_project's VALU instructions go: one PMC pass per ablation flag of the kernel (GSWT_DBG_FLAGS: 256 = nothing behind the launch
 # table, 128 = stop in front of the record gather, 16 = stop after the frustum cull, 8 = no stores / pairs, 0 = the whole kernel).
 # Usage (GPU box): bash tools/pmc_project_ablation.sh <workload>
+export GSWT_HIP_LIB=${GSWT_HIP_LIB:-$PWD/build_var/libgswt_hip_exp.so}   # ablation / variant bits live in the measurement build only (make variants)
 set -o pipefail
 WL=${1:-c3}
 OUT=gpurun_out/pmc_project_$WL

@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes (each in its own run, --kernel-trace only beside --pmc) over frames rendered one at a time, for a list of
 # compositor variants given as "name:segment:debug-flags".  Usage (GPU box): bash tools/pmc_variants.sh <tag> <workload> name:seg:flags ...
+export GSWT_HIP_LIB=${GSWT_HIP_LIB:-$PWD/build_var/libgswt_hip_exp.so}   # ablation / variant bits live in the measurement build only (make variants)
 set -o pipefail
 TAG=$1; WL=$2; shift 2
 OUT=gpurun_out/pmcv_$TAG

@@ -1,5 +1,6 @@
 #!/bin/bash
 # k_project one frame at a time with each ablation flag (see pmc_project_ablation.sh): where its time goes.  GPU box: bash tools/project_ablation_times.sh
+export GSWT_HIP_LIB=${GSWT_HIP_LIB:-$PWD/build_var/libgswt_hip_exp.so}   # ablation / variant bits live in the measurement build only (make variants)
 mkdir -p gpurun_out/abl_t
 export TMPDIR=/tmp
 for FL in 0 8 16 128 256; do

@@ -3,6 +3,8 @@
 (GSWT_OPT_DEBUG_FLAGS: 1 = compositor without the walk, 4 = without staging, 8 = k_project emits no pairs)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the ablation / variant bits of GSWT_OPT_DEBUG_FLAGS exist only in the measurement build (`make -C gswt_renderer_amd/csrc variants`)
+os.environ.setdefault("GSWT_HIP_LIB", os.path.join(ROOT, "build_var", "libgswt_hip_exp.so"))
 sys.path.insert(0, ROOT)
 import torch
 import bench
