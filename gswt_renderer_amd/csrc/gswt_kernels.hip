@@ -1321,11 +1321,14 @@ __global__ __launch_bounds__(256) void k_radix_supscan(uint32_t* __restrict__ gs
 // The block's 4096 items are first ranked INTO LDS (sorted by digit inside the block), then copied out: consecutive threads
 // write consecutive addresses of a digit's run instead of every lane storing two separate words to its own rank position
 // (a wave's store instruction used to touch as many regions as it held distinct digits).
-// AUX (the depth passes of GSWT_ORDER_DEPTH): a second 4-byte payload per item -- the pair's tile id -- travels with it, staged through LDS
-// like the (key, value) pair (16 KB more: 60 KB per workgroup, two workgroups per CU instead of three -- a sort pass is ~650 workgroups at c3,
-// 2.5 per CU).  A first version left each sorted item's source position in the block (u16) and let the copy-out fetch the payload from the
-// block's 16 KB window of the input: 64 scattered dwords per wave instruction, +4.5 us per pass at c3 and +70 us at c5's 21 M pairs.
-template <int kSortThreads, bool AUX>
+// AUX (the depth passes of GSWT_ORDER_DEPTH): a second 4-byte payload per item -- the pair's tile id -- travels with it.
+//   AUX = 1: the ranking leaves each sorted item's source position inside the block (u16, 8 KB of LDS) and the copy-out fetches the payload
+//            from the block's own 16 KB window of the input (64 scattered dwords per wave instruction).  Three workgroups per CU.
+//   AUX = 2: the payload is staged through LDS beside the (key, value) pair (16 KB more: 60 KB per workgroup, two workgroups per CU).
+// Measured per pass (scatter<512>, without payload / AUX 1 / AUX 2): c3 (2.66 M pairs) 18.5 / 22.7 / 26.6 us, c3d (8.2 M) 37.5 / 55.7 / 54.8,
+// c5 (21.4 M) 99 / 164 / 145: the small sort is a latency chain that wants the third workgroup, the large one pays for the scattered
+// reads.  launch_sort takes AUX 2 above 12 M pairs of capacity.
+template <int kSortThreads, int AUX>
 __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
@@ -1350,13 +1353,14 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
     __shared__ uint32_t s_w[4], s_w2[4];
     __shared__ uint32_t s_gs[2][256];                   // direct group sums: [0] earlier groups, [1] all groups (waves 4..7 -> waves 0..3)
     __shared__ uint2 s_kv[kSortBlock];
-    __shared__ uint32_t s_aux[AUX ? kSortBlock : 1];    // AUX: the payload, ranked beside s_kv
+    __shared__ uint32_t s_aux[AUX == 2 ? kSortBlock : 1];    // AUX 2: the payload, ranked beside s_kv
+    __shared__ uint16_t s_src[AUX == 1 ? kSortBlock : 1];    // AUX 1: sorted position inside the block -> source position inside the block
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (int k = 0; k < kSortWaves * 256 / kSortThreads; k++) (&s_h[0][0])[k * kSortThreads + threadIdx.x] = 0;
     __syncthreads();
     const uint32_t blk0 = blockIdx.x * kSortBlock;
     const uint32_t base = blk0 + w * (64 * kSortItems);
-    uint32_t key[kSortItems], val[kSortItems], aux[AUX ? kSortItems : 1];
+    uint32_t key[kSortItems], val[kSortItems], aux[AUX == 2 ? kSortItems : 1];
     // every load of the workgroup is issued before anything is consumed: clamped indices instead of lane masks
     // (masked loads were waited for one by one: 16 + ~30 dependent round trips per wave, the whole 31 us of this kernel)
 #pragma unroll
@@ -1364,7 +1368,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         const uint32_t i = min(base + (uint32_t)k * 64u + lane, n - 1u);      // n > 0 here
         key[k] = keys_in[i];
         val[k] = vals_in[i];
-        if (AUX) aux[AUX ? k : 0] = aux_in[i];
+        if (AUX == 2) aux[AUX == 2 ? k : 0] = aux_in[i];
     }
     // digit = threadIdx.x (first 256 threads): global base of this workgroup's first item with that digit = items with a
     // smaller digit + the same digit in earlier groups of 32 workgroups (gsup) + in earlier workgroups of this group (ghist)
@@ -1467,7 +1471,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
         pos = (uint32_t)__shfl((int)pos, leader, 64);
         if (valid) {
             s_kv[pos + rank] = make_uint2(key[k], val[k]);
-            if (AUX) s_aux[AUX ? pos + rank : 0u] = aux[AUX ? k : 0];
+            if (AUX == 2) s_aux[AUX == 2 ? pos + rank : 0u] = aux[AUX == 2 ? k : 0];
+            if (AUX == 1) s_src[AUX == 1 ? pos + rank : 0u] = (uint16_t)(w * (64u * kSortItems) + (uint32_t)k * 64u + lane);
         }
     }
     __syncthreads();
@@ -1480,7 +1485,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* 
             const uint2 kv = s_kv[i];
             const uint32_t gp = s_g[((kv.x - kmin) >> shift) & mask] + i;
             vals_out[gp] = kv.y;
-            if (AUX) aux_out[gp] = s_aux[AUX ? i : 0u];
+            if (AUX == 2) aux_out[gp] = s_aux[AUX == 2 ? i : 0u];
+            if (AUX == 1) aux_out[gp] = aux_in[blk0 + s_src[AUX == 1 ? i : 0u]];
             if (!ranges) keys_out[gp] = kv.x;
             else {
                 // LAST pass of the frame's pair sort: the block in LDS is sorted by the whole key (the passes before ordered the
@@ -2609,9 +2615,11 @@ int launch_sort(hipStream_t s, uint32_t* keys_a, uint32_t* vals_a, uint32_t* key
 #define GSWT_SORT_PASS(T)                                                                                                        \
         GSWT_LAUNCH(k_radix_hist<T>, dim3(nblk), dim3(T), s, ki, n_ptr, n_cap, (uint32_t)shift, mask, nbits, ghist, gsup, gtot, nblk, nsup, krange); \
         if (nsup > kSupDirect) GSWT_LAUNCH(k_radix_supscan, dim3(64), dim3(256), s, gsup, gtot, nsup);                          \
-        if (aux_a) GSWT_LAUNCH((k_radix_scatter<T, true>), dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
+        if (aux_a && n_cap > (12u << 20)) GSWT_LAUNCH((k_radix_scatter<T, 2>), dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits, \
                            ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr, krange, xi, xo);                  \
-        else GSWT_LAUNCH((k_radix_scatter<T, false>), dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
+        else if (aux_a) GSWT_LAUNCH((k_radix_scatter<T, 1>), dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
+                           ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr, krange, xi, xo);                  \
+        else GSWT_LAUNCH((k_radix_scatter<T, 0>), dim3(nblk), dim3(T), s, ki, vi, ko, vo, n_ptr, n_cap, (uint32_t)shift, mask, nbits,    \
                            ghist, gsup, gtot, nblk, nsup, shift + 8 >= key_bits ? ranges : (uint2*)nullptr, krange, xi, xo)
         if (threads == 512) { GSWT_SORT_PASS(512); }
         else { GSWT_SORT_PASS(256); }
