@@ -47,14 +47,22 @@ def _cases():
             rc["draw_mode"] = int(_RNG.integers(1, 5))
         if k % 6 == 5:
             rc["point_cloud_radius"] = 0.003
-        out.append(pytest.param(cfg, (tuple(float(x) for x in pos), tuple(float(x) for x in tgt)), rc, bool(k % 3 == 0), id=f"case{k}"))
+        # round 4: the order mode (reference / global depth sort) and the compositor variant (k_composite + k_combine, decoupled waves,
+        # folded combine) rotate through the cases too
+        mode = dict(order_mode=int(k % 4 == 1), composite=(0, 1, 2)[k % 3])
+        out.append(pytest.param(cfg, (tuple(float(x) for x in pos), tuple(float(x) for x in tgt)), rc, bool(k % 3 == 0), mode, id=f"case{k}"))
     return out
 
 
-@pytest.mark.parametrize("cfg,cam,rc,bg", _cases())
-def test_random_sweep(renderer, cfg, cam, rc, bg):
+@pytest.mark.parametrize("cfg,cam,rc,bg,mode", _cases())
+def test_random_sweep(renderer, cfg, cam, rc, bg, mode):
+    from gswt_renderer_amd import _lib as L
     W, Hh = (272, 176)
-    with np.errstate(all="ignore"):
-        img, ref, kinds, st = _run_case(renderer, cfg, cam, W, Hh, lod0=500, bg=bg, render_config=rc,
-                                        t_eps=1e-5 if cfg["surface_type"] == 0 else 0.0)
-    assert H.max_abs_diff(img, ref) <= TOL, (cfg, cam, rc, kinds, st)
+    t_eps = 1e-5 if cfg["surface_type"] == 0 else 0.0
+    renderer.set_option(L.GSWT_OPT_COMPOSITE, mode["composite"])
+    try:
+        with np.errstate(all="ignore"):
+            img, ref, kinds, st = _run_case(renderer, cfg, cam, W, Hh, lod0=500, bg=bg, render_config=rc, t_eps=t_eps, order_mode=mode["order_mode"])
+    finally:
+        renderer.set_option(L.GSWT_OPT_COMPOSITE, 0)
+    assert H.max_abs_diff(img, ref) <= TOL + t_eps, (cfg, cam, rc, mode, kinds, st)
