@@ -2,12 +2,15 @@
 //
 //   k_cull        : per-draw viewport cull + lod_enable skip (renderer.rs:472-497), column-band cull; clears the frame counters
 //   k_project     : Wang-tile instancing + vs_main (gswt.wgsl:27-422) per list entry: None / HeightMap / Sphere surface,
-//                   LOD blend, EWA projection, debug draw modes
-//   k_totals/k_emit : (splat, 16x16 screen tile) pair emission in composite order, no scan launches
-//   radix sort    : stable LSD sort of the pairs on the tile bits only; k_mg_* : merged-group lists on the device
-//   k_ranges/k_items : per-screen-tile [start, end) of the sorted pair list; work items (tile, segment of its list: GSWT_OPT_SEGMENT pairs)
+//                   LOD blend, EWA projection, debug draw modes; <STRICT> (default) evaluates the shader text operator by operator
+//   k_totals/k_emit : (splat, 16x16 screen tile) pair emission in composite order, no scan launches; k_emit<DEPTH> also keys every
+//                   pair with its splat's depth bits (GSWT_ORDER_DEPTH: the global radix depth sort)
+//   radix sort    : stable LSD sort of the pairs on the tile bits (reference order), preceded by passes on the depth bits in use with
+//                   the tile id as payload (depth order); k_mg_* : merged-group lists on the device
+//   k_items       : work items (tile, segment of its list: GSWT_OPT_SEGMENT pairs) from the per-tile [start, end) the last pass leaves
 //   k_composite   : front-to-back alpha compositing (fs_main gswt.wgsl:425-435 + blend/depth state
-//                   renderer.rs:118-129,179-185): LDS-staged batches, per-sub-block lists, wave ballot early termination
+//                   renderer.rs:118-129,179-185): LDS-staged batches, per-sub-block lists, wave ballot early termination;
+//                   k_composite_dw: the same with the four waves of an item decoupled; <FOLD>: folds the segment partials itself
 //   k_combine     : folds the segment partials of long tile lists; k_unshard : all-gathered shards -> frame
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off.  Contraction is OFF for the
@@ -1199,7 +1202,7 @@ constexpr uint32_t kSortWideMax = 0xFFFFFFFFu;  // pair capacities up to this us
 constexpr uint32_t kSupShift = 5;
 constexpr uint32_t kSupDirect = 32;             // up to this many groups the scatter kernel reads every group row instead of digit totals
 
-// Key range of the depth sort as k_depth_keys leaves it: [0] = ~smallest key, [1] = largest (both through atomicMax, so the frame's zeroed
+// Key range of the depth sort as k_emit<DEPTH> leaves it: [0] = ~smallest key, [1] = largest (both through atomicMax, so the frame's zeroed
 // scratch words are the neutral start); no keys at all reads as (0, 0).
 __device__ __forceinline__ void load_krange(const uint32_t* __restrict__ krange, uint32_t& kmin, uint32_t& kmax)
 {
