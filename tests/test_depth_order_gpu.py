@@ -134,3 +134,26 @@ def test_depth_sort_pass_count_follows_the_depth_range(renderer):
             assert np.array_equal(img, img_p), passes
     finally:
         renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 3)
+
+
+def test_depth_order_survives_a_pair_overflow_with_and_without_the_graph(renderer):
+    """The pair buffers (and in depth order the tile-id payload buffers beside them) grow when a frame outgrows them; the overflowed frame is
+    re-run by the fence / wait.  With the capacity pinned far below the frame's pair count the depth-ordered image must still be the
+    complete one, launch by launch and as a graph."""
+    s = _setup(renderer, "c1")
+    W, Hh = s["W"], s["H"]
+    want = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+    n_pairs = renderer.timings()["n_pairs"]
+    assert n_pairs > 10000
+    try:
+        for graph in (0, 1):
+            renderer.set_option(L.GSWT_OPT_GRAPH, graph)
+            renderer.set_option(L.GSWT_OPT_TIMING, 0 if graph else 2)
+            renderer.set_option(L.GSWT_OPT_PAIR_CAP, 256)         # the next frame overflows; the capacity then grows
+            img = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+            assert renderer.timings()["n_pairs"] == n_pairs
+            assert np.array_equal(img, want), graph
+    finally:
+        renderer.set_option(L.GSWT_OPT_PAIR_CAP, 0)
+        renderer.set_option(L.GSWT_OPT_GRAPH, 0)
+        renderer.set_option(L.GSWT_OPT_TIMING, 2)
