@@ -284,6 +284,7 @@ def main():
                     "gswt.wgsl:152-258 writes it; v2: the fma-chain / single-reciprocal rounding sequence (the default until round 3)")
     ap.add_argument("--composite", type=int, default=-1, help="GSWT_OPT_COMPOSITE: 0 k_composite + k_combine, 1 k_composite_dw (decoupled waves) + k_combine, "
                     "2 k_composite<FOLD> (no k_combine launch); default: the library's")
+    ap.add_argument("--depth-sort", type=int, default=0, help="GSWT_OPT_DEPTH_SORT with --order depth: 0 auto, 1 global depth passes, 2 tile-local LDS sort")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU baseline: fly-path frames are rendered by the oracle until this much time has gone (at most 24 frames)")
     args = ap.parse_args()
     if args.timing_every <= 0:
@@ -332,6 +333,8 @@ def main():
     r.set_option(L.GSWT_OPT_STRICT_VS, 1 if args.vertex_stage == "strict" else 0)
     if args.composite >= 0:
         r.set_option(L.GSWT_OPT_COMPOSITE, args.composite)
+    if args.depth_sort:
+        r.set_option(L.GSWT_OPT_DEPTH_SORT, args.depth_sort)
     order_mode = L.GSWT_ORDER_DEPTH if args.order == "depth" else L.GSWT_ORDER_REFERENCE
     wang.upload_to(r)
     hmap = wang.height_map() if int(wang.user.surface_type) == 1 else None
@@ -737,6 +740,7 @@ def main():
                        "map": [2 * w["half"][0] + 1, 2 * w["half"][1] + 1],
                        "width": W, "height": H, "n_draws": int(last["n_draws"]), "n_instanced": int(last["n_instanced"]),
                        "n_visible": int(last["n_visible"]), "n_pairs_mean": int(P), "order": args.order,
+                       "depth_sort_frames_tile_local_global_longest_list": list(r.depth_stats()) if args.order == "depth" else None,
                        "vertex_stage": "strict (gswt.wgsl:152-258 operator by operator; the default)" if args.vertex_stage == "strict" else "rounding sequence v2 (GSWT_OPT_STRICT_VS = 0)",
                        "transmittance_eps": args.t_eps, "skybox_proxy_passes": bool(use_passes),
                        "parallelism": (f"screen-tile-column bands x{world} (projection culled per band) + RCCL all-gather; no hardware 1 -> N curve has been "

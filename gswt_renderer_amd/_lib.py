@@ -34,6 +34,7 @@ GSWT_OPT_GRAPH = 9
 GSWT_OPT_STRICT_VS = 10
 GSWT_OPT_DEPTH_PASSES = 12
 GSWT_OPT_COMPOSITE = 13
+GSWT_OPT_DEPTH_SORT = 14
 GSWT_SHARD_ROWS = 0
 GSWT_SHARD_COLUMNS = 1
 
@@ -199,6 +200,7 @@ SYMBOLS = {
     "gswt_debug_read_projected": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gswt_debug_read_ranges": (C.c_int, [_P, _P, C.c_size_t, C.POINTER(C.c_size_t)]),
     "gswt_debug_frame_times": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "gswt_debug_depth_stats": (C.c_int, [_P, C.POINTER(C.c_ulonglong)]),
     "gswt_debug_merge_stats": (C.c_int, [_P, _P]),
     "gswt_debug_merge_stats_deep": (C.c_int, [_P, _P]),
     "gswt_debug_totals": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),

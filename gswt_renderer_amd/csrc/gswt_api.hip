@@ -45,7 +45,9 @@ void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr,
                 const uint32_t* = nullptr, uint32_t* = nullptr, uint32_t* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t, uint32_t*);
+                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t, uint32_t*, bool);
+void launch_tile_depth_sort(hipStream_t, const uint2*, uint32_t*, const uint32_t*, const uint32_t*, int, unsigned long long*);
+uint32_t tile_depth_sort_cap();
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
 void launch_proxy(hipStream_t, const ProxyArgs&, const float*, const float4*, float4*, float*);
@@ -244,6 +246,7 @@ struct FrameSlot {
     DevBuf<uint32_t> aux_a, aux_b;         // GSWT_ORDER_DEPTH: the pairs' tile ids, carried through the depth passes as the sort's payload
     bool strict_vs = false;                // GSWT_OPT_STRICT_VS as it stood when the frame was submitted (a re-run keeps it)
     uint32_t depth_passes = 0;             // GSWT_ORDER_DEPTH: radix passes this frame's depth sort was launched with
+    bool depth_local = false;              // ... or the tile-local depth sort (k_tile_depth_sort)
     DevBuf<float4> partials;
     DevBuf<float4> col_f;                  // debug draw modes: float colours per slot
     DevBuf<float> depths;                  // per-slot depth: frames with a proxy depth buffer or GSWT_ORDER_DEPTH only
@@ -328,6 +331,12 @@ struct gswt_ctx {
     // ulps: three).  A frame that needs more is flagged on the device and re-run; 32 frames in a row that need fewer give one back.
     uint32_t depth_passes = 3;
     uint32_t depth_passes_low_run = 0, depth_passes_low_max = 0;
+    // ... or, while every screen tile's pair list fits k_tile_depth_sort's LDS buffer, the tile-local path: tile passes first (depth bits as
+    // payload), then one kernel that depth-sorts each tile's slice in LDS.  GSWT_OPT_DEPTH_SORT: 0 = by the longest tile list the recent
+    // frames reported (k_items), 1 = always the global passes, 2 = always tile-local (a frame with a longer list falls back by re-run).
+    int opt_depth_sort = 0;
+    uint32_t depth_max_tile_len = 0;       // longest tile list of the last finished depth-ordered frame (0: none yet -- try tile-local)
+    unsigned long long stat_depth_local = 0, stat_depth_global = 0;     // depth-ordered frames enqueued on either path (re-runs included)
     int last_slot = 0;
     DevBuf<float4> bg_rgba, out_img;
     DevBuf<float> bg_depth;
@@ -632,6 +641,10 @@ try {
     case GSWT_OPT_COMPOSITE:
         if (value < 0 || value > 2) return fail(c, GSWT_ERR_BAD_ARG, "unknown compositor variant %d", value);
         c->opt_composite = value; return GSWT_OK;
+    case GSWT_OPT_DEPTH_SORT:
+        if (value < 0 || value > 2) return fail(c, GSWT_ERR_BAD_ARG, "GSWT_OPT_DEPTH_SORT: 0 (auto), 1 (global passes) or 2 (tile-local)");
+        c->opt_depth_sort = value; c->depth_max_tile_len = 0;
+        return GSWT_OK;
     case GSWT_OPT_DEPTH_PASSES:
         if (value < 1 || value > 4) return fail(c, GSWT_ERR_BAD_ARG, "depth-sort passes must be 1..4");
         c->depth_passes = (uint32_t)value; c->depth_passes_low_run = 0;
@@ -1384,11 +1397,14 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // GSWT_ORDER_DEPTH: the pair list is sorted on the depth bits first, with as many 8-bit passes as the key ranges of the recent frames
     // needed (k_items flags a frame that needs more: finish_frame re-runs it); the tile ids travel as the payload of those passes
     sl.depth_passes = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->depth_passes, 1u), 4u) : 0u;
-    const int depth_bits = 8 * (int)sl.depth_passes;
+    // a re-run after the tile-local path flagged a list that does not fit takes the global passes (finish_frame raised depth_max_tile_len)
+    sl.depth_local = depth_order && c->opt_depth_sort != 1 && c->depth_max_tile_len <= tile_depth_sort_cap();
+    const int depth_bits = sl.depth_local ? 0 : 8 * (int)sl.depth_passes;
+    if (depth_order) (sl.depth_local ? c->stat_depth_local : c->stat_depth_global)++;
     if (depth_order) { HIP_TRY(c, sl.aux_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.aux_b.ensure_roomy((size_t)cap + 1)); }
     // radix workspaces: per sort the zeroed part (group rows, digit totals) in front of its per-workgroup rows (written in full)
-    const size_t rz_pair = radix_ws_zero_words(cap, key_bits), rz_depth = depth_order ? radix_ws_zero_words(cap, depth_bits) : 0;
-    const size_t rw_pair = radix_ws_words(cap, key_bits), rw_depth = depth_order ? radix_ws_words(cap, depth_bits) : 0;
+    const size_t rz_pair = radix_ws_zero_words(cap, key_bits), rz_depth = depth_bits ? radix_ws_zero_words(cap, depth_bits) : 0;
+    const size_t rw_pair = radix_ws_words(cap, key_bits), rw_depth = depth_bits ? radix_ws_words(cap, depth_bits) : 0;
     // one contiguous u32 region whose head k_cull clears: [counters: 16][super_sums: n_super2][pair sort: zeroed part .. rows][depth sort likewise]
     HIP_TRY(c, sl.ghist.ensure_roomy(16 + n_super2 + rw_pair + rw_depth + 16));
     uint32_t* const zero_a = sl.ghist.p;
@@ -1448,6 +1464,14 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p);
         vals_sorted = where ? sl.vals_b.p : sl.vals_a.p;
+    } else if (sl.depth_local) {
+        // tile-local path: tile ids are the sort key, the depth bits its payload; then every tile's slice is depth-sorted in LDS
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, sl.depths.p, sl.aux_a.p, d_krange);
+        if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
+        const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p, nullptr, sl.aux_a.p, sl.aux_b.p);
+        uint32_t* const vals_t = where ? sl.vals_b.p : sl.vals_a.p;
+        launch_tile_depth_sort(s, sl.ranges.p, vals_t, where ? sl.aux_b.p : sl.aux_a.p, d_krange, n_tiles, d_counters);
+        vals_sorted = vals_t;
     } else {
         launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.aux_a.p, sl.vals_a.p, sl.depths.p, sl.keys_a.p, d_krange);
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
@@ -1465,7 +1489,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // ---- composite
     launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.depths.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
                      sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr,
-                     d_counters, sl.hc_dev, c->opt_composite, depth_order ? d_krange : nullptr, sl.depth_passes, d_tile_tick);
+                     d_counters, sl.hc_dev, c->opt_composite, depth_order && !sl.depth_local ? d_krange : nullptr, sl.depth_passes, d_tile_tick, depth_order);
     c->last_n_tiles = (uint32_t)n_tiles;
     c->last_slot = (int)(&sl - c->slots);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));
@@ -1494,8 +1518,12 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
         if (attempt >= 2) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");
         if (P64 > sl.cap || sl.args.cfg.order_mode != GSWT_ORDER_DEPTH)
             c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 2 + 4096, 0xFFFFFF00ull));
-        if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH && sl.hc[2] > sl.depth_passes) {
-            c->depth_passes = (uint32_t)std::min<unsigned long long>(sl.hc[2], 4ull); c->depth_passes_low_run = 0;
+        if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH) {
+            const uint32_t need = (uint32_t)(sl.hc[2] & 0xFFFFFFFFull), max_len = (uint32_t)(sl.hc[2] >> 32);
+            if (!sl.depth_local && need > sl.depth_passes) { c->depth_passes = std::min<uint32_t>(need, 4u); c->depth_passes_low_run = 0; }
+            // the tile-local depth sort met a list longer than its LDS buffer: the re-run takes the global passes (k_items may not have
+            // seen the whole frame's lengths yet when the flag was raised, so at least cap + 1)
+            if (sl.depth_local) c->depth_max_tile_len = std::max<uint32_t>(std::max<uint32_t>(max_len, c->depth_max_tile_len), tile_depth_sort_cap() + 1u);
         }
         int rc = enqueue_frame(c, sl);
         if (rc != GSWT_OK) return rc;
@@ -1504,8 +1532,10 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
     // keep 25-50 % headroom over the running pair count without shrinking on every small dip
     if (!c->opt_fixed_pair_cap && (uint64_t)P + P / 4 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 2 + 4096, 0xFFFFFF00ull);
     if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH) {
-        const uint32_t need = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>(sl.hc[2], 1ull), 4ull);
-        if (need < c->depth_passes && sl.depth_passes == c->depth_passes) {
+        const uint32_t need = std::min<uint32_t>(std::max<uint32_t>((uint32_t)(sl.hc[2] & 0xFFFFFFFFull), 1u), 4u);
+        c->depth_max_tile_len = (uint32_t)(sl.hc[2] >> 32);        // (every depth-ordered frame reports it: the next one picks its path by it)
+        if (sl.depth_local) { /* the pass count is the kernel's own business there */ }
+        else if (need < c->depth_passes && sl.depth_passes == c->depth_passes) {
             c->depth_passes_low_max = c->depth_passes_low_run ? std::max(c->depth_passes_low_max, need) : need;
             if (++c->depth_passes_low_run >= 32u) { c->depth_passes = c->depth_passes_low_max; c->depth_passes_low_run = 0; }
         } else if (need >= c->depth_passes) c->depth_passes_low_run = 0;
@@ -1969,6 +1999,13 @@ int gswt_debug_graph_stats(const gswt_ctx* c, unsigned long long out[3])
     out[0] = c->stat_graph_launches; out[1] = c->stat_graph_rebuilds; out[2] = c->stat_graph_node_updates;
     return GSWT_OK;
 }
+
+int gswt_debug_depth_stats(const gswt_ctx* c, unsigned long long out[3])
+try {
+    if (!c || !out) return GSWT_ERR_BAD_ARG;
+    out[0] = c->stat_depth_local; out[1] = c->stat_depth_global; out[2] = c->depth_max_tile_len;
+    return GSWT_OK;
+} GSWT_CATCH("gswt_debug_depth_stats")
 
 int gswt_debug_merge_stats(const gswt_ctx* c, unsigned long long out[2])
 {

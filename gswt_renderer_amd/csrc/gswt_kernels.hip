@@ -1624,6 +1624,103 @@ __global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ j
 // k_ranges, read the sorted keys back for it: 5 us + a launch at c3, 18 us at c5.)
 // ------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------
+// k_tile_depth_sort -- GSWT_ORDER_DEPTH, the tile-local path: the pair list has been sorted on the tile bits with each pair's depth bits as
+// the payload; one workgroup per screen tile now sorts that tile's slice by depth INSIDE LDS -- a stable LSD radix sort on the bits of
+// (depth key - the frame's smallest), all passes back to back (three at c3) -- and writes the slots back in place.  Inside a tile: true
+// depth order, equal depths in composite order: bit for bit what the global depth passes in front of the tile sort produce, without their
+// three trips through HBM, their histogram kernels and their launches (c3: 3 x 27.8 us -> one kernel).  The ranking is k_radix_scatter's:
+// each wave owns 1 024 consecutive items, ranks them 64 at a time with ballot match-any (in-wave order = list order), per-wave digit
+// counters in LDS, one exclusive scan over (digit, wave).  A list longer than the LDS buffer (kTileSortCap pairs) cannot be sorted here:
+// the workgroup flags the frame, the host re-runs it with the global passes and keeps them while k_items reports lists that long.
+// ------------------------------------------------------------------------------------
+constexpr uint32_t kTileSortCap = 8192u;
+__global__ __launch_bounds__(512) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ vals, const uint32_t* __restrict__ dkeys,
+                                                         const uint32_t* __restrict__ krange, unsigned long long* __restrict__ counters)
+{
+    constexpr int kItems = (int)(kTileSortCap / 512u);            // 16 per thread: wave w owns items [1024 w, 1024 w + 1024)
+    __shared__ uint2 s_kv[kTileSortCap];
+    __shared__ uint32_t s_h[8][256];
+    __shared__ uint32_t s_w[4];
+    const uint2 rg = ranges[blockIdx.x];                          // (~start, end); (0, 0): no pairs
+    if (rg.y == 0u) return;
+    const uint32_t start = ~rg.x, n = rg.y - start;
+    if (n <= 1u) return;
+    if (n > kTileSortCap) { if (threadIdx.x == 0u) counters[3] = 1ull; return; }
+    uint32_t kmin, kmax;
+    load_krange(krange, kmin, kmax);
+    const uint32_t need = sort_passes_needed(krange);
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, base_w = w * (64u * (uint32_t)kItems);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t key[kItems], val[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {                            // clamped, unmasked loads
+        const uint32_t i = min(base_w + (uint32_t)k * 64u + lane, n - 1u);
+        key[k] = dkeys[start + i] - kmin;
+        val[k] = vals[start + i];
+    }
+    for (uint32_t p = 0; p < need; p++) {
+        const uint32_t shift = 8u * p;
+        for (uint32_t q = threadIdx.x; q < 8u * 256u; q += 512u) (&s_h[0][0])[q] = 0u;
+        __syncthreads();
+        unsigned long long pm[kItems];
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {
+            pm[k] = 0ull;
+            if (base_w + (uint32_t)k * 64u >= n) continue;        // wave-uniform: this round holds no item
+            const bool valid = base_w + (uint32_t)k * 64u + lane < n;
+            const uint32_t dgt = (key[k] >> shift) & 255u;
+            const unsigned long long peers = match_digit(dgt, valid, 8u);
+            pm[k] = peers;
+            if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+        }
+        __syncthreads();
+        // exclusive scan over (digit, wave): thread d < 256 owns digit d
+        uint32_t cnt[8], tot = 0, inc = 0;
+        const bool dig = threadIdx.x < 256u;
+        const uint32_t d = threadIdx.x & 255u;
+        if (dig) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) { cnt[q] = s_h[q][d]; tot += cnt[q]; }
+            inc = wave_incl_scan(tot, lane);
+            if (lane == 63u) s_w[w] = inc;
+        }
+        __syncthreads();
+        if (dig) {
+            uint32_t b = inc - tot;
+            for (uint32_t q = 0; q < w; q++) b += s_w[q];
+#pragma unroll
+            for (int q = 0; q < 8; q++) { s_h[q][d] = b; b += cnt[q]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {
+            if (base_w + (uint32_t)k * 64u >= n) continue;
+            const bool valid = base_w + (uint32_t)k * 64u + lane < n;
+            const uint32_t dgt = valid ? (key[k] >> shift) & 255u : 0u;
+            const unsigned long long peers = pm[k];
+            const uint32_t rank = (uint32_t)__popcll(peers & lt);
+            uint32_t pos = 0;
+            if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+            const int leader = valid ? (int)__ffsll((long long)peers) - 1 : (int)lane;
+            pos = (uint32_t)__shfl((int)pos, leader, 64);
+            if (valid) s_kv[pos + rank] = make_uint2(key[k], val[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kItems; k++) {                        // back into list order for the next pass (and the write-back)
+            const uint32_t i = base_w + (uint32_t)k * 64u + lane;
+            if (i < n) { const uint2 kv = s_kv[i]; key[k] = kv.x; val[k] = kv.y; }
+        }
+        // (the next pass's first barrier, behind the clearing of s_h, also orders these reads before its writes to s_kv)
+    }
+#pragma unroll
+    for (int k = 0; k < kItems; k++) {
+        const uint32_t i = base_w + (uint32_t)k * 64u + lane;
+        if (i < n) vals[start + i] = val[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_composite: one workgroup (4 wave64) per work item = (16x16 screen tile, segment of its pair list).
 // Wave w owns the 16x4 pixel strip of rows 4w .. 4w+3; inside a wave the four 16-lane groups own the
 // four 4x4 sub-blocks of that strip and walk DIFFERENT splats concurrently (the c3 scene averages ~9 covered
@@ -1646,13 +1743,13 @@ __global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ j
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
                                                 uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items,
                                                 const uint32_t* __restrict__ krange, uint32_t n_launched, unsigned long long* __restrict__ counters,
-                                                uint32_t all_tiles)
+                                                uint32_t all_tiles, uint32_t report_max)
 {
     // all_tiles (GSWT_OPT_FOLD_COMBINE): a tile without pairs gets one EMPTY work item -- k_composite then writes its background, and no
     // k_combine launch follows the compositor
     if (krange && blockIdx.x == 0u && threadIdx.x == 0u) {
         const uint32_t need = sort_passes_needed(krange);
-        counters[2] = need;
+        *reinterpret_cast<uint32_t*>(counters + 2) = need;                   // (the low half: the high one takes the longest tile list)
         if (need > n_launched) counters[3] = 1ull;
     }
     // One workgroup per 8192 tiles (c3: one workgroup, c5: four).  Thread t owns tiles base + j * 1024 + t, j = 0..7: every
@@ -1692,6 +1789,15 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
         if (lane == 63u) s_carry[w] = pi;
         __syncthreads();
         for (uint32_t i = 0; i < 16u; i++) carry += s_carry[i];
+    }
+    if (report_max) {
+        // GSWT_ORDER_DEPTH: the longest tile list of the frame -> high half of counters[2]: the host picks the tile-local depth sort (lists that
+        // fit its LDS buffer) or the global depth passes for the next frames by it
+        uint32_t mx = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) mx = max(mx, base + j * 1024 + (int)threadIdx.x < n_tiles ? r[j].y - r[j].x : 0u);
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, o, 64));
+        if (lane == 0u && mx) atomicMax(reinterpret_cast<uint32_t*>(counters + 2) + 1, mx);        // <= 16 per workgroup, <= 4 workgroups
     }
     uint32_t cnt[kPer], inc[kPer];
 #pragma unroll
@@ -2655,13 +2761,22 @@ void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks
 
 // `ranges` must be zero on entry (k_cull clears it each frame)
 
+// GSWT_ORDER_DEPTH, tile-local path: depth-sorts every screen tile's slice of the (tile-sorted) pair list in LDS; dkeys = the pairs' depth
+// bits in the same order (the tile sort's payload)
+void launch_tile_depth_sort(hipStream_t s, const uint2* ranges, uint32_t* vals, const uint32_t* dkeys, const uint32_t* krange, int n_tiles,
+                            unsigned long long* counters)
+{
+    if (n_tiles > 0) GSWT_LAUNCH(k_tile_depth_sort, dim3((uint32_t)n_tiles), dim3(512), s, ranges, vals, dkeys, krange, counters);
+}
+uint32_t tile_depth_sort_cap() { return kTileSortCap; }
+
 // ranges -> per-tile segment counts -> item_base (exclusive scan, item_base[n_tiles] = #items) ->
 // k_composite over an upper bound of items -> k_combine.
 void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const uint32_t* vals, const Rec* recs, const float* depths,
                       const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
                       hipEvent_t ev_begin, hipEvent_t ev_end, unsigned long long* counters, unsigned long long* host_counters, int variant,
-                      const uint32_t* krange, uint32_t depth_passes, uint32_t* tile_tick)
+                      const uint32_t* krange, uint32_t depth_passes, uint32_t* tile_tick, bool report_max)
 {
     if (n_tiles == 0) {                 // a shard without screen tiles (more ranks than tile columns): the events still exist
         if (ev_begin) hipEventRecord(ev_begin, s);
@@ -2672,7 +2787,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     // variant 2 (GSWT_OPT_FOLD_COMBINE): k_composite folds the segment partials itself and writes the empty tiles: no k_combine launch
     const bool fold = variant == 2 && tile_tick != nullptr && host_counters != nullptr;
     GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items, krange, depth_passes, counters,
-                fold ? 1u : 0u);
+                fold ? 1u : 0u, report_max ? 1u : 0u);
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
 #ifdef GSWT_EXPERIMENTS

@@ -312,6 +312,12 @@ class GSWTRenderer:
         self._check(self._lib.gswt_debug_read_projected(self._h, _ptr(out), out.shape[0], C.byref(n)))
         return out[:n.value]
 
+    def depth_stats(self):
+        """GSWT_ORDER_DEPTH: (frames on the tile-local path, frames on the global depth passes, longest tile list of the last depth-ordered frame)."""
+        a = (C.c_ulonglong * 3)()
+        self._check(self._lib.gswt_debug_depth_stats(self._h, a))
+        return int(a[0]), int(a[1]), int(a[2])
+
     def frame_times(self, ticket_ref: int, ticket: int):
         """(start, end, gather end) of slot `ticket`'s frame in ms after the start of slot `ticket_ref`'s frame (device timeline)."""
         out = (C.c_float * 3)()

@@ -200,7 +200,11 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                   batch; 1 k_composite_dw -- the four waves of a work item decoupled (128-pair batches through a ring of three LDS
                                   buffers, ready / consumed counters instead of barriers); 2 k_composite<FOLD> -- the segments of a long tile list
                                   are folded by whichever of their workgroups finishes last (agent-scope stores + a ticket per tile), tiles
-                                  without pairs are work items: no k_combine launch behind the compositor.  Same image bit for bit */ };
+                                  without pairs are work items: no k_combine launch behind the compositor.  Same image bit for bit */,
+       GSWT_OPT_DEPTH_SORT = 14 /* how GSWT_ORDER_DEPTH orders the pairs: 1 = global radix passes on the depth bits in front of the tile passes;
+                                   2 = tile passes first (depth bits as payload), then every screen tile's slice is depth-sorted inside LDS by
+                                   one workgroup (lists up to 8 192 pairs; a frame with a longer one is re-run with the global passes);
+                                   0 (default) = 2 while the longest tile list the recent frames reported fits, else 1.  Same image bit for bit */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data
@@ -508,6 +512,9 @@ GSWT_API int gswt_debug_merge_stats_deep(const gswt_ctx *ctx, unsigned long long
 /* Test / profiling hook: [start, end) of every screen tile in the sorted pair list of the last
  * gswt_render (2 u32 per tile, shard-local tile order). Host pointer. */
 GSWT_API int gswt_debug_read_ranges(gswt_ctx *ctx, uint32_t *out, size_t capacity_tiles, size_t *n_tiles);
+/* GSWT_ORDER_DEPTH bookkeeping: out[0] = frames enqueued on the tile-local path (k_tile_depth_sort), [1] = on the global depth passes
+ * (re-runs count), [2] = the longest screen-tile pair list of the last finished depth-ordered frame. */
+GSWT_API int gswt_debug_depth_stats(const gswt_ctx *ctx, unsigned long long out[3]);
 /* Device timeline of two frame slots (tests of the frame / gather overlap): out_ms[0] = start of slot `ticket`'s frame kernels, [1] = their
  * end, [2] = end of its gather + re-assembly (NaN if it was not gathered), in ms after the START of slot `ticket_ref`'s frame.  Both frames
  * submitted with GSWT_OPT_TIMING >= 1 and complete (the call synchronises). */

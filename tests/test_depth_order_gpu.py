@@ -46,6 +46,25 @@ def test_depth_order_at_baseline_size(renderer, name):
     # what bench.py --order depth times: the early-out at 1e-5
     img_e = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH, transmittance_eps=1e-5)
     assert H.max_abs_diff(img_e, ref_d) <= TOL
+    # the two ways to get there -- global radix passes on the depth bits in front of the tile passes, or tile passes first and every tile's
+    # slice depth-sorted in LDS (lists up to 8 192 pairs; the dense c3d has longer ones and falls back) -- give the same bits
+    try:
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 1)
+        l0, g0, _ = renderer.depth_stats()
+        img_g = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+        l1, g1, max_len = renderer.depth_stats()
+        assert (l1 - l0, g1 - g0) == (0, 1) and max_len > 256
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 2)
+        img_l = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+        l2, g2, _ = renderer.depth_stats()
+        print(f"{name}: longest tile list {max_len} pairs; tile-local frames {l2 - l1}, global {g2 - g1}")
+        if max_len <= 8192:
+            assert (l2 - l1, g2 - g1) == (1, 0)
+        else:
+            assert (l2 - l1, g2 - g1) == (1, 1)               # tried, flagged on the device, re-run with the global passes
+        assert np.array_equal(img_g, img) and np.array_equal(img_l, img)
+    finally:
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 0)
     # the mode is not a no-op: neighbouring Wang tiles interpenetrate, and a tile's presorted list is only ordered along one of nine
     # directions, so the reference order and the true depth order give different images
     d = H.max_abs_diff(ref_d, ref_r)
