@@ -331,9 +331,9 @@ struct gswt_ctx {
     // ulps: three).  A frame that needs more is flagged on the device and re-run; 32 frames in a row that need fewer give one back.
     uint32_t depth_passes = 3;
     uint32_t depth_passes_low_run = 0, depth_passes_low_max = 0;
-    // ... or, while every screen tile's pair list fits k_tile_depth_sort's LDS buffer, the tile-local path: tile passes first (depth bits as
-    // payload), then one kernel that depth-sorts each tile's slice in LDS.  GSWT_OPT_DEPTH_SORT: 0 = by the longest tile list the recent
-    // frames reported (k_items), 1 = always the global passes, 2 = always tile-local (a frame with a longer list falls back by re-run).
+    // ... or the tile-local path: tile passes first (depth bits as payload), then one kernel that depth-sorts each tile's slice in LDS.
+    // GSWT_OPT_DEPTH_SORT: 0 / 1 = the global passes (the default: faster at every size measured), 2 = tile-local while every screen tile's
+    // list fits k_tile_depth_sort's LDS buffer (k_items reports the longest; a frame that meets a longer one falls back by re-run).
     int opt_depth_sort = 0;
     uint32_t depth_max_tile_len = 0;       // longest tile list of the last finished depth-ordered frame (0: none yet -- try tile-local)
     unsigned long long stat_depth_local = 0, stat_depth_global = 0;     // depth-ordered frames enqueued on either path (re-runs included)
@@ -1398,7 +1398,9 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // needed (k_items flags a frame that needs more: finish_frame re-runs it); the tile ids travel as the payload of those passes
     sl.depth_passes = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->depth_passes, 1u), 4u) : 0u;
     // a re-run after the tile-local path flagged a list that does not fit takes the global passes (finish_frame raised depth_max_tile_len)
-    sl.depth_local = depth_order && c->opt_depth_sort != 1 && c->depth_max_tile_len <= tile_depth_sort_cap();
+    // (measured at c3: k_tile_depth_sort 115 us against 3 x 27.8 us for the global passes -- the longest list's workgroup IS the kernel --, so
+    // the tile-local path runs only when asked for: GSWT_OPT_DEPTH_SORT = 2)
+    sl.depth_local = depth_order && c->opt_depth_sort == 2 && c->depth_max_tile_len <= tile_depth_sort_cap();
     const int depth_bits = sl.depth_local ? 0 : 8 * (int)sl.depth_passes;
     if (depth_order) (sl.depth_local ? c->stat_depth_local : c->stat_depth_global)++;
     if (depth_order) { HIP_TRY(c, sl.aux_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.aux_b.ensure_roomy((size_t)cap + 1)); }

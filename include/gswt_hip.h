@@ -201,10 +201,10 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                   buffers, ready / consumed counters instead of barriers); 2 k_composite<FOLD> -- the segments of a long tile list
                                   are folded by whichever of their workgroups finishes last (agent-scope stores + a ticket per tile), tiles
                                   without pairs are work items: no k_combine launch behind the compositor.  Same image bit for bit */,
-       GSWT_OPT_DEPTH_SORT = 14 /* how GSWT_ORDER_DEPTH orders the pairs: 1 = global radix passes on the depth bits in front of the tile passes;
-                                   2 = tile passes first (depth bits as payload), then every screen tile's slice is depth-sorted inside LDS by
-                                   one workgroup (lists up to 8 192 pairs; a frame with a longer one is re-run with the global passes);
-                                   0 (default) = 2 while the longest tile list the recent frames reported fits, else 1.  Same image bit for bit */ };
+       GSWT_OPT_DEPTH_SORT = 14 /* how GSWT_ORDER_DEPTH orders the pairs: 0 / 1 (default) = global radix passes on the depth bits in front of the
+                                   tile passes; 2 = tile passes first (depth bits as payload), then every screen tile's slice is depth-sorted
+                                   inside LDS by one workgroup (lists up to 8 192 pairs; a frame with a longer one is re-run with the global
+                                   passes).  Same image bit for bit; measured slower than the global passes */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

@@ -46,8 +46,9 @@ def test_depth_order_at_baseline_size(renderer, name):
     # what bench.py --order depth times: the early-out at 1e-5
     img_e = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH, transmittance_eps=1e-5)
     assert H.max_abs_diff(img_e, ref_d) <= TOL
-    # the two ways to get there -- global radix passes on the depth bits in front of the tile passes, or tile passes first and every tile's
-    # slice depth-sorted in LDS (lists up to 8 192 pairs; the dense c3d has longer ones and falls back) -- give the same bits
+    # the two ways to get there -- global radix passes on the depth bits in front of the tile passes (the default), or tile passes first and
+    # every tile's slice depth-sorted in LDS (GSWT_OPT_DEPTH_SORT = 2: lists up to 8 192 pairs; the dense c3d has longer ones and falls
+    # back) -- give the same bits
     try:
         renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 1)
         l0, g0, _ = renderer.depth_stats()
