@@ -288,7 +288,14 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU baseline: fly-path frames are rendered by the oracle until this much time has gone (at most 24 frames)")
     args = ap.parse_args()
     if args.timing_every <= 0:
-        args.timing_every = 2 if args.steps < 64 else 3       # 0 = auto: short runs time every other frame (10 samples in the driver's 20 steps; the frames between them can go through GSWT_OPT_GRAPH); 3 is coprime with the 4 frame slots, so every slot is sampled
+        # 0 = auto.  Every third frame of a long run carries hipEvents (3 is coprime with the five frame slots: every slot is sampled).  A short
+        # fly-path run on one GPU (the driver's --steps 20) carries NONE inside its timed region: ten samples, two per slot, were never a
+        # measurement, the frames that carried them cost the submitting thread 52 us instead of 34 (4 190-4 350 against
+        # 4 500-4 570 frames/s, three runs each), and the roofline figures come from the 480-frame steady loop timed right behind the region
+        # (roofline.kernel_ms_source).  Other short runs (static camera, N > 1: no steady loop follows) time every other frame.
+        short_with_steady = args.steps < 64 and args.mode == "flypath" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.freeze_sort \
+            and int(os.environ.get("GSWT_BENCH_FAKE_WORLD", "0")) <= 1
+        args.timing_every = (1 << 30) if short_with_steady else (2 if args.steps < 64 else 3)
 
     # Only the final JSON line may reach stdout (RCCL prints a version banner there): park the real stdout and point
     # fd 1 at stderr for the rest of the run.
@@ -764,7 +771,7 @@ def main():
                          "valu_issue_frac": valu["valu_issue_frac"] if valu else None,
                          "traffic_source": (f"profiles/{os.path.basename(pmc_path)} (committed PMC passes: NOT measured in this run)" if traffic is not None else None),
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "kernel_ms_min_slot": comp * 1e3, "kernel_ms": comp * 1e3, "kernel_ms_samples": len(by_slot.get(best_slot, st["comp_ms"])), "timed_every": max(1, args.timing_every),
+                         "kernel_ms_min_slot": comp * 1e3, "kernel_ms": comp * 1e3, "kernel_ms_samples": len(by_slot.get(best_slot, st["comp_ms"])), "timed_every": (None if args.timing_every >= (1 << 30) else max(1, args.timing_every)),
                          "kernel_ms_by_slot": {str(k): round(v, 5) for k, v in slot_means.items()}, "kernel_ms_slot": best_slot, "kernel_ms_all_slots": comp_all * 1e3,
                          "frac_all_slots": achieved_all / HBM_PEAK_GBS,
                          "frac_note": "`achieved` / `frac` use kernel_ms_min_slot: the hipEvent bracket of the frame slot whose stream has a hardware queue of its own (the other "
