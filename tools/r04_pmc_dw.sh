@@ -5,7 +5,7 @@ WL=${1:-c3}
 export TMPDIR=/tmp
 O=gpurun_out/pmc_dw_$WL; mkdir -p $O
 for CV in 0 1; do
-  export GSWT_COMPOSITE=$CV
+  export GSWT_COMPOSITE=$CV; mkdir -p $O/v$CV
   for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_TRANS_F32"; do
     D=$O/v$CV/$(echo $C | tr ' ' '_')
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python3 tools/serial_frames.py $WL 8 > $D.log 2>&1 || tail -2 $D.log
