@@ -35,6 +35,7 @@ GSWT_OPT_STRICT_VS = 10
 GSWT_OPT_DEPTH_PASSES = 12
 GSWT_OPT_COMPOSITE = 13
 GSWT_OPT_DEPTH_SORT = 14
+GSWT_OPT_NO_CHUNK_CULL = 15
 GSWT_SHARD_ROWS = 0
 GSWT_SHARD_COLUMNS = 1
 

@@ -29,7 +29,7 @@
 
 namespace gswt {
 void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t,
-                 uint32_t*, uint4*, uint32_t*, uint32_t);
+                 uint32_t*, uint4*, uint32_t*, uint32_t, const uint2*, uint32_t, const float*, bool);
 void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const MergeSources&, uint32_t*, uint32_t*);
 void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
@@ -87,7 +87,8 @@ struct DevBuf {
     void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
 };
 
-struct ListRef { uint32_t pair_base, pair_count, self_base, self_count; };
+// (pair_box / self_box: first chunk box of the list in static_boxes; chunk k = the k-th 256 entries from the END of the list, as k_project walks it)
+struct ListRef { uint32_t pair_base, pair_count, self_base, self_count, pair_box, self_box; };
 
 // Behind synchronous copies whose data the frames read: the frame slots' streams are non-blocking, i.e. not ordered behind the
 // null stream, and a synchronous copy from pageable memory may return once the data is staged.  Setup paths only.
@@ -283,6 +284,7 @@ struct gswt_ctx {
     size_t n_splats = 0;
     float loc_lo[3] = {}, loc_hi[3] = {}, loc_max_trace = 0.0f;      // tile-local bounds of the splat centres, largest covariance trace
     DevBuf<uint32_t> static_list;
+    DevBuf<float> static_boxes;            // tile-local bounding box (lo.xyz, hi.xyz) of every 256-entry chunk of every static list (k_live's chunk cull)
     std::vector<ListRef> lists;
     int n_lod = 0, n_tile = 0, n_view = 0;
     bool scene_ready = false;
@@ -313,6 +315,7 @@ struct gswt_ctx {
     // GSWT_OPT_COMPOSITE: 0 = k_composite + k_combine, 1 = k_composite_dw (decoupled waves) + k_combine, 2 = k_composite<FOLD>: the last
     // segment of a tile to finish folds the partials, empty tiles are work items, no k_combine launch
     int opt_composite = 0;
+    int opt_no_chunk_cull = 0;             // GSWT_OPT_NO_CHUNK_CULL: k_live keeps every chunk of a surviving draw (A/B and tests: same image)
     unsigned long long stat_graph_launches = 0, stat_graph_rebuilds = 0, stat_graph_node_updates = 0;
     int pending_frames = 0;                // GSWT_OPT_DEFER_SWAP >= 2: frames still to be submitted on the old set
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled
@@ -589,7 +592,7 @@ void gswt_destroy(gswt_ctx* c)
     if (c->ev_push) hipEventDestroy(c->ev_push);
     if (c->ev_unshard) hipEventDestroy(c->ev_unshard);
     c->gather_buf.release();
-    c->tex.release(); c->static_list.release(); c->hmap.release(); for (auto& ds : c->sets) ds.release();
+    c->tex.release(); c->static_list.release(); c->static_boxes.release(); c->hmap.release(); for (auto& ds : c->sets) ds.release();
     c->raw_depth.release(); 
     c->mg_ws.release(); c->sky_faces.release(); c->proxy_tex.release(); c->bg_rgba.release(); c->out_img.release(); c->bg_depth.release(); c->dbg.release();
     for (auto& sl : c->slots) {
@@ -641,6 +644,7 @@ try {
     case GSWT_OPT_COMPOSITE:
         if (value < 0 || value > 2) return fail(c, GSWT_ERR_BAD_ARG, "unknown compositor variant %d", value);
         c->opt_composite = value; return GSWT_OK;
+    case GSWT_OPT_NO_CHUNK_CULL: c->opt_no_chunk_cull = value != 0; return GSWT_OK;
     case GSWT_OPT_DEPTH_SORT:
         if (value < 0 || value > 2) return fail(c, GSWT_ERR_BAD_ARG, "GSWT_OPT_DEPTH_SORT: 0 (auto), 1 (global passes) or 2 (tile-local)");
         c->opt_depth_sort = value; c->depth_max_tile_len = 0;
@@ -704,6 +708,28 @@ try {
     const size_t nl = (size_t)n_lod * n_tile * n_view;
     c->lists.assign(nl, ListRef{});
     std::vector<uint32_t> arena;
+    std::vector<float> boxes;               // six floats per chunk
+    // bounding box of every chunk of list [base, base + count): chunk k = entries count - 256 (k + 1) .. count - 256 k - 1 (k_project's order);
+    // a chunk that holds a non-finite position gets the infinite box (never culled)
+    auto add_boxes = [&](uint32_t base, uint32_t count) -> uint32_t {
+        const uint32_t first = (uint32_t)(boxes.size() / 6);
+        for (uint32_t k = 0; (size_t)k * kChunk < count; k++) {
+            const uint32_t hi_i = count - k * (uint32_t)kChunk, lo_i = hi_i > (uint32_t)kChunk ? hi_i - (uint32_t)kChunk : 0u;
+            float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+            bool odd = false;
+            for (uint32_t j = lo_i; j < hi_i; j++) {
+                float pq[3];
+                memcpy(pq, tex_data + 8 * (size_t)(arena[base + j] & kIdxMask), 12);
+                for (int a = 0; a < 3; a++) {
+                    if (!(pq[a] == pq[a]) || pq[a] > 3e38f || pq[a] < -3e38f) odd = true;
+                    lo[a] = std::min(lo[a], pq[a]); hi[a] = std::max(hi[a], pq[a]);
+                }
+            }
+            for (int a = 0; a < 3; a++) boxes.push_back(odd ? -__builtin_inff() : lo[a]);
+            for (int a = 0; a < 3; a++) boxes.push_back(odd ? __builtin_inff() : hi[a]);
+        }
+        return first;
+    };
     size_t total = 0;
     for (size_t i = 0; i < nl; i++) total += lists[i].splat_count;
     arena.reserve(2 * total);
@@ -723,11 +749,15 @@ try {
         for (uint32_t j = 0; j < L.splat_count; j++)
             if (L.gs_lod_id[j] == lod) arena.push_back(L.gs_index[j] | (lod << kLodShift));
         ref.self_count = (uint32_t)arena.size() - ref.self_base;
+        ref.pair_box = add_boxes(ref.pair_base, ref.pair_count);
+        ref.self_box = add_boxes(ref.self_base, ref.self_count);
         c->lists[i] = ref;
     }
     if (arena.size() >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_upload_scene: static lists exceed 2^32 entries");
     HIP_TRY(c, c->static_list.ensure(arena.size() + 1));
     HIP_TRY(c, hipMemcpy(c->static_list.p, arena.data(), arena.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, c->static_boxes.ensure(boxes.size() + 6));
+    if (!boxes.empty()) HIP_TRY(c, hipMemcpy(c->static_boxes.p, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, null_stream_done());
     c->n_lod = n_lod; c->n_tile = n_tile; c->n_view = n_view;
     c->scene_ready = true;
@@ -840,7 +870,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
             if (g.merged_has_lod && !merged_lod_id && !device_merge)
                 return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: draw %d needs merged_lod_id", i);
             if (g.tile.single_draw != 1u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: merged draw %d without single_draw", i);
-            d.merged = 1; d.list_base = g.merged_offset; d.count = g.merged_count;
+            d.merged = 1; d.list_base = g.merged_offset; d.count = g.merged_count; d.box_base = 0xFFFFFFFFu;
         } else {
             if (g.tile.single_draw == 1u) return fail(c, GSWT_ERR_BAD_ARG, "gswt_set_draws: single_draw on static draw %d", i);
             if ((int)g.base_lod >= c->n_lod || (int)g.base_tile >= c->n_tile || (int)g.base_view >= c->n_view)
@@ -851,6 +881,7 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
             d.merged = 0;
             d.list_base = prefilter ? L.self_base : L.pair_base;
             d.count = prefilter ? L.self_count : L.pair_count;
+            d.box_base = prefilter ? L.self_box : L.pair_box;
         }
         d.entry_base = (uint32_t)entries;
         entries += d.count;
@@ -1451,7 +1482,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     const size_t n_zero_a = 16 + n_super2 + rz_pair;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
                 reinterpret_cast<uint32_t*>(sl.ranges.p), ((uint32_t)n_tiles + 1u) * 2u + (uint32_t)n_tiles, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
-                d_radix_depth, (uint32_t)rz_depth);
+                d_radix_depth, (uint32_t)rz_depth, D.chunk_tab.p, D.n_chunks, c->static_boxes.p, c->opt_no_chunk_cull == 0 && !dbg);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p, sl.col_f.p, cap, sl.strict_vs);

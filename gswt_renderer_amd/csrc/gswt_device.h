@@ -34,6 +34,7 @@ struct DrawDev {
     uint32_t tile_idx;        // tile_id.y (debug draw mode 1)
     uint32_t tile_view;       // tile_id.z (debug draw mode 4)
     uint32_t map_coord[2];    // TileUniforms.map_coord (sphere surface)
+    uint32_t box_base;        // static draws: first chunk box of the draw's list (chunk k = the k-th 256 entries from the END of the list); ~0: none
 };
 
 // Per-frame constants (kernel argument, by value).

@@ -334,11 +334,9 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
                                               uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
                                               uint32_t* __restrict__ zero_b, uint32_t n_zero_b,
                                               uint32_t* __restrict__ zero_c, uint32_t n_zero_c,
-                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab,
                                               uint32_t* __restrict__ zero_d, uint32_t n_zero_d)
 {
-    // eight lanes per draw: all of them evaluate the (cheap) cull, lane 0 of the eight keeps the flag and allocates the draw's range
-    // of the live-chunk table, and the eight fill it together (a merged group has up to a few hundred chunks)
+    // eight lanes per draw (they used to fill the draw's range of the live-chunk table together; k_live builds that table now, chunk by chunk)
     const uint32_t gtid = blockIdx.x * 256u + threadIdx.x;
     const uint32_t i = gtid >> 3, sub = gtid & 7u;
     for (uint32_t j = gtid; j < n_zero_a; j += gridDim.x * 256u) zero_a[j] = 0u;
@@ -394,19 +392,74 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
         if (band_misses(f, lo, hi, bidx, bidy)) culled = 1;
     }
     if (have && sub == 0u) draw_culled[i] = culled;
-    // Launch table of k_project for THIS frame: only the chunks of surviving draws, in the per-XCD layout of chunk_tab_xcd
-    // (position k * 8 + x runs on XCD x = draw % 8).  The workgroups of culled chunks used to learn that they are culled from
-    // three dependent loads each (chunk table -> draw record -> cull flag): 21 k of c3's 39 k chunks, 290 k of c5's 366 k.
-    // The order inside an XCD's list is the order of the atomic adds: irrelevant, a chunk's output slots are fixed.
-    const bool live = have && !culled && d.count != 0u;
-    const uint32_t nch = live ? (d.count + (uint32_t)kChunk - 1u) / (uint32_t)kChunk : 0u, x = i & 7u;
-    uint32_t pos = 0;
-    if (live && sub == 0u) pos = atomicAdd(&live_cnt[x], nch);
-    pos = (uint32_t)__shfl((int)pos, (int)((threadIdx.x & 63u) & ~7u), 64);           // from lane 0 of this draw's eight
-    // an entry carries what the chunk's first load needs -- the list position of its lane 0 and the list's length and arena -- so that
-    // k_project's list-word load does not wait for the draw record (one dependent round trip less in front of the gathers)
-    for (uint32_t k = sub; k < nch; k += 8u)
-        live_tab[(size_t)(pos + k) * 8u + x] = make_uint4(i, k * (uint32_t)kChunk, d.list_base + d.count - 1u - k * (uint32_t)kChunk, d.count | (d.merged ? 0x80000000u : 0u));
+}
+
+// ------------------------------------------------------------------------------------
+// k_live: the launch table of k_project for THIS frame, one thread per chunk (a chunk = 256 list entries of one draw): only the chunks of
+// the draws that survive k_cull, in the per-XCD layout of chunk_tab_xcd (position k * 8 + x runs on XCD x = draw % 8; the order inside an
+// XCD's list is the order of the atomic adds: irrelevant, a chunk's output slots are fixed).  An entry carries what the chunk's first load
+// needs -- the list position of its lane 0 and the list's length and arena -- so that k_project's list-word load does not wait for the draw record.
+// Round 4: CHUNK-LEVEL FRUSTUM CULL.  The reference culls whole tile draws on the CPU (renderer.rs:472-494: min |x|, min |y|, max z of the four
+// corner NDCs, which lets every tile through that has one corner near the view axis), and vs_main then drops splat by splat
+// (gswt.wgsl:163-167).  A draw's list is presorted by depth, so a chunk of it is a slab of the tile: measured on the c3 frame, 49 % of the
+// chunks of the surviving draws hold NO splat that passes vs_main's frustum test -- half of k_project's live workgroups gathered 256 records
+// to find that out.  Every static list carries the tile-local bounding box of each of its chunks (gswt_upload_scene); a chunk whose box,
+// moved to the draw's offset, lies on the far side of ONE of the five planes of that test at all eight corners (clip-space coordinates are
+// affine in the position, so then at every point of the box; a relative margin of 1e-3 covers the rounding of both evaluations) is left out
+// of the table.  Nothing that vs_main would keep is dropped: images, visible and pair counts are bit-identical (GSWT_OPT_NO_CHUNK_CULL).
+// Plain surface only (HeightMap / Sphere move a splat off its flat position); merged groups carry no boxes yet (their lists are rebuilt per
+// sort event and mix member tiles) and stay whole.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_live(const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab, uint32_t n_chunks,
+                                              const uint32_t* __restrict__ draw_culled, const float* __restrict__ boxes, uint32_t chunk_cull,
+                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab)
+{
+    __shared__ uint32_t s_cnt[8], s_base[8];
+    if (threadIdx.x < 8u) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    bool live = false;
+    uint4 e = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t x = 0, rank = 0;
+    if (c < n_chunks) {
+        const uint2 ct = chunk_tab[c];
+        const DrawDev& d = draws[ct.x];
+        live = draw_culled[ct.x] == 0u && d.count != 0u;
+        if (live && chunk_cull && d.merged == 0u && d.box_base != 0xFFFFFFFFu && f.surface_type == 0u) {
+            const float* b = boxes + 6u * (size_t)(d.box_base + (ct.y >> 8));
+            float lo[3], hi[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {                 // the same (pos + offset) * scene_scale as vs_main: rounding is monotonic, so the box still holds every centre
+                const float a = (b[k] + d.off[k]) * f.scene_scale[k], z = (b[3 + k] + d.off[k]) * f.scene_scale[k];
+                lo[k] = fminf(a, z); hi[k] = fmaxf(a, z);
+            }
+            bool xp = true, xn = true, yp = true, yn = true, zn = true;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float px = (k & 1) ? hi[0] : lo[0], py = (k & 2) ? hi[1] : lo[1], pz = (k & 4) ? hi[2] : lo[2];
+                float cv[4], q[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) cv[r] = ((f.V[r] * px + f.V[4 + r] * py) + f.V[8 + r] * pz) + f.V[12 + r];
+#pragma unroll
+                for (int r = 0; r < 4; r++) q[r] = ((f.GP[r] * cv[0] + f.GP[4 + r] * cv[1]) + f.GP[8 + r] * cv[2]) + f.GP[12 + r] * cv[3];
+                const float clip = 1.2f * q[3];
+                const float m = 1e-3f * (((fabsf(q[0]) + fabsf(q[1])) + fabsf(q[2])) + fabsf(clip)) + 1e-3f;
+                xp = xp && (q[0] - clip > m); xn = xn && (-q[0] - clip > m);        // (a NaN compares false: such a chunk stays)
+                yp = yp && (q[1] - clip > m); yn = yn && (-q[1] - clip > m);
+                zn = zn && (-q[2] - clip > m);
+            }
+            if (xp || xn || yp || yn || zn) live = false;
+        }
+        x = ct.x & 7u;
+        if (live) {
+            e = make_uint4(ct.x, ct.y, d.list_base + d.count - 1u - ct.y, d.count | (d.merged ? 0x80000000u : 0u));
+            rank = atomicAdd(&s_cnt[x], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8u && s_cnt[threadIdx.x] != 0u) s_base[threadIdx.x] = atomicAdd(&live_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    if (live) live_tab[(size_t)(s_base[x] + rank) * 8u + x] = e;
 }
 
 // ------------------------------------------------------------------------------------
@@ -2630,11 +2683,14 @@ GraphRec*& graph_recorder()
 
 void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, uint32_t* cell_culled, uint32_t n_cells,
                  uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b, uint32_t* zero_c, uint32_t n_zero_c,
-                 uint32_t* live_cnt, uint4* live_tab, uint32_t* zero_d, uint32_t n_zero_d)
+                 uint32_t* live_cnt, uint4* live_tab, uint32_t* zero_d, uint32_t n_zero_d,
+                 const uint2* chunk_tab, uint32_t n_chunks, const float* boxes, bool chunk_cull)
 {
     uint32_t grid = (n_draws * 8u + 255u) / 256u;          // eight lanes per draw
     if (grid < 32) grid = 32;
-    GSWT_LAUNCH(k_cull, dim3(grid), dim3(256), s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, live_cnt, live_tab, zero_d, n_zero_d);
+    GSWT_LAUNCH(k_cull, dim3(grid), dim3(256), s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, zero_d, n_zero_d);
+    if (n_chunks) GSWT_LAUNCH(k_live, dim3((n_chunks + 255u) / 256u), dim3(256), s, f, draws, chunk_tab, n_chunks, (const uint32_t*)draw_culled, boxes,
+                              chunk_cull && boxes ? 1u : 0u, live_cnt, live_tab);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,

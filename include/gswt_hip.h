@@ -204,7 +204,10 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
        GSWT_OPT_DEPTH_SORT = 14 /* how GSWT_ORDER_DEPTH orders the pairs: 0 / 1 (default) = global radix passes on the depth bits in front of the
                                    tile passes; 2 = tile passes first (depth bits as payload), then every screen tile's slice is depth-sorted
                                    inside LDS by one workgroup (lists up to 8 192 pairs; a frame with a longer one is re-run with the global
-                                   passes).  Same image bit for bit; measured slower than the global passes */ };
+                                   passes).  Same image bit for bit; measured slower than the global passes */,
+       GSWT_OPT_NO_CHUNK_CULL = 15 /* 1: the per-chunk frustum cull in front of the projection is off (every 256-entry chunk of a draw that
+                                      survives the reference's tile cull is projected, as until round 3).  Same image bit for bit: the cull
+                                      only leaves out chunks none of whose splats vs_main's own frustum test (gswt.wgsl:163-167) would keep */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

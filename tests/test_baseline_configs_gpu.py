@@ -57,6 +57,14 @@ def test_baseline_config_matches_oracle(renderer, name):
     # what bench.py times: front-to-back early termination at 1e-5
     img_e = pipe.render(s["cu"], W, Hh, transmittance_eps=1e-5)
     assert H.max_abs_diff(img_e, ref) <= TOL
+    # the per-chunk frustum cull in front of the projection (k_live) only leaves out chunks none of whose splats vs_main would keep: same bits without it
+    renderer.set_option(L.GSWT_OPT_NO_CHUNK_CULL, 1)
+    try:
+        img_n = pipe.render(s["cu"], W, Hh)
+        tn = renderer.timings()
+    finally:
+        renderer.set_option(L.GSWT_OPT_NO_CHUNK_CULL, 0)
+    assert np.array_equal(img_n, img) and (tn["n_visible"], tn["n_pairs"]) == (t["n_visible"], t["n_pairs"])
     if name in ("c3", "c3s"):
         # c4's shard layout on one device: 8 column bands, each with its own draw cull; their union is the frame, bit for bit
         # (c3s: the same on the Sphere surface, whose cells are bounded by sphere_cell_box)
