@@ -407,8 +407,8 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
 // moved to the draw's offset, lies on the far side of ONE of the five planes of that test at all eight corners (clip-space coordinates are
 // affine in the position, so then at every point of the box; a relative margin of 1e-3 covers the rounding of both evaluations) is left out
 // of the table.  Nothing that vs_main would keep is dropped: images, visible and pair counts are bit-identical (GSWT_OPT_NO_CHUNK_CULL).
-// Plain surface only (HeightMap / Sphere move a splat off its flat position); merged groups carry no boxes yet (their lists are rebuilt per
-// sort event and mix member tiles) and stay whole.
+// Plain and HeightMap surfaces (the Sphere mapping moves a splat far from its flat position: no cull there); merged groups carry no boxes
+// yet (their lists are rebuilt per sort event and mix member tiles) and stay whole.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_live(const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab, uint32_t n_chunks,
                                               const uint32_t* __restrict__ draw_culled, const float* __restrict__ boxes, uint32_t chunk_cull,
@@ -425,13 +425,21 @@ __global__ __launch_bounds__(256) void k_live(const Frame f, const DrawDev* __re
         const uint2 ct = chunk_tab[c];
         const DrawDev& d = draws[ct.x];
         live = draw_culled[ct.x] == 0u && d.count != 0u;
-        if (live && chunk_cull && d.merged == 0u && d.box_base != 0xFFFFFFFFu && f.surface_type == 0u) {
+        if (live && chunk_cull && d.merged == 0u && d.box_base != 0xFFFFFFFFu && f.surface_type <= 1u) {
             const float* b = boxes + 6u * (size_t)(d.box_base + (ct.y >> 8));
             float lo[3], hi[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) {                 // the same (pos + offset) * scene_scale as vs_main: rounding is monotonic, so the box still holds every centre
                 const float a = (b[k] + d.off[k]) * f.scene_scale[k], z = (b[3 + k] + d.off[k]) * f.scene_scale[k];
                 lo[k] = fminf(a, z); hi[k] = fmaxf(a, z);
+            }
+            if (f.surface_type == 1u) {
+                // HeightMap surface (gswt.wgsl:565-599): the mapped centre is (x, y, h(x, y) hz) + n z with |n| = 1 and h between the map's
+                // extremes (k_cull's band cull bounds a cell the same way): x and y move by at most |z|, the height lies in
+                // [surf_zlo - |z|, surf_zhi + |z|]; a little slack for the rounding of the bilinear sample and of n
+                const float zp = fmaxf(fabsf(lo[2]), fabsf(hi[2])) * 1.0001f + 1e-6f;
+                lo[0] -= zp; hi[0] += zp; lo[1] -= zp; hi[1] += zp;
+                lo[2] = f.surf_zlo - zp - 1e-4f * (fabsf(f.surf_zlo) + 1.0f); hi[2] = f.surf_zhi + zp + 1e-4f * (fabsf(f.surf_zhi) + 1.0f);
             }
             bool xp = true, xn = true, yp = true, yn = true, zn = true;
 #pragma unroll
