@@ -46,7 +46,7 @@ int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_
                 const uint32_t* = nullptr, uint32_t* = nullptr, uint32_t* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t, uint32_t*, bool);
-void launch_tile_depth_sort(hipStream_t, const uint2*, uint32_t*, const uint32_t*, const uint32_t*, int, unsigned long long*);
+void launch_tile_depth_sort(hipStream_t, const uint2*, uint32_t*, const uint32_t*, int, uint32_t*, unsigned long long*);
 uint32_t tile_depth_sort_cap();
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
@@ -335,8 +335,8 @@ struct gswt_ctx {
     uint32_t depth_passes = 3;
     uint32_t depth_passes_low_run = 0, depth_passes_low_max = 0;
     // ... or the tile-local path: tile passes first (depth bits as payload), then one kernel that depth-sorts each tile's slice in LDS.
-    // GSWT_OPT_DEPTH_SORT: 0 / 1 = the global passes (the default: faster at every size measured), 2 = tile-local while every screen tile's
-    // list fits k_tile_depth_sort's LDS buffer (k_items reports the longest; a frame that meets a longer one falls back by re-run).
+    // GSWT_OPT_DEPTH_SORT: 0 / 2 = tile-local while every screen tile's list fits k_tile_depth_sort's LDS buffer (k_items reports the longest;
+    // a frame that meets a longer one falls back by re-run), 1 = the global passes always.
     int opt_depth_sort = 0;
     uint32_t depth_max_tile_len = 0;       // longest tile list of the last finished depth-ordered frame (0: none yet -- try tile-local)
     unsigned long long stat_depth_local = 0, stat_depth_global = 0;     // depth-ordered frames enqueued on either path (re-runs included)
@@ -1405,8 +1405,10 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     sl.n_tiles = n_tiles;
     float4* const d_out = a.d_out;
     // (behind the per-tile ranges: one ticket word per tile for GSWT_OPT_COMPOSITE = 2, cleared with them by k_cull)
-    HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1 + ((size_t)n_tiles + 1) / 2 + 1));
+    // (and behind those: the tile-local depth sort's list of long tiles, [0] = count, cleared likewise)
+    HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1 + ((size_t)n_tiles + 1) / 2 + 1 + ((size_t)n_tiles + 2) / 2 + 1));
     uint32_t* const d_tile_tick = reinterpret_cast<uint32_t*>(sl.ranges.p + (size_t)n_tiles + 1);
+    uint32_t* const d_long_tiles = d_tile_tick + n_tiles;
     const bool dbg = c->opt_debug_varyings != 0;
     const bool need_depths = a.d_bgd != nullptr || cfg->order_mode == GSWT_ORDER_DEPTH;
     if (dbg) HIP_TRY(c, c->dbg.ensure((size_t)D.n_entries + 1));
@@ -1429,9 +1431,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // needed (k_items flags a frame that needs more: finish_frame re-runs it); the tile ids travel as the payload of those passes
     sl.depth_passes = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->depth_passes, 1u), 4u) : 0u;
     // a re-run after the tile-local path flagged a list that does not fit takes the global passes (finish_frame raised depth_max_tile_len)
-    // (measured at c3: k_tile_depth_sort 115 us against 3 x 27.8 us for the global passes -- the longest list's workgroup IS the kernel --, so
-    // the tile-local path runs only when asked for: GSWT_OPT_DEPTH_SORT = 2)
-    sl.depth_local = depth_order && c->opt_depth_sort == 2 && c->depth_max_tile_len <= tile_depth_sort_cap();
+    // (GSWT_OPT_DEPTH_SORT: 0 = tile-local while the longest list fits its LDS buffer, 1 = always the global passes, 2 = as 0)
+    sl.depth_local = depth_order && c->opt_depth_sort != 1 && c->depth_max_tile_len <= tile_depth_sort_cap();
     const int depth_bits = sl.depth_local ? 0 : 8 * (int)sl.depth_passes;
     if (depth_order) (sl.depth_local ? c->stat_depth_local : c->stat_depth_global)++;
     if (depth_order) { HIP_TRY(c, sl.aux_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.aux_b.ensure_roomy((size_t)cap + 1)); }
@@ -1481,7 +1482,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // part is contiguous with the head; the depth sort's (behind the pair sort's rows) is the kernel's second clear range.
     const size_t n_zero_a = 16 + n_super2 + rz_pair;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
-                reinterpret_cast<uint32_t*>(sl.ranges.p), ((uint32_t)n_tiles + 1u) * 2u + (uint32_t)n_tiles, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
+                reinterpret_cast<uint32_t*>(sl.ranges.p), ((uint32_t)n_tiles + 1u) * 2u + (uint32_t)n_tiles + 1u, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
                 d_radix_depth, (uint32_t)rz_depth, D.chunk_tab.p, D.n_chunks, c->static_boxes.p, c->opt_no_chunk_cull == 0 && !dbg);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
@@ -1503,7 +1504,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p, nullptr, sl.aux_a.p, sl.aux_b.p);
         uint32_t* const vals_t = where ? sl.vals_b.p : sl.vals_a.p;
-        launch_tile_depth_sort(s, sl.ranges.p, vals_t, where ? sl.aux_b.p : sl.aux_a.p, d_krange, n_tiles, d_counters);
+        launch_tile_depth_sort(s, sl.ranges.p, vals_t, where ? sl.aux_b.p : sl.aux_a.p, n_tiles, d_long_tiles, d_counters);
         vals_sorted = vals_t;
     } else {
         launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.aux_a.p, sl.vals_a.p, sl.depths.p, sl.keys_a.p, d_krange);

@@ -1288,15 +1288,25 @@ __device__ __forceinline__ uint32_t sort_passes_needed(const uint32_t* __restric
 // (Round 4, measured and dropped: a fast path for rounds whose 64 items share one digit -- one broadcast + one ballot instead of nbits
 // ballots, taken in the passes after the first, where the pairs of one screen tile are neighbours: the last pass of the c3 pair sort went
 // from 18.5 to 21.8 us.  Too few rounds are uniform, and the mixed ones pay the two extra wave-wide operations.)
+// One step per key bit, six vector instructions each: the lane's bit sign-extended (v_bfe_i32: -1 / 0), the ballot of the set bits
+// (v_cmp straight into a scalar pair), and per half of the mask peers &= ~(ballot ^ own) (v_xnor, v_and).  Unrolled, so no loop counter
+// either.  (Until round 4 the loop was rolled and went through __ballot(int): ten vector instructions, two s_nop and the loop's scalar
+// bookkeeping per bit -- about twice the issue slots.)
 __device__ __forceinline__ unsigned long long match_digit(uint32_t dgt, bool valid, uint32_t nbits)
 {
-    unsigned long long peers = __ballot(valid);
-    for (uint32_t b = 0; b < nbits; b++) {
-        const bool bit = (dgt >> b) & 1u;
-        const unsigned long long m = __ballot(valid && bit);
-        peers &= bit ? m : ~m;
+    const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+    uint32_t plo = (uint32_t)vm, phi = (uint32_t)(vm >> 32);
+    // (all eight steps whatever the digit's width: the callers mask the digit, so a bit above it is clear in every lane and its step
+    // changes nothing -- five instructions, against a branch per bit on a count the compiler keeps as a lane mask)
+    (void)nbits;
+#pragma unroll
+    for (uint32_t b = 0; b < 8u; b++) {
+        const uint32_t own = (uint32_t)__builtin_amdgcn_sbfe((int)dgt, b, 1u);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(own != 0u);
+        plo &= ~((uint32_t)m ^ own);
+        phi &= ~((uint32_t)(m >> 32) ^ own);
     }
-    return peers;
+    return ((unsigned long long)phi << 32) | plo;
 }
 
 template <int kSortThreads>
@@ -1687,97 +1697,162 @@ __global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ j
 // ------------------------------------------------------------------------------------
 // k_tile_depth_sort -- GSWT_ORDER_DEPTH, the tile-local path: the pair list has been sorted on the tile bits with each pair's depth bits as
 // the payload; one workgroup per screen tile now sorts that tile's slice by depth INSIDE LDS -- a stable LSD radix sort on the bits of
-// (depth key - the frame's smallest), all passes back to back (three at c3) -- and writes the slots back in place.  Inside a tile: true
-// depth order, equal depths in composite order: bit for bit what the global depth passes in front of the tile sort produce, without their
-// three trips through HBM, their histogram kernels and their launches (c3: 3 x 27.8 us -> one kernel).  The ranking is k_radix_scatter's:
-// each wave owns 1 024 consecutive items, ranks them 64 at a time with ballot match-any (in-wave order = list order), per-wave digit
-// counters in LDS, one exclusive scan over (digit, wave).  A list longer than the LDS buffer (kTileSortCap pairs) cannot be sorted here:
-// the workgroup flags the frame, the host re-runs it with the global passes and keeps them while k_items reports lists that long.
+// (depth key - the TILE's smallest key), all passes back to back -- and writes the slots back in place.  Inside a tile: true depth order,
+// equal depths in composite order: bit for bit what the global depth passes in front of the tile sort produce, without their three trips
+// through HBM, their histogram kernels and their launches.  The ranking is k_radix_scatter's: each wave owns a run of consecutive
+// 64-item rounds and ranks them with ballot match-any (in-wave order = list order), per-wave digit counters in LDS, one exclusive scan
+// over (digit, wave).  The digit width follows the tile's own key span: `passes` = ceil(bits / 8) digits of ceil(bits / passes) bits.
+//
+// Three size classes, one launch each (c3: 8 160 screen tiles, 4 679 of them sky; 2 133 lists of up to 512 pairs hold 18 % of the 2.66 M
+// pairs, 1 290 of 513 .. 4 096 hold 72 %, 58 longer ones 10 % -- tools/tile_lengths.py):
+//   <64, 8, false>    one WAVE per screen tile, lists of up to 512 pairs (5 KB of LDS, no barrier that costs anything)
+//   <256, 16, false>  one 256-thread workgroup per tile, 513 .. 4 096 pairs (36 KB); a longer list's tile id goes onto `long_list`
+//                     ([0] = count, cleared by k_cull)
+//   <1024, 16, true>  a fixed grid that walks long_list: up to 16 384 pairs per list (144 KB of LDS, one workgroup per CU)
+// (The first build -- one 512-thread / 64-KB workgroup for every tile, 32 unconditional loads per thread -- took 115 us at c3; the classes
+// as built here 12.6 + 27.9 + 16.0 us, each with ~4.8 us of launch floor, against 3 x (24.7 + 5.1) us for the global depth passes.  Other
+// cuts measured: profiles/r04_depth_sort_variants.txt.)
+// A list longer than that cannot be sorted here: the workgroup flags the frame (counters[3]), the host re-runs it with the global passes
+// and keeps them while k_items reports lists that long.
 // ------------------------------------------------------------------------------------
-constexpr uint32_t kTileSortCap = 8192u;
-__global__ __launch_bounds__(512) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ vals, const uint32_t* __restrict__ dkeys,
-                                                         const uint32_t* __restrict__ krange, unsigned long long* __restrict__ counters)
+constexpr uint32_t kTileSortCap = 16384u, kTileSortLongGrid = 256u;
+// WAVE: one wave of a larger workgroup sorts a list on its own (THREADS = 64): its LDS slices are private and a wave's LDS operations complete
+// in order, so the workgroup barriers become compiler-level fences
+template <bool WAVE>
+__device__ __forceinline__ void tls_sync()
 {
-    constexpr int kItems = (int)(kTileSortCap / 512u);            // 16 per thread: wave w owns items [1024 w, 1024 w + 1024)
-    __shared__ uint2 s_kv[kTileSortCap];
-    __shared__ uint32_t s_h[8][256];
-    __shared__ uint32_t s_w[4];
-    const uint2 rg = ranges[blockIdx.x];                          // (~start, end); (0, 0): no pairs
-    if (rg.y == 0u) return;
-    const uint32_t start = ~rg.x, n = rg.y - start;
-    if (n <= 1u) return;
-    if (n > kTileSortCap) { if (threadIdx.x == 0u) counters[3] = 1ull; return; }
-    uint32_t kmin, kmax;
-    load_krange(krange, kmin, kmax);
-    const uint32_t need = sort_passes_needed(krange);
-    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u, base_w = w * (64u * (uint32_t)kItems);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t key[kItems], val[kItems];
-#pragma unroll
-    for (int k = 0; k < kItems; k++) {                            // clamped, unmasked loads
-        const uint32_t i = min(base_w + (uint32_t)k * 64u + lane, n - 1u);
-        key[k] = dkeys[start + i] - kmin;
-        val[k] = vals[start + i];
-    }
-    for (uint32_t p = 0; p < need; p++) {
-        const uint32_t shift = 8u * p;
-        for (uint32_t q = threadIdx.x; q < 8u * 256u; q += 512u) (&s_h[0][0])[q] = 0u;
-        __syncthreads();
-        unsigned long long pm[kItems];
-#pragma unroll
-        for (int k = 0; k < kItems; k++) {
-            pm[k] = 0ull;
-            if (base_w + (uint32_t)k * 64u >= n) continue;        // wave-uniform: this round holds no item
-            const bool valid = base_w + (uint32_t)k * 64u + lane < n;
-            const uint32_t dgt = (key[k] >> shift) & 255u;
-            const unsigned long long peers = match_digit(dgt, valid, 8u);
-            pm[k] = peers;
-            if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+    if (WAVE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else __syncthreads();
+}
+template <int THREADS, int ROUNDS, bool LONG, bool WAVE = false>
+__device__ __forceinline__ void tile_depth_sort_one(uint32_t tile, const uint2* __restrict__ ranges, uint32_t* __restrict__ vals, const uint32_t* __restrict__ dkeys,
+                                                    uint32_t* __restrict__ long_list, unsigned long long* __restrict__ counters, uint32_t n_lo, bool push,
+                                                    uint2* s_kv, uint32_t (*s_h)[256], uint32_t* s_w, uint32_t* s_mn, uint32_t* s_mx)
+{
+    constexpr uint32_t CAP = (uint32_t)(THREADS * ROUNDS);
+    constexpr int NW = THREADS / 64;
+    // (everything the control flow hangs on is read through v_readfirstlane: a value loaded from memory sits in a vector register, and the
+    // compiler then predicates every "uniform" branch below with exec-mask nests instead of scalar branches)
+    const uint2 rgv = ranges[__builtin_amdgcn_readfirstlane(tile)];  // (~start, end); (0, 0): no pairs
+    const uint32_t rg_x = __builtin_amdgcn_readfirstlane(rgv.x), rg_y = __builtin_amdgcn_readfirstlane(rgv.y);
+    if (rg_y == 0u) return;
+    const uint32_t start = ~rg_x, n = rg_y - start;
+    if (n <= max(n_lo, 1u)) return;                               // (a shorter list: the class below's)
+    if (n > CAP) {                                                // workgroup-uniform
+        if ((WAVE ? (threadIdx.x & 63u) : threadIdx.x) == 0u && (LONG || push)) {
+            if (LONG || n > kTileSortCap) counters[3] = 1ull;
+            else long_list[1u + atomicAdd(&long_list[0], 1u)] = tile;
         }
-        __syncthreads();
-        // exclusive scan over (digit, wave): thread d < 256 owns digit d
-        uint32_t cnt[8], tot = 0, inc = 0;
-        const bool dig = threadIdx.x < 256u;
-        const uint32_t d = threadIdx.x & 255u;
+        return;
+    }
+    static_assert(!WAVE || THREADS == 64, "wave-local mode is one wave");
+    const uint32_t lane = threadIdx.x & 63u, w = WAVE ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = WAVE ? lane : threadIdx.x;
+    const uint32_t rounds = (n + 63u) >> 6, rpw = (rounds + (uint32_t)NW - 1u) / (uint32_t)NW;   // wave w owns rounds [w rpw, (w + 1) rpw)
+    const uint32_t base_w = w * rpw * 64u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t key[ROUNDS], val[ROUNDS];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; k++) {
+        key[k] = 0u; val[k] = 0u;
+        if ((uint32_t)k >= rpw || base_w + (uint32_t)k * 64u >= n) continue;                      // wave-uniform: this round holds no item
+        const uint32_t i = min(base_w + (uint32_t)k * 64u + lane, n - 1u);                         // (the lanes past the end repeat the last item)
+        key[k] = dkeys[start + i];
+        val[k] = vals[start + i];
+        mn = min(mn, key[k]); mx = max(mx, key[k]);
+    }
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); }
+    if (lane == 0u) { s_mn[w] = mn; s_mx[w] = mx; }
+    tls_sync<WAVE>();
+#pragma unroll
+    for (int q = 0; q < NW; q++) { mn = min(mn, s_mn[q]); mx = max(mx, s_mx[q]); }
+    mn = __builtin_amdgcn_readfirstlane(mn); mx = __builtin_amdgcn_readfirstlane(mx);
+    const uint32_t span = mx - mn;
+    if (span == 0u) return;                                       // one depth: the list is in order already
+    const uint32_t bits = 32u - (uint32_t)__clz((int)span), passes = (bits + 7u) >> 3, nb = (bits + passes - 1u) / passes, dmask = (1u << nb) - 1u;
+#pragma unroll
+    for (int k = 0; k < ROUNDS; k++) key[k] -= mn;
+    for (uint32_t p = 0; p < passes; p++) {
+        const uint32_t shift = nb * p;
+        for (uint32_t q = tid; q < (uint32_t)NW * 256u; q += (uint32_t)THREADS) (&s_h[0][0])[q] = 0u;
+        tls_sync<WAVE>();                                          // (also: the previous pass's reads of s_kv are done)
+        uint32_t pm[ROUNDS];                                     // per round: rank among the peers | first peer's lane << 8 | peers << 16
+#pragma unroll
+        for (int k = 0; k < ROUNDS; k++) {
+            pm[k] = 0u;
+            if ((uint32_t)k >= rpw || base_w + (uint32_t)k * 64u >= n) continue;
+            const bool valid = base_w + (uint32_t)k * 64u + lane < n;
+            const uint32_t dgt = (key[k] >> shift) & dmask;
+            const unsigned long long peers = match_digit(dgt, valid, nb);
+            const uint32_t rank = (uint32_t)__popcll(peers & lt), cnt = (uint32_t)__popcll(peers);
+            pm[k] = rank | (valid ? (uint32_t)(__ffsll((long long)peers) - 1) : lane) << 8 | cnt << 16;
+            if (valid && rank == 0u) atomicAdd(&s_h[w][dgt], cnt);
+        }
+        tls_sync<WAVE>();
+        // exclusive scan over (digit, wave): the first 256 threads own one digit each (a one-wave workgroup: four per lane)
+        constexpr int SCAN_T = THREADS < 256 ? THREADS : 256, DPT = 256 / SCAN_T;
+        uint32_t cnt[DPT][NW], tot = 0, inc = 0;
+        const bool dig = tid < (uint32_t)SCAN_T;
+        const uint32_t d0 = (tid & (uint32_t)(SCAN_T - 1)) * (uint32_t)DPT;
         if (dig) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) { cnt[q] = s_h[q][d]; tot += cnt[q]; }
+            for (int j = 0; j < DPT; j++)
+#pragma unroll
+                for (int q = 0; q < NW; q++) { cnt[j][q] = s_h[q][d0 + (uint32_t)j]; tot += cnt[j][q]; }
             inc = wave_incl_scan(tot, lane);
             if (lane == 63u) s_w[w] = inc;
         }
-        __syncthreads();
+        tls_sync<WAVE>();
         if (dig) {
             uint32_t b = inc - tot;
             for (uint32_t q = 0; q < w; q++) b += s_w[q];
 #pragma unroll
-            for (int q = 0; q < 8; q++) { s_h[q][d] = b; b += cnt[q]; }
-        }
-        __syncthreads();
+            for (int j = 0; j < DPT; j++)
 #pragma unroll
-        for (int k = 0; k < kItems; k++) {
-            if (base_w + (uint32_t)k * 64u >= n) continue;
+                for (int q = 0; q < NW; q++) { s_h[q][d0 + (uint32_t)j] = b; b += cnt[j][q]; }
+        }
+        tls_sync<WAVE>();
+        // (measured and dropped: the counter updates, broadcasts and stores of all rounds as three loops instead of one, so that the LDS
+        // round trips of different rounds overlap: 35.3 against 30.6 us at c3 for the 256-thread class -- the extra live registers cost a wave)
+#pragma unroll
+        for (int k = 0; k < ROUNDS; k++) {
+            if ((uint32_t)k >= rpw || base_w + (uint32_t)k * 64u >= n) continue;
             const bool valid = base_w + (uint32_t)k * 64u + lane < n;
-            const uint32_t dgt = valid ? (key[k] >> shift) & 255u : 0u;
-            const unsigned long long peers = pm[k];
-            const uint32_t rank = (uint32_t)__popcll(peers & lt);
+            const uint32_t dgt = (key[k] >> shift) & dmask;
             uint32_t pos = 0;
-            if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
-            const int leader = valid ? (int)__ffsll((long long)peers) - 1 : (int)lane;
-            pos = (uint32_t)__shfl((int)pos, leader, 64);
-            if (valid) s_kv[pos + rank] = make_uint2(key[k], val[k]);
+            if (valid && (pm[k] & 255u) == 0u) pos = atomicAdd(&s_h[w][dgt], pm[k] >> 16);
+            pos = (uint32_t)__shfl((int)pos, (int)((pm[k] >> 8) & 255u), 64) + (pm[k] & 255u);
+            if (valid) s_kv[pos] = make_uint2(key[k], val[k]);
         }
-        __syncthreads();
+        tls_sync<WAVE>();
+        if (p + 1u == passes) break;
 #pragma unroll
-        for (int k = 0; k < kItems; k++) {                        // back into list order for the next pass (and the write-back)
+        for (int k = 0; k < ROUNDS; k++) {                        // back into list order for the next pass
             const uint32_t i = base_w + (uint32_t)k * 64u + lane;
-            if (i < n) { const uint2 kv = s_kv[i]; key[k] = kv.x; val[k] = kv.y; }
+            if ((uint32_t)k < rpw && i < n) { const uint2 kv = s_kv[i]; key[k] = kv.x; val[k] = kv.y; }
         }
-        // (the next pass's first barrier, behind the clearing of s_h, also orders these reads before its writes to s_kv)
     }
-#pragma unroll
-    for (int k = 0; k < kItems; k++) {
-        const uint32_t i = base_w + (uint32_t)k * 64u + lane;
-        if (i < n) vals[start + i] = val[k];
+    for (uint32_t i = tid; i < n; i += (uint32_t)THREADS) vals[start + i] = s_kv[i].y;
+}
+
+template <int THREADS, int ROUNDS, bool LONG>
+__global__ __launch_bounds__(THREADS) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ vals, const uint32_t* __restrict__ dkeys,
+                                                             uint32_t n_tiles, uint32_t* __restrict__ long_list, unsigned long long* __restrict__ counters,
+                                                             uint32_t n_lo, uint32_t push)
+{
+    constexpr int NW = THREADS / 64;
+    __shared__ uint2 s_kv[THREADS * ROUNDS];
+    __shared__ uint32_t s_h[NW][256];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_mn[NW], s_mx[NW];
+    if (!LONG) {
+        if (blockIdx.x < n_tiles) tile_depth_sort_one<THREADS, ROUNDS, LONG>(blockIdx.x, ranges, vals, dkeys, long_list, counters, n_lo, push != 0u, s_kv, s_h, s_w, s_mn, s_mx);
+    } else {
+        const uint32_t n_long = min(long_list[0], n_tiles);      // written by the launch in front of this one
+        for (uint32_t t = blockIdx.x; t < n_long; t += gridDim.x) {
+            tile_depth_sort_one<THREADS, ROUNDS, LONG>(long_list[1u + t], ranges, vals, dkeys, long_list, counters, n_lo, false, s_kv, s_h, s_w, s_mn, s_mx);
+            __syncthreads();                                      // the next list reuses the LDS
+        }
     }
 }
 
@@ -2827,10 +2902,15 @@ void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks
 
 // GSWT_ORDER_DEPTH, tile-local path: depth-sorts every screen tile's slice of the (tile-sorted) pair list in LDS; dkeys = the pairs' depth
 // bits in the same order (the tile sort's payload)
-void launch_tile_depth_sort(hipStream_t s, const uint2* ranges, uint32_t* vals, const uint32_t* dkeys, const uint32_t* krange, int n_tiles,
+void launch_tile_depth_sort(hipStream_t s, const uint2* ranges, uint32_t* vals, const uint32_t* dkeys, int n_tiles, uint32_t* long_list,
                             unsigned long long* counters)
 {
-    if (n_tiles > 0) GSWT_LAUNCH(k_tile_depth_sort, dim3((uint32_t)n_tiles), dim3(512), s, ranges, vals, dkeys, krange, counters);
+    if (n_tiles <= 0) return;
+    // three size classes, one launch each: a wave per tile, a 256-thread workgroup per tile, a fixed grid over the list of still longer ones
+    const uint32_t nt = (uint32_t)n_tiles;
+    GSWT_LAUNCH((k_tile_depth_sort<64, 8, false>), dim3(nt), dim3(64), s, ranges, vals, dkeys, nt, long_list, counters, 0u, 0u);
+    GSWT_LAUNCH((k_tile_depth_sort<256, 16, false>), dim3(nt), dim3(256), s, ranges, vals, dkeys, nt, long_list, counters, 512u, 1u);
+    GSWT_LAUNCH((k_tile_depth_sort<1024, 16, true>), dim3(kTileSortLongGrid), dim3(1024), s, ranges, vals, dkeys, nt, long_list, counters, 4096u, 0u);
 }
 uint32_t tile_depth_sort_cap() { return kTileSortCap; }
 

@@ -201,10 +201,11 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                   buffers, ready / consumed counters instead of barriers); 2 k_composite<FOLD> -- the segments of a long tile list
                                   are folded by whichever of their workgroups finishes last (agent-scope stores + a ticket per tile), tiles
                                   without pairs are work items: no k_combine launch behind the compositor.  Same image bit for bit */,
-       GSWT_OPT_DEPTH_SORT = 14 /* how GSWT_ORDER_DEPTH orders the pairs: 0 / 1 (default) = global radix passes on the depth bits in front of the
-                                   tile passes; 2 = tile passes first (depth bits as payload), then every screen tile's slice is depth-sorted
-                                   inside LDS by one workgroup (lists up to 8 192 pairs; a frame with a longer one is re-run with the global
-                                   passes).  Same image bit for bit; measured slower than the global passes */,
+       GSWT_OPT_DEPTH_SORT = 14 /* how GSWT_ORDER_DEPTH orders the pairs: 0 (default) / 2 = tile passes first (depth bits as payload), then every
+                                   screen tile's slice is depth-sorted inside LDS (k_tile_depth_sort: lists up to 16 384 pairs; a frame with a
+                                   longer one is re-run with the global passes, and the frames after it take them until the lists are short
+                                   again); 1 = always global radix passes on the depth bits in front of the tile passes.  Same image bit for
+                                   bit */,
        GSWT_OPT_NO_CHUNK_CULL = 15 /* 1: the per-chunk frustum cull in front of the projection is off (every 256-entry chunk of a draw that
                                       survives the reference's tile cull is projected, as until round 3).  Same image bit for bit: the cull
                                       only leaves out chunks none of whose splats vs_main's own frustum test (gswt.wgsl:163-167) would keep */ };

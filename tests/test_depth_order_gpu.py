@@ -47,8 +47,8 @@ def test_depth_order_at_baseline_size(renderer, name):
     img_e = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH, transmittance_eps=1e-5)
     assert H.max_abs_diff(img_e, ref_d) <= TOL
     # the two ways to get there -- global radix passes on the depth bits in front of the tile passes (the default), or tile passes first and
-    # every tile's slice depth-sorted in LDS (GSWT_OPT_DEPTH_SORT = 2: lists up to 8 192 pairs; the dense c3d has longer ones and falls
-    # back) -- give the same bits
+    # every tile's slice depth-sorted in LDS (GSWT_OPT_DEPTH_SORT = 2: lists up to 16 384 pairs; a frame with a longer one falls back, see
+    # the test below) -- give the same bits
     try:
         renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 1)
         l0, g0, _ = renderer.depth_stats()
@@ -59,7 +59,7 @@ def test_depth_order_at_baseline_size(renderer, name):
         img_l = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
         l2, g2, _ = renderer.depth_stats()
         print(f"{name}: longest tile list {max_len} pairs; tile-local frames {l2 - l1}, global {g2 - g1}")
-        if max_len <= 8192:
+        if max_len <= 16384:
             assert (l2 - l1, g2 - g1) == (1, 0)
         else:
             assert (l2 - l1, g2 - g1) == (1, 1)               # tried, flagged on the device, re-run with the global passes
@@ -95,8 +95,44 @@ def test_depth_order_at_baseline_size(renderer, name):
         assert rows >= 16 and np.array_equal(uni, img)
 
 
-def test_depth_order_frames_replay_as_one_graph(renderer):
-    """No host word enters the depth-ordered chain any more (the sort reads its item count and key range on the device), so
+def test_tile_local_depth_sort_long_lists_and_the_fallback(renderer):
+    """c3's scene on a small framebuffer: few screen tiles, so the pair lists are long.  At 800x448 (1 400 tiles) the longest lists go through
+    the long-list workgroups of k_tile_depth_sort (1 024 < pairs <= 16 384); at 256x144 (144 tiles) a list exceeds the LDS buffer, the device
+    flags the frame and the host re-runs it with the global passes.  Same bits as the global passes either way, and within 1e-4 of the checker."""
+    import bench
+    from gswt_renderer_amd import host, workloads
+    s = _setup(renderer, "c3")
+    cam = workloads.camera_for("c3")
+    try:
+        for (W, Hh), expect_local in (((800, 448), True), ((256, 144), False)):
+            cu, vp = host.camera_uniforms(cam["pos"], cam["target"], cam["up"], cam["fovy"], cam["near"], cam["far"], W, Hh)
+            s["cu"], s["ocu"] = cu, orc.Camera176.from_buffer_copy(bytes(cu))
+            s["tex"], s["draws"] = bench.oracle_draws(s["wang"], s["sort"], vp)
+            renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 1)
+            img_g = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+            _, _, max_len = renderer.depth_stats()
+            renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 2)
+            l0, g0, _ = renderer.depth_stats()
+            img_l = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+            l1, g1, _ = renderer.depth_stats()
+            print(f"{W}x{Hh}: longest tile list {max_len} pairs; tile-local frames {l1 - l0}, global {g1 - g0}")
+            assert (max_len > 1024 and max_len <= 16384) if expect_local else max_len > 16384
+            assert (l1 - l0, g1 - g0) == ((1, 0) if expect_local else (1, 1))
+            assert np.array_equal(img_l, img_g)
+            ref_d, st = orc.render(s["ocu"], s["osu"], s["tex"], s["draws"], W, Hh, height_map=s["hm"], order_mode=1)
+            assert renderer.timings()["n_pairs"] == st["n_pairs16"]
+            assert H.max_abs_diff(img_l, ref_d) <= TOL
+            # the next frame knows the longest list of the last one and takes the right path at once
+            img_l2 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+            l2, g2, _ = renderer.depth_stats()
+            assert (l2 - l1, g2 - g1) == ((1, 0) if expect_local else (0, 1)) and np.array_equal(img_l2, img_g)
+    finally:
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 0)
+
+
+@pytest.mark.parametrize("depth_sort", [0, 1])
+def test_depth_order_frames_replay_as_one_graph(renderer, depth_sort):
+    """(depth_sort: the tile-local LDS sort -- the default -- and the global depth passes.)  No host word enters the depth-ordered chain any more (the sort reads its item count and key range on the device), so
     GSWT_OPT_GRAPH covers it: same bits as launch by launch, over a moving camera, all frame slots in flight."""
     import torch
     import bench
@@ -111,6 +147,7 @@ def test_depth_order_frames_replay_as_one_graph(renderer):
         cams.append(host.camera_uniforms(pos, tgt, cam["up"], cam["fovy"], cam["near"], cam["far"], W, Hh)[0])
     outs = [torch.empty((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in cams]
     renderer.set_option(L.GSWT_OPT_TIMING, 0)
+    renderer.set_option(L.GSWT_OPT_DEPTH_SORT, depth_sort)
     try:
         want = []
         for cu, o in zip(cams, outs):
@@ -130,6 +167,7 @@ def test_depth_order_frames_replay_as_one_graph(renderer):
     finally:
         renderer.set_option(L.GSWT_OPT_GRAPH, 0)
         renderer.set_option(L.GSWT_OPT_TIMING, 2)
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 0)
     assert g1[0] - g0[0] == len(cams)                   # every frame went through hipGraphLaunch
     for a, o in zip(want, outs):
         assert np.array_equal(a, o.cpu().numpy())
@@ -137,7 +175,7 @@ def test_depth_order_frames_replay_as_one_graph(renderer):
 
 
 def test_depth_sort_pass_count_follows_the_depth_range(renderer):
-    """The depth sort launches as many 8-bit passes as the depth ranges of recent frames needed; a frame whose visible depths span more bits
+    """(GSWT_OPT_DEPTH_SORT = 1: the global depth passes.)  The depth sort launches as many 8-bit passes as the depth ranges of recent frames needed; a frame whose visible depths span more bits
     is flagged on the device (k_items) and re-run with more, like a pair-buffer overflow: the image never shows a partially sorted frame.
     More passes than needed sort all the same."""
     s = _setup(renderer, "c1")
@@ -148,15 +186,21 @@ def test_depth_sort_pass_count_follows_the_depth_range(renderer):
     assert st["n_visible"] > 10000 and t["n_visible"] == st["n_visible"] and t["n_pairs"] == st["n_pairs16"]
     assert H.max_abs_diff(img, ref_d) <= TOL
     try:
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 1)
+        l0, g0, _ = renderer.depth_stats()
         for passes in (1, 2, 4):
             renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, passes)
             img_p = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
             assert np.array_equal(img, img_p), passes
+        l1, g1, _ = renderer.depth_stats()
+        assert l1 == l0 and g1 - g0 >= 3
     finally:
         renderer.set_option(L.GSWT_OPT_DEPTH_PASSES, 3)
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 0)
 
 
-def test_depth_order_survives_a_pair_overflow_with_and_without_the_graph(renderer):
+@pytest.mark.parametrize("depth_sort", [0, 1])
+def test_depth_order_survives_a_pair_overflow_with_and_without_the_graph(renderer, depth_sort):
     """The pair buffers (and in depth order the tile-id payload buffers beside them) grow when a frame outgrows them; the overflowed frame is
     re-run by the fence / wait.  With the capacity pinned far below the frame's pair count the depth-ordered image must still be the
     complete one, launch by launch and as a graph."""
@@ -166,6 +210,7 @@ def test_depth_order_survives_a_pair_overflow_with_and_without_the_graph(rendere
     n_pairs = renderer.timings()["n_pairs"]
     assert n_pairs > 10000
     try:
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, depth_sort)
         for graph in (0, 1):
             renderer.set_option(L.GSWT_OPT_GRAPH, graph)
             renderer.set_option(L.GSWT_OPT_TIMING, 0 if graph else 2)
@@ -177,3 +222,4 @@ def test_depth_order_survives_a_pair_overflow_with_and_without_the_graph(rendere
         renderer.set_option(L.GSWT_OPT_PAIR_CAP, 0)
         renderer.set_option(L.GSWT_OPT_GRAPH, 0)
         renderer.set_option(L.GSWT_OPT_TIMING, 2)
+        renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 0)
