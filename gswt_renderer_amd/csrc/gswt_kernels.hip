@@ -22,6 +22,10 @@
 
 namespace gswt {
 
+// Lane mask of a predicate.  (Not __ballot(int): its argument is an int, so the compiler first materialises the predicate as 0 / 1 in a
+// vector register and compares that again -- two vector instructions per ballot that v_cmp had already answered.)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ float clampf(float e, float lo, float hi) { return fminf(fmaxf(e, lo), hi); }
 
@@ -1343,8 +1347,8 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
             const bool valid = base + (uint32_t)k * 64u + lane < n;           // valid lanes are a prefix of the wave
             const uint32_t dgt = ((key[k] - kmin) >> shift) & mask;
             const uint32_t prev = (uint32_t)__shfl_up((int)dgt, 1, 64);
-            const unsigned long long heads = __ballot(valid && (lane == 0u || prev != dgt));
-            const unsigned long long vmask = __ballot(valid);
+            const unsigned long long heads = ballot64(valid && (lane == 0u || prev != dgt));
+            const unsigned long long vmask = ballot64(valid);
             if ((heads >> lane) & 1ull) {
                 const unsigned long long later = heads & ~((2ull << lane) - 1ull);      // run heads behind this lane
                 const uint32_t end = later ? (uint32_t)__ffsll((long long)later) - 1u : (uint32_t)__popcll(vmask);
@@ -1975,7 +1979,7 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
 
 #ifdef GSWT_STATS
 __device__ unsigned long long g_stats[8];
-#define GSWT_STAT_STEP(C) { unsigned long long cm_ = __ballot(C); if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[0], 1ull); \
+#define GSWT_STAT_STEP(C) { unsigned long long cm_ = ballot64(C); if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[0], 1ull); \
     atomicAdd(&g_stats[1], (unsigned long long)__popcll(cm_)); if (cm_ == 0ull) atomicAdd(&g_stats[2], 1ull); \
     unsigned z_ = 0; for (int q_ = 0; q_ < 4; q_++) if (((cm_ >> (16 * q_)) & 0xFFFFull) == 0ull) z_++; atomicAdd(&g_stats[6], (unsigned long long)z_); } }
 #define GSWT_STAT_BATCH(NMAX, C0, C1, C2, C3) { if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_stats[3], 1ull); atomicAdd(&g_stats[4], (unsigned long long)(NMAX)); \
@@ -2029,13 +2033,13 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 #pragma unroll
     for (int c = 0; c < (int)(BATCH / 64u); c++) {
         const uint32_t idx = (uint32_t)c * 64u + lane;
-        bool h0 = false, h1 = false, h2 = false, h3 = false;
-        if (idx < n) {
-            // the staged hit mask of the pair: this wave's strip is bits r0 .. r0 + 3 (r0 = 4 x strip)
-            const uint32_t hm = s_bb[idx] >> (uint32_t)g.r0;
-            h0 = (hm & 1u) != 0u; h1 = (hm & 2u) != 0u; h2 = (hm & 4u) != 0u; h3 = (hm & 8u) != 0u;
-        }
-        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+        // the staged hit mask of the pair: this wave's strip is bits r0 .. r0 + 3 (r0 = 4 x strip).  Read unconditionally (idx < BATCH: a
+        // slot past the batch's end holds an older batch's word) and cleared by a select: predicates that come out of an `if` reach the
+        // ballots as 0 / 1 registers compared once more -- eight vector instructions per 64 pairs that four v_cmp already answered
+        const uint32_t hm_raw = s_bb[idx] >> (uint32_t)g.r0;
+        const uint32_t hm = idx < n ? hm_raw : 0u;
+        const bool h0 = (hm & 1u) != 0u, h1 = (hm & 2u) != 0u, h2 = (hm & 4u) != 0u, h3 = (hm & 8u) != 0u;
+        const unsigned long long m0 = ballot64(h0), m1 = ballot64(h1), m2 = ballot64(h2), m3 = ballot64(h3);
 #define GSWT_APPEND(H, M, CNT, G)                                                                                         \
         if (M) {                                                                                                            \
             if (H) wlist[(G) * kStride + (CNT) + __builtin_amdgcn_mbcnt_hi((uint32_t)((M) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)(M), 0u))] = (uint16_t)(idx * 16u); \
@@ -2112,7 +2116,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
             c0 = n0; c1 = n1;
         }
 #undef GSWT_DSTEP
-        if (EARLY && __ballot(T >= t_eps) == 0ull) wave_live = false;
+        if (EARLY && ballot64(T >= t_eps) == 0ull) wave_live = false;
         return;
     }
     // pad this group's list with the null record up to the wave's even step count (+2: the walk reads two entries ahead)
@@ -2142,7 +2146,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
         const float r2 = fmaf(pp.y, pp.y, pp.x * pp.x);                                             \
         bool cover = r2 <= 4.0f;                                                                    \
         if (DEPTH) cover = cover && DV < dbuf;                                                      \
-        if (__ballot(cover) != 0ull) {                                                              \
+        if (ballot64(cover) != 0ull) {                                                              \
             const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q1.z));           \
             const float Bv = cover ? e : 0.0f;                                                      \
             const float wgt = T * Bv;                                                               \
@@ -2168,7 +2172,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
         /* the blend runs under EXEC masking (s_and_saveexec on the coverage mask, skipped when no lane is covered): round 2 predicated it   \
            with a v_cndmask behind a wave-uniform ballot test; one VALU instruction less per step, 95.8 -> 93.0 us at c3 (round 3).           \
            (DPPW && PK: that older form, kept as a measurement variant of the -DGSWT_EXPERIMENTS build) */                                   \
-        if ((DPPW && PK) ? __ballot(cover) != 0ull : cover) {                                       \
+        if ((DPPW && PK) ? ballot64(cover) != 0ull : cover) {                                       \
             const float e = __builtin_amdgcn_exp2f(fmaf(r2, -1.4426950408889634f, Q0.w));           \
             const float Bv = (DPPW && PK) ? (cover ? e : 0.0f) : e;                                 \
             const float wgt = T * Bv;                                                               \
@@ -2212,7 +2216,7 @@ __device__ __forceinline__ void composite_bin_walk(const Frame& f, const CompLan
 #undef GSWT_RECD
     // Saturated pixels keep accumulating weights below t_eps (the oracle has no cut at all); the early-out is per wave
     // and per batch: once no pixel of the strip has T >= t_eps the wave stops binning and walking.
-    if (EARLY && __ballot(T >= t_eps) == 0ull) wave_live = false;
+    if (EARLY && ballot64(T >= t_eps) == 0ull) wave_live = false;
 }
 
 // Measured and dropped in the walk (all bit-identical, c3, base 97 us):
