@@ -285,6 +285,7 @@ def main():
     ap.add_argument("--composite", type=int, default=-1, help="GSWT_OPT_COMPOSITE: 0 k_composite + k_combine, 1 k_composite_dw (decoupled waves) + k_combine, "
                     "2 k_composite<FOLD> (no k_combine launch); default: the library's")
     ap.add_argument("--depth-sort", type=int, default=0, help="GSWT_OPT_DEPTH_SORT with --order depth: 0 auto, 1 global depth passes, 2 tile-local LDS sort")
+    ap.add_argument("--item-order", type=int, default=-1, help="GSWT_OPT_ITEM_ORDER: 0 the compositor's work items in tile order, 1 heaviest first")
     ap.add_argument("--no-chunk-cull", action="store_true", help="GSWT_OPT_NO_CHUNK_CULL: project every chunk of the draws that survive the tile cull (A/B of the per-chunk frustum cull)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0, help="CPU baseline: fly-path frames are rendered by the oracle until this much time has gone (at most 24 frames)")
     args = ap.parse_args()
@@ -345,6 +346,8 @@ def main():
         r.set_option(L.GSWT_OPT_DEPTH_SORT, args.depth_sort)
     if args.no_chunk_cull:
         r.set_option(L.GSWT_OPT_NO_CHUNK_CULL, 1)
+    if args.item_order >= 0:
+        r.set_option(L.GSWT_OPT_ITEM_ORDER, args.item_order)
     order_mode = L.GSWT_ORDER_DEPTH if args.order == "depth" else L.GSWT_ORDER_REFERENCE
     wang.upload_to(r)
     hmap = wang.height_map() if int(wang.user.surface_type) == 1 else None

@@ -36,6 +36,7 @@ GSWT_OPT_DEPTH_PASSES = 12
 GSWT_OPT_COMPOSITE = 13
 GSWT_OPT_DEPTH_SORT = 14
 GSWT_OPT_NO_CHUNK_CULL = 15
+GSWT_OPT_ITEM_ORDER = 16
 GSWT_SHARD_ROWS = 0
 GSWT_SHARD_COLUMNS = 1
 

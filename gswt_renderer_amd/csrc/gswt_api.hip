@@ -45,7 +45,7 @@ void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr,
                 const uint32_t* = nullptr, uint32_t* = nullptr, uint32_t* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
-                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t, uint32_t*, bool);
+                      uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t, uint32_t*, bool, bool);
 void launch_tile_depth_sort(hipStream_t, const uint2*, uint32_t*, const uint32_t*, int, uint32_t*, unsigned long long*);
 uint32_t tile_depth_sort_cap();
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
@@ -338,6 +338,7 @@ struct gswt_ctx {
     // GSWT_OPT_DEPTH_SORT: 0 / 2 = tile-local while every screen tile's list fits k_tile_depth_sort's LDS buffer (k_items reports the longest;
     // a frame that meets a longer one falls back by re-run), 1 = the global passes always.
     int opt_depth_sort = 0;
+    int opt_item_order = 0;               // GSWT_OPT_ITEM_ORDER: 1 = the compositor's work items heaviest first (k_items)
     uint32_t depth_max_tile_len = 0;       // longest tile list of the last finished depth-ordered frame (0: none yet -- try tile-local)
     unsigned long long stat_depth_local = 0, stat_depth_global = 0;     // depth-ordered frames enqueued on either path (re-runs included)
     int last_slot = 0;
@@ -645,6 +646,7 @@ try {
         if (value < 0 || value > 2) return fail(c, GSWT_ERR_BAD_ARG, "unknown compositor variant %d", value);
         c->opt_composite = value; return GSWT_OK;
     case GSWT_OPT_NO_CHUNK_CULL: c->opt_no_chunk_cull = value != 0; return GSWT_OK;
+    case GSWT_OPT_ITEM_ORDER: c->opt_item_order = value != 0; return GSWT_OK;
     case GSWT_OPT_DEPTH_SORT:
         if (value < 0 || value > 2) return fail(c, GSWT_ERR_BAD_ARG, "GSWT_OPT_DEPTH_SORT: 0 (auto), 1 (global passes) or 2 (tile-local)");
         c->opt_depth_sort = value; c->depth_max_tile_len = 0;
@@ -1523,7 +1525,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // ---- composite
     launch_composite(s, f, sl.ranges.p, vals_sorted, sl.recs.p, sl.depths.p, sl.col_f.p, a.d_bg, a.d_bgd, d_out, n_tiles, out_rows, seg, cap,
                      sl.item_base.p, sl.item_tab.p, sl.partials.p, c->opt_timing >= 1 ? ev[7] : nullptr, c->opt_timing >= 1 ? ev[8] : nullptr,
-                     d_counters, sl.hc_dev, c->opt_composite, depth_order && !sl.depth_local ? d_krange : nullptr, sl.depth_passes, d_tile_tick, depth_order);
+                     d_counters, sl.hc_dev, c->opt_composite, depth_order && !sl.depth_local ? d_krange : nullptr, sl.depth_passes, d_tile_tick, depth_order,
+                     c->opt_item_order != 0);
     c->last_n_tiles = (uint32_t)n_tiles;
     c->last_slot = (int)(&sl - c->slots);
     if (c->opt_timing >= 1) HIP_TRY(c, hipEventRecord(ev[6], s));

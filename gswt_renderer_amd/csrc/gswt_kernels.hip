@@ -1880,6 +1880,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_depth_sort(const uint2* __rest
 // tens of thousands): one launch instead of count + 3 scan launches.
 // GSWT_ORDER_DEPTH (krange != nullptr): also the depth sort's pass check -- counters[2] = 8-bit passes this frame's depth range needs; more
 // than were launched = the pair list is not in depth order: the frame is flagged (counters[3]) and the host re-runs it with more passes.
+template <bool HEAVY>
 __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges, int n_tiles, uint32_t seg,
                                                 uint32_t* __restrict__ item_base, uint4* __restrict__ item_tab, uint32_t max_items,
                                                 const uint32_t* __restrict__ krange, uint32_t n_launched, unsigned long long* __restrict__ counters,
@@ -1961,16 +1962,87 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
         if (lane == 63u) s_tot = pi;
     }
     __syncthreads();
+    if (!HEAVY) {
 #pragma unroll
-    for (int j = 0; j < kPer; j++) {
-        const int t = base + j * 1024 + (int)threadIdx.x;
-        if (t < n_tiles) {
+        for (int j = 0; j < kPer; j++) {
+            const int t = base + j * 1024 + (int)threadIdx.x;
+            if (t < n_tiles) {
+                const uint32_t first = carry + s_t[j * 16 + (int)w] + inc[j] - cnt[j];
+                item_base[t] = first;
+                const uint32_t multi = cnt[j] > 1u ? 1u : 0u;
+                for (uint32_t k = 0; k < cnt[j] && first + k < max_items; k++) {
+                    const uint32_t a = r[j].x + k * seg;
+                    item_tab[first + k] = make_uint4((uint32_t)t, (k << 1) | multi, a, min(r[j].y, a + seg));
+                }
+            }
+        }
+    } else {
+        // GSWT_OPT_ITEM_ORDER = 1, heaviest first: the compositor's workgroups start in table order, so the table lists the work items by
+        // falling length -- class 0: the full segments (`seg` pairs), classes 1 .. 15: the last (or only) segment of a tile by sixteenths of
+        // `seg` -- and the short ones fill the slots the long ones leave.  item_base[t] stays the tile's first PARTIAL slot (k_composite
+        // writes a segment's partial to item_base[tile] + segment, k_combine reads them from there): only the hand-out order changes.  Inside a
+        // class the order is whatever the waves' LDS atomics make it (the image does not depend on it).  A workgroup orders the items of its
+        // own 8 192 tiles (c3: the frame's; c5: a quarter's).
+        constexpr uint32_t kCls = 16u;
+        __shared__ uint32_t s_cls[kCls], s_off[kCls];
+        if (threadIdx.x < kCls) s_cls[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t full[kPer], rcls[kPer];                 // full segments of the tile; class of its remainder item (kCls: none)
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const uint32_t len = r[j].y - r[j].x;
+            full[j] = cnt[j] ? (seg_pow2 ? len >> seg_sh : len / seg) : 0u;
+            const uint32_t rem = len - full[j] * seg;
+            rcls[j] = cnt[j] > full[j] ? (rem ? (kCls - 1u) - min(kCls - 1u, ((rem - 1u) * kCls) / seg) : kCls - 1u) : kCls;
+            if (rcls[j] == 0u) rcls[j] = 1u;             // (class 0 is the full segments' alone: its slots are handed out by a scan)
+        }
+        // per-class counts: one LDS atomic per wave and class present
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            uint32_t fs = full[j];
+            for (int o = 32; o > 0; o >>= 1) fs += (uint32_t)__shfl_down((int)fs, o, 64);
+            if (lane == 0u && fs) atomicAdd(&s_cls[0], fs);
+            unsigned long long left = ballot64(rcls[j] < kCls);
+            while (left) {
+                const uint32_t c = (uint32_t)__shfl((int)rcls[j], (int)__ffsll((long long)left) - 1, 64);
+                const unsigned long long m = ballot64(rcls[j] == c);
+                if (lane == 0u) atomicAdd(&s_cls[c], (uint32_t)__popcll(m));
+                left &= ~m;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0u) { uint32_t a = 0; for (uint32_t c = 0; c < kCls; c++) { s_off[c] = a; a += s_cls[c]; } }
+        __syncthreads();
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int t = base + j * 1024 + (int)threadIdx.x;
             const uint32_t first = carry + s_t[j * 16 + (int)w] + inc[j] - cnt[j];
-            item_base[t] = first;
+            if (t < n_tiles) item_base[t] = first;
             const uint32_t multi = cnt[j] > 1u ? 1u : 0u;
-            for (uint32_t k = 0; k < cnt[j] && first + k < max_items; k++) {
-                const uint32_t a = r[j].x + k * seg;
-                item_tab[first + k] = make_uint4((uint32_t)t, (k << 1) | multi, a, min(r[j].y, a + seg));
+            // the full segments: a wave scan of their counts, one LDS atomic per wave for the run of slots
+            const uint32_t fi = wave_incl_scan(full[j], lane);
+            uint32_t fb = 0;
+            if (lane == 63u && fi) fb = atomicAdd(&s_off[0], fi);
+            fb = (uint32_t)__shfl((int)fb, 63, 64) + fi - full[j];
+            for (uint32_t k = 0; k < full[j]; k++) {
+                const uint32_t a = r[j].x + k * seg, pos = carry + fb + k;
+                if (pos < max_items) item_tab[pos] = make_uint4((uint32_t)t, (k << 1) | multi, a, a + seg);
+            }
+            // the remainder items, class by class
+            unsigned long long left = ballot64(rcls[j] < kCls);
+            while (left) {
+                const int src = (int)__ffsll((long long)left) - 1;
+                const uint32_t c = (uint32_t)__shfl((int)rcls[j], src, 64);
+                const unsigned long long m = ballot64(rcls[j] == c);
+                uint32_t pb = 0;
+                if (lane == (uint32_t)src) pb = atomicAdd(&s_off[c], (uint32_t)__popcll(m));
+                pb = (uint32_t)__shfl((int)pb, src, 64);
+                if (rcls[j] == c) {
+                    const uint32_t k = full[j], a = r[j].x + k * seg, pos = carry + pb + (uint32_t)__popcll(m & lt);
+                    if (pos < max_items) item_tab[pos] = make_uint4((uint32_t)t, (k << 1) | multi, a, r[j].y);
+                }
+                left &= ~m;
             }
         }
     }
@@ -2418,13 +2490,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     GSWT_TR(6, tr_walk)
     const float k255 = 1.0f / 255.0f;      // colour is continuous: sum(w * byte) / 255 vs sum(w * (byte / 255)) differ in the last bits only
     if (!COLF) { ar *= k255; ag *= k255; ab *= k255; }
+    // (the partial's slot: the tile's first + the segment's number -- the table position only while the table is in tile order)
+    const uint32_t pslot = multi_seg ? item_base[tile] + (it.y >> 1) : 0u;
     if (multi_seg && !FOLD) {
         // partial (C, T) of this segment; k_combine folds the segments front to back
-        partials[(size_t)item * 256u + tid] = make_float4(ar, ag, ab, T);
+        partials[(size_t)pslot * 256u + tid] = make_float4(ar, ag, ab, T);
         return;
     }
     if (multi_seg && FOLD) {
-        float* const pp = reinterpret_cast<float*>(partials + (size_t)item * 256u + tid);
+        float* const pp = reinterpret_cast<float*>(partials + (size_t)pslot * 256u + tid);
         __hip_atomic_store(pp + 0, ar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(pp + 1, ag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(pp + 2, ab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2657,7 +2731,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(COLF ? 6 : 
     const float k255 = 1.0f / 255.0f;
     if (!COLF) { ar *= k255; ag *= k255; ab *= k255; }
     if (multi_seg) {
-        partials[(size_t)item * 256u + tid] = make_float4(ar, ag, ab, T);
+        partials[(size_t)(item_base[tile] + (it.y >> 1)) * 256u + tid] = make_float4(ar, ag, ab, T);      // (k_composite: pslot)
         return;
     }
     uint32_t tid2 = threadIdx.x;
@@ -2924,7 +2998,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
                       const float4* col_f, const float4* bg_rgba, const float* bg_depth, float4* out, int n_tiles, int out_rows,
                       uint32_t seg, uint32_t n_pairs, uint32_t* item_base, uint4* item_tab, float4* partials,
                       hipEvent_t ev_begin, hipEvent_t ev_end, unsigned long long* counters, unsigned long long* host_counters, int variant,
-                      const uint32_t* krange, uint32_t depth_passes, uint32_t* tile_tick, bool report_max)
+                      const uint32_t* krange, uint32_t depth_passes, uint32_t* tile_tick, bool report_max, bool heavy_first)
 {
     if (n_tiles == 0) {                 // a shard without screen tiles (more ranks than tile columns): the events still exist
         if (ev_begin) hipEventRecord(ev_begin, s);
@@ -2934,8 +3008,13 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     const uint32_t max_items = (uint32_t)n_tiles + n_pairs / seg + 1u;
     // variant 2 (GSWT_OPT_FOLD_COMBINE): k_composite folds the segment partials itself and writes the empty tiles: no k_combine launch
     const bool fold = variant == 2 && tile_tick != nullptr && host_counters != nullptr;
-    GSWT_LAUNCH(k_items, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items, krange, depth_passes, counters,
+    if (heavy_first) {
+        GSWT_LAUNCH(k_items<true>, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items, krange, depth_passes, counters,
                 fold ? 1u : 0u, report_max ? 1u : 0u);
+    } else {
+        GSWT_LAUNCH(k_items<false>, dim3((n_tiles + 8191) / 8192), dim3(1024), s, ranges, n_tiles, seg, item_base, item_tab, max_items, krange, depth_passes, counters,
+                fold ? 1u : 0u, report_max ? 1u : 0u);
+    }
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
     if (ev_begin) hipEventRecord(ev_begin, s);
 #ifdef GSWT_EXPERIMENTS

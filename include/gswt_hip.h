@@ -208,7 +208,9 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                    bit */,
        GSWT_OPT_NO_CHUNK_CULL = 15 /* 1: the per-chunk frustum cull in front of the projection is off (every 256-entry chunk of a draw that
                                       survives the reference's tile cull is projected, as until round 3).  Same image bit for bit: the cull
-                                      only leaves out chunks none of whose splats vs_main's own frustum test (gswt.wgsl:163-167) would keep */ };
+                                      only leaves out chunks none of whose splats vs_main's own frustum test (gswt.wgsl:163-167) would keep */,
+       GSWT_OPT_ITEM_ORDER = 16 /* order in which the compositor's work items (screen tile, segment of its pair list) are handed out: 0 = tile
+                                  order, 1 = heaviest first (full segments, then the remainders by falling length).  Same image bit for bit */ };
 GSWT_API int gswt_set_option(gswt_ctx *ctx, int key, int value);
 
 /* GSWTRenderer::new (renderer.rs:31-349): uploads PreloadData.tile_splats_merged.tex_data

@@ -112,3 +112,32 @@ def test_folded_combine_variants(renderer, kw):
     assert np.array_equal(b, c)                          # same segment length: bit-identical with and without k_combine
     assert np.abs(b.astype(np.float64) - ref).max() <= 1e-4 + kw.get("t_eps", 0.0)
     assert np.abs(a.astype(np.float64) - b).max() <= 2e-6 + kw.get("t_eps", 0.0)      # another segment length regroups the fold
+
+
+@pytest.mark.parametrize("name,seg", [("c3", 1536), ("c3", 256), ("c3d", 4096)])
+def test_heaviest_first_item_order_bit_identical(renderer, name, seg):
+    """GSWT_OPT_ITEM_ORDER = 1: k_items lists the compositor's work items by falling length (full segments first) instead of in tile order;
+    a segment's partial still goes to its tile's slot + its number, so the image is the same bit for bit under all three compositors, with
+    and without the early-out, in both orders of the pairs."""
+    import bench
+    w, wang, cu, vp, sort = bench.build_workload(name)
+    W, Hh = w["width"], w["height"]
+    su = wang.scene_uniforms()
+    wang.upload_to(renderer)
+    renderer.configure(None)
+    renderer.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
+    renderer.set_option(L.GSWT_OPT_SEGMENT, seg)
+    try:
+        for variant in (0, 1, 2):
+            renderer.set_option(L.GSWT_OPT_COMPOSITE, variant)
+            for kw in (dict(), dict(transmittance_eps=1e-5), dict(order_mode=L.GSWT_ORDER_DEPTH)):
+                renderer.set_option(L.GSWT_OPT_ITEM_ORDER, 0)
+                a = renderer.render(cu, su, W, Hh, **kw)
+                renderer.set_option(L.GSWT_OPT_ITEM_ORDER, 1)
+                b = renderer.render(cu, su, W, Hh, **kw)
+                assert a[..., 3].max() > 0.5
+                assert np.array_equal(a, b), (name, seg, variant, kw, float(np.abs(a - b).max()))
+    finally:
+        renderer.set_option(L.GSWT_OPT_SEGMENT, L.GSWT_DEFAULT_SEGMENT)
+        renderer.set_option(L.GSWT_OPT_COMPOSITE, 0)
+        renderer.set_option(L.GSWT_OPT_ITEM_ORDER, 0)

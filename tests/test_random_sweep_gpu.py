@@ -49,7 +49,7 @@ def _cases():
             rc["point_cloud_radius"] = 0.003
         # round 4: the order mode (reference / global depth sort) and the compositor variant (k_composite + k_combine, decoupled waves,
         # folded combine) rotate through the cases too
-        mode = dict(order_mode=int(k % 4 == 1), composite=(0, 1, 2)[k % 3], depth_sort=(0, 1)[(k // 4) % 2])
+        mode = dict(order_mode=int(k % 4 == 1), composite=(0, 1, 2)[k % 3], depth_sort=(0, 1)[(k // 4) % 2], item_order=(k // 2) % 2)
         out.append(pytest.param(cfg, (tuple(float(x) for x in pos), tuple(float(x) for x in tgt)), rc, bool(k % 3 == 0), mode, id=f"case{k}"))
     return out
 
@@ -61,10 +61,12 @@ def test_random_sweep(renderer, cfg, cam, rc, bg, mode):
     t_eps = 1e-5 if cfg["surface_type"] == 0 else 0.0
     renderer.set_option(L.GSWT_OPT_COMPOSITE, mode["composite"])
     renderer.set_option(L.GSWT_OPT_DEPTH_SORT, mode["depth_sort"])     # (depth-ordered cases: global passes / tile-local LDS sort)
+    renderer.set_option(L.GSWT_OPT_ITEM_ORDER, mode["item_order"])
     try:
         with np.errstate(all="ignore"):
             img, ref, kinds, st = _run_case(renderer, cfg, cam, W, Hh, lod0=500, bg=bg, render_config=rc, t_eps=t_eps, order_mode=mode["order_mode"])
     finally:
         renderer.set_option(L.GSWT_OPT_COMPOSITE, 0)
         renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 0)
+        renderer.set_option(L.GSWT_OPT_ITEM_ORDER, 0)
     assert H.max_abs_diff(img, ref) <= TOL + t_eps, (cfg, cam, rc, mode, kinds, st)

@@ -23,6 +23,8 @@ if os.environ.get("GSWT_VS", "") == "v2":
     r.set_option(L.GSWT_OPT_STRICT_VS, 0)
 if os.environ.get("GSWT_NO_CHUNK_CULL"):
     r.set_option(L.GSWT_OPT_NO_CHUNK_CULL, 1)
+if os.environ.get("GSWT_ITEM_ORDER"):
+    r.set_option(L.GSWT_OPT_ITEM_ORDER, int(os.environ["GSWT_ITEM_ORDER"]))
 if os.environ.get("GSWT_DEPTH_SORT"):
     r.set_option(L.GSWT_OPT_DEPTH_SORT, int(os.environ["GSWT_DEPTH_SORT"]))
 if os.environ.get("GSWT_COMPOSITE"):
