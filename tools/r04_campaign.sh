@@ -20,11 +20,16 @@ if has lines; then
   timeout -k 10 300 python bench.py --graph --no-cpu-baseline > $O/bench_c3_graph.json 2>> $O/bench_c3.err; line $O/bench_c3_graph.json
   timeout -k 10 400 python bench.py --order depth > $O/bench_c3_depth.json 2> $O/bench_c3_depth.err; line $O/bench_c3_depth.json
   timeout -k 10 300 python bench.py --order depth --graph --no-cpu-baseline > $O/bench_c3_depth_graph.json 2>> $O/bench_c3_depth.err; line $O/bench_c3_depth_graph.json
+  timeout -k 10 300 python bench.py --order depth --depth-sort 1 --no-cpu-baseline > $O/bench_c3_depth_global_passes.json 2>> $O/bench_c3_depth.err; line $O/bench_c3_depth_global_passes.json
+  timeout -k 10 300 python bench.py --no-chunk-cull --no-cpu-baseline > $O/bench_c3_no_chunk_cull.json 2>> $O/bench_c3.err; line $O/bench_c3_no_chunk_cull.json
   timeout -k 10 300 python bench.py --vertex-stage v2 --no-cpu-baseline > $O/bench_c3_v2.json 2>> $O/bench_c3.err; line $O/bench_c3_v2.json
   timeout -k 10 400 python bench.py --workload c3d > $O/bench_c3d.json 2> $O/bench_c3d.err; line $O/bench_c3d.json
   timeout -k 10 300 python bench.py --workload c3d --composite 1 --no-cpu-baseline > $O/bench_c3d_dw.json 2>> $O/bench_c3d.err; line $O/bench_c3d_dw.json
   timeout -k 10 300 python bench.py --workload c3d --order depth --no-cpu-baseline > $O/bench_c3d_depth.json 2>> $O/bench_c3d.err; line $O/bench_c3d_depth.json
+  timeout -k 10 300 python bench.py --workload c3d --order depth --depth-sort 1 --no-cpu-baseline > $O/bench_c3d_depth_global_passes.json 2>> $O/bench_c3d.err; line $O/bench_c3d_depth_global_passes.json
   timeout -k 10 300 python bench.py --workload c3h --no-cpu-baseline > $O/bench_c3h.json 2> $O/bench_c3h.err; line $O/bench_c3h.json
+  timeout -k 10 300 python bench.py --workload c3h --no-chunk-cull --no-cpu-baseline > $O/bench_c3h_no_chunk_cull.json 2>> $O/bench_c3h.err; line $O/bench_c3h_no_chunk_cull.json
+  timeout -k 10 400 python bench.py --workload c5 --no-chunk-cull --no-cpu-baseline > $O/bench_c5_no_chunk_cull.json 2>> $O/bench_c5.err; line $O/bench_c5_no_chunk_cull.json
   timeout -k 10 400 python bench.py --workload c3s > $O/bench_c3s.json 2> $O/bench_c3s.err; line $O/bench_c3s.json
   timeout -k 10 600 python bench.py --workload c5 > $O/bench_c5_passes.json 2> $O/bench_c5.err; line $O/bench_c5_passes.json
   timeout -k 10 400 python bench.py --workload c5 --order depth --no-cpu-baseline > $O/bench_c5_depth.json 2>> $O/bench_c5.err; line $O/bench_c5_depth.json
@@ -44,6 +49,14 @@ if has serial; then
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_$WL -- python3 tools/serial_frames.py $WL 20 > $O/serial_$WL.log 2>&1
     python3 tools/pmc_summary.py stats $(find $O/serial_$WL -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial_$WL.csv; rm -rf $O/serial_$WL
   done
+  for WL in c3 c3h c5; do
+    GSWT_NO_CHUNK_CULL=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_n$WL -- python3 tools/serial_frames.py $WL 20 > $O/serial_nocull_$WL.log 2>&1
+    python3 tools/pmc_summary.py stats $(find $O/serial_n$WL -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial_${WL}_no_chunk_cull.csv; rm -rf $O/serial_n$WL
+  done
+  for WL in c3 c3d; do
+    GSWT_ORDER=depth GSWT_DEPTH_SORT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_g$WL -- python3 tools/serial_frames.py $WL 20 > $O/serial_depth_global_$WL.log 2>&1
+    python3 tools/pmc_summary.py stats $(find $O/serial_g$WL -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial_${WL}_depth_global_passes.csv; rm -rf $O/serial_g$WL
+  done
   for WL in c3 c3d c5; do
     GSWT_ORDER=depth rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial_d$WL -- python3 tools/serial_frames.py $WL 20 > $O/serial_depth_$WL.log 2>&1
     python3 tools/pmc_summary.py stats $(find $O/serial_d$WL -name "*kernel_stats.csv" | head -1) $O/kernel_stats_serial_${WL}_depth.csv; rm -rf $O/serial_d$WL
@@ -52,6 +65,7 @@ if has serial; then
 fi
 if has shard; then
   timeout -k 10 300 python tools/shard_emulation.py c3 100 > $O/shard_emulation_c3.txt 2>&1; tail -12 $O/shard_emulation_c3.txt
+  timeout -k 10 100 python3 tools/tile_lengths.py c3 c3d c3h > $O/tile_lengths.txt 2>&1
   GSWT_GRAPH=1 timeout -k 10 300 python tools/shard_emulation.py c3 100 > $O/shard_emulation_c3_graph.txt 2>&1; tail -8 $O/shard_emulation_c3_graph.txt
 fi
 echo campaign done
