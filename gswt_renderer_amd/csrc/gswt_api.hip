@@ -315,7 +315,7 @@ struct gswt_ctx {
     // GSWT_OPT_COMPOSITE: 0 = k_composite + k_combine, 1 = k_composite_dw (decoupled waves) + k_combine, 2 = k_composite<FOLD>: the last
     // segment of a tile to finish folds the partials, empty tiles are work items, no k_combine launch
     int opt_composite = 0;
-    int opt_no_chunk_cull = 0;             // GSWT_OPT_NO_CHUNK_CULL: k_live keeps every chunk of a surviving draw (A/B and tests: same image)
+    int opt_no_chunk_cull = 0;             // GSWT_OPT_NO_CHUNK_CULL: k_cull keeps every chunk of a surviving draw (A/B and tests: same image)
     unsigned long long stat_graph_launches = 0, stat_graph_rebuilds = 0, stat_graph_node_updates = 0;
     int pending_frames = 0;                // GSWT_OPT_DEFER_SWAP >= 2: frames still to be submitted on the old set
     int merge_target = 0;                  // gswt_set_draws_merge_groups -> set_draws_impl: the set being filled

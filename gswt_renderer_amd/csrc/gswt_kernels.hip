@@ -328,21 +328,74 @@ __device__ __forceinline__ bool band_misses(const Frame& f, const float lo[3], c
     return xmax + rad < (float)(f.col0 * kTile) || xmin - rad >= (float)(f.col1 * kTile);
 }
 
-// Also clears the per-frame accumulators (first kernel of the frame; saves three memset launches).
+// The CPU viewport culling + lod_enable skip of renderer.rs:472-497 for one draw (+ the band cull of a column-band shard).
 // Band culling works on MAP CELLS: every splat of a Wang-tile instance lies in (cell origin + the scene's tile-local position
 // bounds), f.loc_lo .. f.loc_hi, so a plain / blending draw is tested with its own offset and the members of a merged group
 // through cell_culled[map id] (k_project skips such entries before gathering their records): the heaviest band no longer
 // projects whole merged groups that merely touch it.  No per-sort-event bounds pass.
-__global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __restrict__ draws, uint32_t n_draws,
-                                              uint32_t* __restrict__ draw_culled, uint32_t* __restrict__ cell_culled, uint32_t n_cells,
-                                              uint32_t* __restrict__ zero_a, uint32_t n_zero_a,
-                                              uint32_t* __restrict__ zero_b, uint32_t n_zero_b,
-                                              uint32_t* __restrict__ zero_c, uint32_t n_zero_c,
-                                              uint32_t* __restrict__ zero_d, uint32_t n_zero_d)
+__device__ __forceinline__ bool draw_is_culled(const Frame& f, const DrawDev& d)
 {
-    // eight lanes per draw (they used to fill the draw's range of the live-chunk table together; k_live builds that table now, chunk by chunk)
+    bool culled = false;
+    if (d.cull_enable) {
+        float mx = 3.402823466e+38f, my = 3.402823466e+38f, mz = -3.402823466e+38f;
+        for (int ci = 0; ci < 4; ci++) {
+            float px = d.corners[3 * ci], py = d.corners[3 * ci + 1], pz = d.corners[3 * ci + 2];
+            float c4[4];
+            for (int r = 0; r < 4; r++)
+                c4[r] = ((f.VP[r] * px + f.VP[4 + r] * py) + f.VP[8 + r] * pz) + f.VP[12 + r] * 1.0f;
+            float cx = c4[0] / c4[3], cy = c4[1] / c4[3], cz = c4[2] / c4[3];
+            if (fabsf(cx) < mx) mx = fabsf(cx);
+            if (fabsf(cy) < my) my = fabsf(cy);
+            if (cz > mz) mz = cz;
+        }
+        float clip = f.culling_dist;
+        if (mz < -clip || mx > clip || my > clip) culled = true;
+    }
+    if (!((f.lod_enable_mask >> (d.lod & 31u)) & 1u)) culled = true;
+    // Column-band sharding: drop the draw when none of its splats can touch this rank's pixel columns.  (Doing the same
+    // cull on the host and launching k_project / k_emit over the surviving chunks only was measured: no gain -- the
+    // workgroups of culled chunks exit at once and the frames overlap.)
+    if (!culled && f.band_cull && d.count && d.single_draw != 1u) {
+        const float lo[3] = {f.loc_lo[0] + d.off[0], f.loc_lo[1] + d.off[1], f.loc_lo[2] + d.off[2]};
+        const float hi[3] = {f.loc_hi[0] + d.off[0], f.loc_hi[1] + d.off[1], f.loc_hi[2] + d.off[2]};
+        float bidx = 0.0f, bidy = 0.0f;
+        if (f.surface_type == 2u) {
+            bidx = (float)(5u * d.map_coord[0] / (f.map_half_wh[0] * 2u));
+            bidy = (float)(2u * d.map_coord[1] / (f.map_half_wh[1] * 2u));
+        }
+        if (band_misses(f, lo, hi, bidx, bidy)) culled = true;
+    }
+    return culled;
+}
+
+// ------------------------------------------------------------------------------------
+// k_cull (first kernel of the frame): clears the per-frame accumulators (saves three memset launches), fills the band-cull table of a
+// column-band shard, and builds the launch table of k_project for THIS frame, one thread per chunk (a chunk = 256 list entries of one draw): only the chunks of
+// the draws that survive the reference's per-draw cull (draw_is_culled: every chunk's thread evaluates its own draw's -- until late in round 4 a
+// kernel of its own in front of this one, one launch and ~6 us more), in the per-XCD layout of chunk_tab_xcd (position k * 8 + x runs on XCD x = draw % 8; the order inside an
+// XCD's list is the order of the atomic adds: irrelevant, a chunk's output slots are fixed).  An entry carries what the chunk's first load
+// needs -- the list position of its lane 0 and the list's length and arena -- so that k_project's list-word load does not wait for the draw record.
+// Round 4: CHUNK-LEVEL FRUSTUM CULL.  The reference culls whole tile draws on the CPU (renderer.rs:472-494: min |x|, min |y|, max z of the four
+// corner NDCs, which lets every tile through that has one corner near the view axis), and vs_main then drops splat by splat
+// (gswt.wgsl:163-167).  A draw's list is presorted by depth, so a chunk of it is a slab of the tile: measured on the c3 frame, 49 % of the
+// chunks of the surviving draws hold NO splat that passes vs_main's frustum test -- half of k_project's live workgroups gathered 256 records
+// to find that out.  Every static list carries the tile-local bounding box of each of its chunks (gswt_upload_scene); a chunk whose box,
+// moved to the draw's offset, lies on the far side of ONE of the five planes of that test at all eight corners (clip-space coordinates are
+// affine in the position, so then at every point of the box; a relative margin of 1e-3 covers the rounding of both evaluations) is left out
+// of the table.  Nothing that vs_main would keep is dropped: images, visible and pair counts are bit-identical (GSWT_OPT_NO_CHUNK_CULL).
+// Plain and HeightMap surfaces (the Sphere mapping moves a splat far from its flat position: no cull there); merged groups carry no boxes
+// yet (their lists are rebuilt per sort event and mix member tiles) and stay whole.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __restrict__ draws, uint32_t* __restrict__ draw_culled,
+                                              uint32_t* __restrict__ cell_culled, uint32_t n_cells,
+                                              uint32_t* __restrict__ zero_a, uint32_t n_zero_a, uint32_t* __restrict__ zero_b, uint32_t n_zero_b,
+                                              uint32_t* __restrict__ zero_c, uint32_t n_zero_c, uint32_t* __restrict__ zero_d, uint32_t n_zero_d,
+                                              const uint2* __restrict__ chunk_tab, uint32_t n_chunks, const float* __restrict__ boxes, uint32_t chunk_cull,
+                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab)
+{
+    __shared__ uint32_t s_cnt[8], s_base[8];
+    if (threadIdx.x < 8u) s_cnt[threadIdx.x] = 0u;
     const uint32_t gtid = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t i = gtid >> 3, sub = gtid & 7u;
     for (uint32_t j = gtid; j < n_zero_a; j += gridDim.x * 256u) zero_a[j] = 0u;
     for (uint32_t j = gtid; j < n_zero_b; j += gridDim.x * 256u) zero_b[j] = 0u;
     for (uint32_t j = gtid; j < n_zero_c; j += gridDim.x * 256u) zero_c[j] = 0u;       // per-chunk pair counts: culled chunks never run
@@ -363,63 +416,6 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
             cell_culled[j] = band_misses(f, lo, hi, bidx, bidy) ? 1u : 0u;
         }
     }
-    const bool have = i < n_draws;
-    const DrawDev& d = draws[have ? i : 0u];
-    uint32_t culled = 0;
-    if (d.cull_enable) {
-        float mx = 3.402823466e+38f, my = 3.402823466e+38f, mz = -3.402823466e+38f;
-        for (int ci = 0; ci < 4; ci++) {
-            float px = d.corners[3 * ci], py = d.corners[3 * ci + 1], pz = d.corners[3 * ci + 2];
-            float c4[4];
-            for (int r = 0; r < 4; r++)
-                c4[r] = ((f.VP[r] * px + f.VP[4 + r] * py) + f.VP[8 + r] * pz) + f.VP[12 + r] * 1.0f;
-            float cx = c4[0] / c4[3], cy = c4[1] / c4[3], cz = c4[2] / c4[3];
-            if (fabsf(cx) < mx) mx = fabsf(cx);
-            if (fabsf(cy) < my) my = fabsf(cy);
-            if (cz > mz) mz = cz;
-        }
-        float clip = f.culling_dist;
-        if (mz < -clip || mx > clip || my > clip) culled = 1;
-    }
-    if (!((f.lod_enable_mask >> (d.lod & 31u)) & 1u)) culled = 1;
-    // Column-band sharding: drop the draw when none of its splats can touch this rank's pixel columns.  (Doing the same
-    // cull on the host and launching k_project / k_emit over the surviving chunks only was measured: no gain -- the
-    // workgroups of culled chunks exit at once and the frames overlap.)
-    if (!culled && f.band_cull && d.count && d.single_draw != 1u) {
-        const float lo[3] = {f.loc_lo[0] + d.off[0], f.loc_lo[1] + d.off[1], f.loc_lo[2] + d.off[2]};
-        const float hi[3] = {f.loc_hi[0] + d.off[0], f.loc_hi[1] + d.off[1], f.loc_hi[2] + d.off[2]};
-        float bidx = 0.0f, bidy = 0.0f;
-        if (f.surface_type == 2u) {
-            bidx = (float)(5u * d.map_coord[0] / (f.map_half_wh[0] * 2u));
-            bidy = (float)(2u * d.map_coord[1] / (f.map_half_wh[1] * 2u));
-        }
-        if (band_misses(f, lo, hi, bidx, bidy)) culled = 1;
-    }
-    if (have && sub == 0u) draw_culled[i] = culled;
-}
-
-// ------------------------------------------------------------------------------------
-// k_live: the launch table of k_project for THIS frame, one thread per chunk (a chunk = 256 list entries of one draw): only the chunks of
-// the draws that survive k_cull, in the per-XCD layout of chunk_tab_xcd (position k * 8 + x runs on XCD x = draw % 8; the order inside an
-// XCD's list is the order of the atomic adds: irrelevant, a chunk's output slots are fixed).  An entry carries what the chunk's first load
-// needs -- the list position of its lane 0 and the list's length and arena -- so that k_project's list-word load does not wait for the draw record.
-// Round 4: CHUNK-LEVEL FRUSTUM CULL.  The reference culls whole tile draws on the CPU (renderer.rs:472-494: min |x|, min |y|, max z of the four
-// corner NDCs, which lets every tile through that has one corner near the view axis), and vs_main then drops splat by splat
-// (gswt.wgsl:163-167).  A draw's list is presorted by depth, so a chunk of it is a slab of the tile: measured on the c3 frame, 49 % of the
-// chunks of the surviving draws hold NO splat that passes vs_main's frustum test -- half of k_project's live workgroups gathered 256 records
-// to find that out.  Every static list carries the tile-local bounding box of each of its chunks (gswt_upload_scene); a chunk whose box,
-// moved to the draw's offset, lies on the far side of ONE of the five planes of that test at all eight corners (clip-space coordinates are
-// affine in the position, so then at every point of the box; a relative margin of 1e-3 covers the rounding of both evaluations) is left out
-// of the table.  Nothing that vs_main would keep is dropped: images, visible and pair counts are bit-identical (GSWT_OPT_NO_CHUNK_CULL).
-// Plain and HeightMap surfaces (the Sphere mapping moves a splat far from its flat position: no cull there); merged groups carry no boxes
-// yet (their lists are rebuilt per sort event and mix member tiles) and stay whole.
-// ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_live(const Frame f, const DrawDev* __restrict__ draws, const uint2* __restrict__ chunk_tab, uint32_t n_chunks,
-                                              const uint32_t* __restrict__ draw_culled, const float* __restrict__ boxes, uint32_t chunk_cull,
-                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab)
-{
-    __shared__ uint32_t s_cnt[8], s_base[8];
-    if (threadIdx.x < 8u) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t c = blockIdx.x * 256u + threadIdx.x;
     bool live = false;
@@ -428,7 +424,9 @@ __global__ __launch_bounds__(256) void k_live(const Frame f, const DrawDev* __re
     if (c < n_chunks) {
         const uint2 ct = chunk_tab[c];
         const DrawDev& d = draws[ct.x];
-        live = draw_culled[ct.x] == 0u && d.count != 0u;
+        const bool dc = draw_is_culled(f, d);
+        if (ct.y == 0u) draw_culled[ct.x] = dc ? 1u : 0u;      // (read by the debug-varyings build of k_project only)
+        live = !dc && d.count != 0u;
         if (live && chunk_cull && d.merged == 0u && d.box_base != 0xFFFFFFFFu && f.surface_type <= 1u) {
             const float* b = boxes + 6u * (size_t)(d.box_base + (ct.y >> 8));
             float lo[3], hi[3];
@@ -2847,11 +2845,11 @@ void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n
                  uint32_t* live_cnt, uint4* live_tab, uint32_t* zero_d, uint32_t n_zero_d,
                  const uint2* chunk_tab, uint32_t n_chunks, const float* boxes, bool chunk_cull)
 {
-    uint32_t grid = (n_draws * 8u + 255u) / 256u;          // eight lanes per draw
+    (void)n_draws;
+    uint32_t grid = (n_chunks + 255u) / 256u;              // one thread per chunk; the clears and the cell table stride over the grid
     if (grid < 32) grid = 32;
-    GSWT_LAUNCH(k_cull, dim3(grid), dim3(256), s, f, draws, n_draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, zero_d, n_zero_d);
-    if (n_chunks) GSWT_LAUNCH(k_live, dim3((n_chunks + 255u) / 256u), dim3(256), s, f, draws, chunk_tab, n_chunks, (const uint32_t*)draw_culled, boxes,
-                              chunk_cull && boxes ? 1u : 0u, live_cnt, live_tab);
+    GSWT_LAUNCH(k_cull, dim3(grid), dim3(256), s, f, draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, zero_d, n_zero_d,
+                chunk_tab, n_chunks, boxes, chunk_cull && boxes ? 1u : 0u, live_cnt, live_tab);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,

@@ -57,7 +57,7 @@ def test_baseline_config_matches_oracle(renderer, name):
     # what bench.py times: front-to-back early termination at 1e-5
     img_e = pipe.render(s["cu"], W, Hh, transmittance_eps=1e-5)
     assert H.max_abs_diff(img_e, ref) <= TOL
-    # the per-chunk frustum cull in front of the projection (k_live) only leaves out chunks none of whose splats vs_main would keep: same bits without it
+    # the per-chunk frustum cull in front of the projection (k_cull) only leaves out chunks none of whose splats vs_main would keep: same bits without it
     renderer.set_option(L.GSWT_OPT_NO_CHUNK_CULL, 1)
     try:
         img_n = pipe.render(s["cu"], W, Hh)
