@@ -207,6 +207,7 @@ SYMBOLS = {
     "gswt_debug_merge_stats_deep": (C.c_int, [_P, _P]),
     "gswt_debug_totals": (C.c_int, [_P, _P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "gswt_debug_sort": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
+    "gswt_debug_tile_depth_sort": (C.c_int, [_P, _P, C.c_size_t, _P, _P, C.c_size_t, C.POINTER(C.c_int)]),
     "gswt_debug_graph_stats": (C.c_int, [_P, _P]),
 }
 

@@ -2030,6 +2030,38 @@ try {
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_sort")
 
+// Test hook: k_tile_depth_sort alone.  lens[t] = length of screen tile t's slice of the (tile-sorted) pair list, the slices back to back;
+// vals / dkeys: the list's values and depth keys (n = sum of lens).  Sorts every slice's vals by its dkeys, stably, in place.  flagged_out:
+// 1 when a slice was longer than the LDS buffer holds (nothing is then guaranteed about that slice; a frame would be re-run).
+int gswt_debug_tile_depth_sort(gswt_ctx* c, const uint32_t* lens, size_t n_tiles, uint32_t* vals, const uint32_t* dkeys, size_t n, int* flagged_out)
+try {
+    if (!c || !lens || !vals || !dkeys || n_tiles == 0 || n_tiles > 0x7FFFFFFFull || n == 0 || n >= 0xFFFFFF00ull) return GSWT_ERR_BAD_ARG;
+    hipSetDevice(c->device);
+    std::vector<uint2> rg(n_tiles);
+    size_t at = 0;
+    for (size_t t = 0; t < n_tiles; t++) {                 // the device's encoding: (~start, end), (0, 0) for a tile without pairs
+        rg[t] = lens[t] ? make_uint2(~(uint32_t)at, (uint32_t)(at + lens[t])) : make_uint2(0u, 0u);
+        at += lens[t];
+    }
+    if (at != n) return fail(c, GSWT_ERR_BAD_ARG, "gswt_debug_tile_depth_sort: the lengths sum to %zu, not %zu", at, n);
+    DevBuf<uint2> d_rg; DevBuf<uint32_t> d_vals, d_keys, d_long; DevBuf<unsigned long long> d_cnt;
+    HIP_TRY(c, d_rg.ensure(n_tiles)); HIP_TRY(c, d_vals.ensure(n + 1)); HIP_TRY(c, d_keys.ensure(n + 1)); HIP_TRY(c, d_long.ensure(n_tiles + 2)); HIP_TRY(c, d_cnt.ensure(8));
+    HIP_TRY(c, hipMemcpy(d_rg.p, rg.data(), n_tiles * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_vals.p, vals, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_keys.p, dkeys, n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(d_long.p, 0, (n_tiles + 2) * 4));
+    HIP_TRY(c, hipMemset(d_cnt.p, 0, 64));
+    launch_tile_depth_sort(c->stream, d_rg.p, d_vals.p, d_keys.p, (int)n_tiles, d_long.p, d_cnt.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long cnt[4];
+    HIP_TRY(c, hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(vals, d_vals.p, n * 4, hipMemcpyDeviceToHost));
+    if (flagged_out) *flagged_out = cnt[3] != 0ull;
+    d_rg.release(); d_vals.release(); d_keys.release(); d_long.release(); d_cnt.release();
+    return GSWT_OK;
+} GSWT_CATCH("gswt_debug_tile_depth_sort")
+
 int gswt_debug_graph_stats(const gswt_ctx* c, unsigned long long out[3])
 {
     if (!c || !out) return GSWT_ERR_BAD_ARG;

@@ -506,6 +506,12 @@ GSWT_API int gswt_debug_totals(gswt_ctx *ctx, const uint32_t *pair_sums, const u
  * Host pointers. */
 GSWT_API int gswt_debug_sort(gswt_ctx *ctx, uint32_t *keys, uint32_t *vals, size_t n, int key_bits);
 
+/* Test hook: the tile-local depth sort of GSWT_ORDER_DEPTH alone (k_tile_depth_sort).  lens[t] = length of screen tile t's slice of the pair
+ * list (the slices lie back to back, n = their sum); every slice's vals are sorted by its dkeys, stably, in place.  *flagged_out = 1 when a
+ * slice is longer than the kernel's LDS buffer holds (16 384 pairs: a frame would be re-run with the global depth passes).  Host pointers. */
+GSWT_API int gswt_debug_tile_depth_sort(gswt_ctx *ctx, const uint32_t *lens, size_t n_tiles, uint32_t *vals, const uint32_t *dkeys, size_t n,
+                                        int *flagged_out);
+
 /* GSWT_OPT_GRAPH bookkeeping since gswt_create: {frames replayed through hipGraphLaunch, graphs (re)built, kernel nodes updated}. */
 GSWT_API int gswt_debug_graph_stats(const gswt_ctx *ctx, unsigned long long out[3]);
 

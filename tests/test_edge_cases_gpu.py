@@ -281,3 +281,51 @@ def test_radix_sort_is_stable_at_every_size(renderer, n, key_bits):
     assert rc == 0, renderer.last_error() if hasattr(renderer, "last_error") else rc
     assert np.array_equal(k2, keys[order])
     assert np.array_equal(v2, vals[order])          # equal keys keep their input order
+
+
+@pytest.mark.gpu
+def test_tile_depth_sort_is_stable_at_every_class_boundary(renderer):
+    """k_tile_depth_sort alone (gswt_debug_tile_depth_sort) against numpy's stable sort, slice by slice: empty tiles, one pair, the
+    boundaries of its three size classes (a wave up to 512 pairs, a 256-thread workgroup up to 4 096, the long-list grid up to 16 384),
+    ragged last rounds, one depth for a whole slice, spans of 1 .. 32 bits (one to four passes, digits of 1 .. 8 bits), many equal keys
+    (ties keep the list's order: the order contract of scene.rs:685-695 inside a depth tie)."""
+    import ctypes as C
+    rng = np.random.default_rng(20261005)
+    lens = [0, 1, 2, 63, 64, 65, 0, 127, 129, 511, 512, 513, 514, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 0, 4095, 4096, 4097, 4098, 5000, 8191, 8192,
+            8193, 12000, 16383, 16384, 3, 0, 700, 300, 4096, 513, 512, 16384, 1]
+    keys, want = [], []
+    for i, n in enumerate(lens):
+        bits = (1, 3, 8, 9, 13, 16, 17, 21, 24, 25, 32, 0)[i % 12]         # span of the slice's keys (0: one depth)
+        if bits == 0:
+            k = np.full(n, 0x3F7F1234, dtype=np.uint32)
+        else:
+            base = np.uint64(rng.integers(0, (1 << 32) - (1 << bits) + 1)) if bits < 32 else np.uint64(0)
+            k = (base + rng.integers(0, 1 << bits, size=n, dtype=np.uint64)).astype(np.uint32)
+            if n > 8 and i % 3 == 0:                                          # runs of equal depths
+                k = np.repeat(k[: (n + 3) // 4], 4)[:n].copy()
+                k = k[rng.permutation(n)]
+        keys.append(k)
+    dk = np.concatenate(keys).astype(np.uint32)
+    n = int(dk.size)
+    vals = rng.permutation(n).astype(np.uint32)                               # any payload: the sort must not look at it
+    out = vals.copy()
+    la = np.asarray(lens, dtype=np.uint32)
+    flagged = C.c_int(-1)
+    lib = L.load()
+    rc = lib.gswt_debug_tile_depth_sort(renderer._h, la.ctypes.data, la.size, out.ctypes.data, dk.ctypes.data, n, C.byref(flagged))
+    assert rc == 0 and flagged.value == 0
+    at = 0
+    for i, m in enumerate(lens):
+        order = np.argsort(dk[at:at + m], kind="stable")
+        assert np.array_equal(out[at:at + m], vals[at:at + m][order]), (i, m)
+        at += m
+    # a slice beyond the LDS buffer is flagged (a frame would be re-run with the global passes); the others are still sorted
+    lens2 = np.asarray([100, 16385, 50], dtype=np.uint32)
+    n2 = int(lens2.sum())
+    dk2 = rng.integers(0, 1 << 20, size=n2, dtype=np.uint64).astype(np.uint32)
+    v2 = np.arange(n2, dtype=np.uint32)
+    o2 = v2.copy()
+    rc = lib.gswt_debug_tile_depth_sort(renderer._h, lens2.ctypes.data, lens2.size, o2.ctypes.data, dk2.ctypes.data, n2, C.byref(flagged))
+    assert rc == 0 and flagged.value == 1
+    assert np.array_equal(o2[:100], v2[:100][np.argsort(dk2[:100], kind="stable")])
+    assert np.array_equal(o2[-50:], v2[-50:][np.argsort(dk2[-50:], kind="stable")])
