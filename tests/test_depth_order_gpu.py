@@ -126,6 +126,20 @@ def test_tile_local_depth_sort_long_lists_and_the_fallback(renderer):
             img_l2 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
             l2, g2, _ = renderer.depth_stats()
             assert (l2 - l1, g2 - g1) == ((1, 0) if expect_local else (0, 1)) and np.array_equal(img_l2, img_g)
+            # ... and the same as one hipGraph per frame: the flagged frame's re-run is another kernel sequence (the graph is rebuilt)
+            renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 2)      # (forgets the longest list: the next frame tries the tile-local path again)
+            renderer.set_option(L.GSWT_OPT_GRAPH, 1)
+            renderer.set_option(L.GSWT_OPT_TIMING, 0)
+            try:
+                l3, g3, _ = renderer.depth_stats()
+                img_q = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+                img_q2 = renderer.render(s["cu"], s["su"], W, Hh, order_mode=L.GSWT_ORDER_DEPTH)
+                l4, g4, _ = renderer.depth_stats()
+            finally:
+                renderer.set_option(L.GSWT_OPT_GRAPH, 0)
+                renderer.set_option(L.GSWT_OPT_TIMING, 2)
+            assert (l4 - l3, g4 - g3) == ((2, 0) if expect_local else (1, 2))
+            assert np.array_equal(img_q, img_g) and np.array_equal(img_q2, img_g)
     finally:
         renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 0)
 
