@@ -1404,8 +1404,11 @@ __global__ __launch_bounds__(256) void k_radix_supscan(uint32_t* __restrict__ gs
 // Measured per pass (scatter<512>, without payload / AUX 1 / AUX 2): c3 (2.66 M pairs) 18.5 / 22.7 / 26.6 us, c3d (8.2 M) 37.5 / 55.7 / 54.8,
 // c5 (21.4 M) 99 / 164 / 145: the small sort is a latency chain that wants the third workgroup, the large one pays for the scattered
 // reads.  launch_sort takes AUX 2 above 12 M pairs of capacity.
+// (512-thread build: at most 80 VGPRs, so that THREE workgroups fit a CU -- c3's 649 blocks are then all resident at once (768 slots) and the
+// kernel lasts one block's chain; at 86 VGPRs, where the five-instruction match_digit first left it, two fit, the blocks ran in two
+// generations, and the chain it had shortened from 12.8 to 9.0 us bought nothing)
 template <int kSortThreads, int AUX>
-__global__ __launch_bounds__(kSortThreads) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+__global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu((kSortThreads == 512 && AUX != 2) ? 6 : 1, 8))) void k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                                                        uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                        const unsigned long long* __restrict__ n_ptr, uint32_t n_cap, uint32_t shift,
                                                        uint32_t mask, uint32_t nbits, const uint32_t* __restrict__ ghist,
