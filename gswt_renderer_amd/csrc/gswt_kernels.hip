@@ -1841,7 +1841,7 @@ __device__ __forceinline__ void tile_depth_sort_one(uint32_t tile, const uint2* 
 }
 
 template <int THREADS, int ROUNDS, bool LONG>
-__global__ __launch_bounds__(THREADS) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ vals, const uint32_t* __restrict__ dkeys,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 4 : 1, 8))) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ vals, const uint32_t* __restrict__ dkeys,
                                                              uint32_t n_tiles, uint32_t* __restrict__ long_list, unsigned long long* __restrict__ counters,
                                                              uint32_t n_lo, uint32_t push)
 {
