@@ -53,6 +53,15 @@ def build_workload(name: str, lod0_override: int | None = None):
     return w, wang, cu, vp, sort
 
 
+def auto_segment(pairs_per_tile: float, pairs_frame: float) -> int:
+    """GSWT_OPT_SEGMENT (pairs per compositor work item) for a frame with this many pairs per screen tile / in all: long for dense frames
+    (a segment cannot skip what the segments in front of it saturated), short enough that the frame has ~2 048 work items."""
+    from gswt_renderer_amd import _lib as L
+    seg_dense = max(L.GSWT_DEFAULT_SEGMENT, 256 * math.ceil(4.0 * pairs_per_tile / 256.0))
+    seg_fill = 256 * max(1, math.ceil(pairs_frame / 2048.0 / 256.0))
+    return int(min(4096, seg_dense, seg_fill))
+
+
 def oracle_draws(wang, sort, vp, culling_dist=1.0):
     """The draw list of a sort event as the CPU oracle takes it (tex, [orc.Draw]): the CPU viewport cull of renderer.rs:472-494
     applied on the host (the HIP path does it on the device).  Checker-side only (cpu_baseline leg and tests)."""
@@ -399,11 +408,16 @@ def main():
     # frame (many pairs per screen tile) wants long segments; a sparse one is indifferent up to ~2 k (gswt_api.hip, opt_segment)
     t0f = r.timings()
     pairs_per_tile = float(t0f["n_pairs"]) / max(1.0, float(t0f["n_tiles"]))
+    pairs_frame = float(t0f["n_pairs"])
     if world > 1 and dist is not None and fake_world <= 1:
-        ppt = torch.tensor([pairs_per_tile], dtype=torch.float64, device=dev)
+        ppt = torch.tensor([pairs_per_tile, pairs_frame], dtype=torch.float64, device=dev)
         dist.all_reduce(ppt, op=dist.ReduceOp.MAX)             # every rank composites with the same segment length
-        pairs_per_tile = float(ppt.item())
-    segment = args.segment if args.segment > 0 else int(min(4096, max(L.GSWT_DEFAULT_SEGMENT, 256 * math.ceil(4.0 * pairs_per_tile / 256.0))))
+        pairs_per_tile, pairs_frame = float(ppt[0].item()), float(ppt[1].item())
+    # ... and a frame with few pairs (one rank's band of a sharded frame) wants SHORT ones, or its work items do not fill the chip: at least
+    # ~2 048 of them (the compositor's resident workgroups).  c3: 1 536 either way; one of eight column bands (345 k pairs): 256 instead of
+    # 1 536 -- k_composite 30 instead of 66 us one frame at a time, 61-75 instead of 73-90 us per frame with five in flight
+    # (tools/shard_emulation.py, GSWT_SEGMENT; profiles/r04_shard_segment_c3.txt)
+    segment = args.segment if args.segment > 0 else auto_segment(pairs_per_tile, pairs_frame)
     r.set_option(L.GSWT_OPT_SEGMENT, segment)
     # three frames in flight on a static camera (a fourth costs 6 %: four buffer sets in rotation), four on the fly path (the
     # fourth covers the bubble a SortData swap-in leaves in the frame stream: +5 %)

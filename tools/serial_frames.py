@@ -33,8 +33,12 @@ order = L.GSWT_ORDER_DEPTH if os.environ.get("GSWT_ORDER", "") == "depth" else L
 wang.upload_to(r)
 r.configure(wang.height_map() if int(wang.user.surface_type) == 1 else None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
+shard = None
+if os.environ.get("GSWT_SHARD"):                   # "rank,world[,cols]": one rank's share of a sharded frame
+    a = os.environ["GSWT_SHARD"].split(",")
+    shard = (int(a[0]), int(a[1]), "cols") if len(a) > 2 else (int(a[0]), int(a[1]))
 out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
 for i in range(n):
-    r.render_wait(r.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5, order_mode=order))
+    r.render_wait(r.render_async(cu, su, W, H, out.data_ptr(), transmittance_eps=1e-5, order_mode=order, **({"shard": shard} if shard else {})))
 print("done", r.timings()["n_pairs"])

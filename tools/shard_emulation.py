@@ -18,13 +18,19 @@ su = wang.scene_uniforms()
 r = GSWTRenderer(0)
 r.set_option(L.GSWT_OPT_TIMING, 0)
 r.set_option(L.GSWT_OPT_GRAPH, int(os.environ.get("GSWT_GRAPH", "0")))      # GSWT_GRAPH=1: one hipGraphLaunch per frame
-print(f"workload {name}, GSWT_OPT_GRAPH = {os.environ.get('GSWT_GRAPH', '0')}", flush=True)
+if os.environ.get("GSWT_SEGMENT"):                 # pairs per compositor work item (default: the library's)
+    r.set_option(L.GSWT_OPT_SEGMENT, int(os.environ["GSWT_SEGMENT"]))
+print(f"workload {name}, GSWT_OPT_GRAPH = {os.environ.get('GSWT_GRAPH', '0')}, GSWT_OPT_SEGMENT = {os.environ.get('GSWT_SEGMENT', 'as bench.py picks it (auto_segment)')}", flush=True)
+if os.environ.get("GSWT_SHARD_CONFIGS"):           # e.g. "cols8,cols4"
+    only = os.environ["GSWT_SHARD_CONFIGS"].split(",")
 wang.upload_to(r)
 r.configure(wang.height_map() if int(wang.user.surface_type) == 1 else None)
 r.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
 configs = [("rows", 1), ("rows", 2), ("rows", 4), ("rows", 8), ("cols", 2), ("cols", 4), ("cols", 8)]
 if name == "c5":
     configs = [("rows", 1), ("rows", 8), ("cols", 2), ("cols", 4), ("cols", 8)]
+if os.environ.get("GSWT_SHARD_CONFIGS"):
+    configs = [(m, n) for m, n in configs if f"{m}{n}" in only]
 for mode, N in configs:
     rows = r.shard_rows_padded(H, N) if (N > 1 and mode == "rows") else H
     cols = r.shard_cols_padded(W, N) if (N > 1 and mode == "cols") else W
@@ -45,6 +51,10 @@ for mode, N in configs:
                 r.render_wait(infl.pop(0))
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / n
+        if not os.environ.get("GSWT_SEGMENT"):         # as bench.py picks it: from the rank's own first frame
+            r.render_wait(r.render_async(cu, su, W, H, outs[0].data_ptr(), transmittance_eps=1e-5, shard=(rank, N, mode) if mode == "cols" else (rank, N)))
+            t0f = r.timings()
+            r.set_option(L.GSWT_OPT_SEGMENT, bench.auto_segment(float(t0f["n_pairs"]) / max(1.0, float(t0f["n_tiles"])), float(t0f["n_pairs"])))
         run(10)
         t_rank = min(run(n_frames), run(n_frames))          # best of two: one allocation growth or clock ramp inside a 100-frame run is not the rank's rate
         per_rank.append(t_rank)
