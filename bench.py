@@ -462,7 +462,7 @@ def main():
         cams = [(tuple(cam0["pos"]), cu0, vp0)]
 
     trace = [] if os.environ.get("GSWT_BENCH_TRACE") else None      # host-side timeline of submits and waits (stderr, after the run)
-    state = {"su": su0, "swaps": 0, "swap_ms": [], "slots": slots}
+    state = {"su": su0, "swaps": 0, "swap_ms": [], "slots": slots, "every": 4}
     stats = {"comp_ms": [], "comp_slot": [], "pairs": [], "stage": [], "submit_ms": []}
     inflight = []
 
@@ -531,11 +531,12 @@ def main():
             i = first + k
             pos, cu, vp = cams[i % len(cams)]
             if worker is not None and lockstep:
-                # N > 1: every 4th camera goes to the worker in order; its SortData is swapped in four frames later on every rank
-                if i % 4 == 0:
+                # N > 1: every E-th camera goes to the worker in order; its SortData is swapped in E frames later on every rank (E: below)
+                E = state["every"]
+                if i % E == 0:
                     worker.submit_ordered(i, pos, vp)
-                if i % 4 == 0 and i >= 4 + first_tag[0]:
-                    res = worker.take(i - 4)
+                if i % E == 0 and i >= E + first_tag[0]:
+                    res = worker.take(i - E)
                     if res is not None:
                         swap_in(res)
             elif worker is not None:
@@ -602,6 +603,27 @@ def main():
             swap_in(res)
     if args.freeze_sort and worker is not None:
         worker.close()
+    if lockstep and worker is not None and not args.freeze_sort:
+        # The reference's worker takes the newest camera whenever it is free (state.rs:323-334); the lock-step stand-in for it hands over every
+        # E-th camera, and E has to leave the worker the time of one event or the render thread waits for it: with E = 4, a 0.28-0.56 ms event
+        # (sort_tiles, at times + build_tiles, at c3) holds a rank of eight, whose frames take ~75 us, at ~120 us per frame.  E = the event time over the
+        # frame time of a short untimed run of this rank's frames (x 1.5, rounded up to a power of two, 4 .. 64), the largest over the ranks.
+        # (an event = sort_tiles; a quarter of them also rebuild the tile map on the fly path: 3 build_tiles in 10 events)
+        ev_ms = (float(np.mean(worker.sort_ms)) if worker.sort_ms else 0.3) + 0.25 * (float(np.mean(worker.build_ms)) if worker.build_ms else 0.3)
+        n_cal = 24
+        torch.cuda.synchronize()
+        t0c = time.perf_counter()
+        run(n_cal, None)
+        torch.cuda.synchronize()
+        fr_ms = 1e3 * (time.perf_counter() - t0c) / n_cal
+        e = 4
+        while e < 64 and e * fr_ms < 1.5 * ev_ms:
+            e *= 2
+        if dist is not None and fake_world <= 1:
+            et = torch.tensor([float(e)], dtype=torch.float64, device=dev)
+            dist.all_reduce(et, op=dist.ReduceOp.MAX)
+            e = int(et.item())
+        state["every"] = int(os.environ.get("GSWT_BENCH_LOCKSTEP_EVERY", e))
     dt = timed_run(args.steps, None if args.freeze_sort else worker, args.warmup)
     main_stats = {k: (list(v) if isinstance(v, list) else v) for k, v in stats.items()}
     if trace is not None:
@@ -778,6 +800,7 @@ def main():
             "sort_events": {"swapped_in": swaps, "swap_in_ms_mean": float(np.mean(swap_ms)) if swap_ms else None,
                             "merged_groups_sorted": mg_built, "merged_groups_copied": mg_reused, "merged_groups_copied_from_older_than_previous_event": mg_deep,
                             "merged_groups_sorted_share": (mg_built / float(mg_built + mg_reused)) if (mg_built + mg_reused) else None,
+                            "lockstep_every": (state["every"] if lockstep else None),
                             "takes_effect": "first frame submitted after the event's device-side list build has finished (GSWT_OPT_DEFER_SWAP = 1)" if defer_swap else ("third frame submitted after the swap-in, on every rank (GSWT_OPT_DEFER_SWAP = 3)" if (world > 1 and args.mode == "flypath" and not args.no_defer_swap) else "next frame (which waits for the build on the device)"),
                             "note": "SortData swap-ins inside the timed region (gswt_set_draws_merge_groups: draw-list upload into the spare draw set + merged lists built on the device, on a stream of their own)"},
             "worker_ms": worker_ms,
