@@ -1502,7 +1502,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         vals_sorted = where ? sl.vals_b.p : sl.vals_a.p;
     } else if (sl.depth_local) {
         // tile-local path: tile ids are the sort key, the depth bits its payload; then every tile's slice is depth-sorted in LDS
-        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, sl.depths.p, sl.aux_a.p, d_krange);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, sl.depths.p, sl.aux_a.p, nullptr);
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p, nullptr, sl.aux_a.p, sl.aux_b.p);
         uint32_t* const vals_t = where ? sl.vals_b.p : sl.vals_a.p;

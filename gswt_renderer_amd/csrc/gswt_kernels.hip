@@ -1217,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
             }
         }
     }
-    if (DEPTH) {
+    if (DEPTH && krange) {                                      // (the tile-local depth sort takes each tile's own range: no krange)
         // key range of the frame: one guarded atomic pair per workgroup.  (One pair per WAVE on the two words is tens of thousands of
         // atomics on two addresses, which the memory side serialises at ~8 ns each.)  The words only grow ([0] holds ~min), so a stale read
         // can only cause a redundant atomic, never a missed one.
