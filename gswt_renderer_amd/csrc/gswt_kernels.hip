@@ -996,6 +996,9 @@ __global__ __launch_bounds__(256 * HALVES) void k_project(
         wsum += __shfl_down(wsum, off, 64);
         wvis += __shfl_down(wvis, off, 64);
     }
+    // (Round 4, measured and reverted: no barrier here -- every wave adding its own sums with fire-and-forget atomics (12 per workgroup
+    // instead of 2 + a store, the rects stored whether or not the chunk emits pairs): k_project 57 -> 183 us at c3, 379 -> 561 at c5.  The
+    // device-scope atomics of a kernel retire at ~1 per ns chip-wide whatever their addresses: 107 k more of them cost 125 us.)
     const uint32_t w0 = 4u * half;             // first wave of this half in the workgroup's tables
     if ((tid & 63u) == 0) { s_wsum[w0 + (tid >> 6)] = wsum; s_wvis[w0 + (tid >> 6)] = wvis; }
     __syncthreads();
