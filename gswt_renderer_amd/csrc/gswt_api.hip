@@ -1428,7 +1428,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     HIP_TRY(c, sl.vals_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.vals_b.ensure_roomy((size_t)cap + 1));
     const bool depth_order = cfg->order_mode == GSWT_ORDER_DEPTH;
     const size_t n_super = (size_t)D.n_chunks / 256 + 1;
-    const size_t n_super2 = 3 * n_super;                            // pair sums, visible sums, exclusive pair prefix (k_totals)
+    const size_t n_super2 = (2 * (size_t)kSuperStride + 1) * n_super;     // pair sums, visible sums (a cache line per word), exclusive pair prefix (k_totals)
     // GSWT_ORDER_DEPTH: the pair list is sorted on the depth bits first, with as many 8-bit passes as the key ranges of the recent frames
     // needed (k_items flags a frame that needs more: finish_frame re-runs it); the tile ids travel as the payload of those passes
     sl.depth_passes = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->depth_passes, 1u), 4u) : 0u;
@@ -1992,16 +1992,17 @@ try {
     if (!c || !pair_sums || !visible_sums || n_super == 0 || !counters_out) return GSWT_ERR_BAD_ARG;
     hipSetDevice(c->device);
     DevBuf<uint32_t> buf;
-    HIP_TRY(c, buf.ensure(3 * (size_t)n_super + 16));
-    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(buf.p + 3 * (size_t)n_super + (n_super & 1));
-    HIP_TRY(c, hipMemset(buf.p, 0, (3 * (size_t)n_super + 16) * 4));
-    HIP_TRY(c, hipMemcpy(buf.p, pair_sums, (size_t)n_super * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(buf.p + n_super, visible_sums, (size_t)n_super * 4, hipMemcpyHostToDevice));
+    const size_t S = kSuperStride, words = (2 * S + 1) * (size_t)n_super;
+    HIP_TRY(c, buf.ensure(words + 16));
+    unsigned long long* d_cnt = reinterpret_cast<unsigned long long*>(buf.p + words + (words & 1));
+    HIP_TRY(c, hipMemset(buf.p, 0, (words + 16) * 4));
+    HIP_TRY(c, hipMemcpy2D(buf.p, S * 4, pair_sums, 4, 4, n_super, hipMemcpyHostToDevice));                 // one word per cache line
+    HIP_TRY(c, hipMemcpy2D(buf.p + S * n_super, S * 4, visible_sums, 4, 4, n_super, hipMemcpyHostToDevice));
     launch_totals(c->stream, buf.p, n_super, d_cnt, pair_cap);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(counters_out, d_cnt, 32, hipMemcpyDeviceToHost));
-    if (super_excl_out) HIP_TRY(c, hipMemcpy(super_excl_out, buf.p + 2 * (size_t)n_super, (size_t)n_super * 4, hipMemcpyDeviceToHost));
+    if (super_excl_out) HIP_TRY(c, hipMemcpy(super_excl_out, buf.p + 2 * S * (size_t)n_super, (size_t)n_super * 4, hipMemcpyDeviceToHost));
     buf.release();
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_totals")

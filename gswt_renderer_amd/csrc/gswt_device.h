@@ -175,6 +175,10 @@ struct GraphNodeRec {
                n_bytes == o.n_bytes && memcmp(args, o.args, n_bytes) == 0;
     }
 };
+// k_project's two-level sums: one word per super-group (256 chunks) for the pairs and one for the visible splats, each on a cache line of its
+// own (16 words apart).  Device-scope atomics on one 64-byte line retire at ~10 ns each whichever XCD they come from (measured: 43 k atomics
+// on 4 lines = +125 us), and side by side the 64 super-group words of c3 were 4 + 4 lines taking 2.7 k atomics each.
+constexpr uint32_t kSuperStride = 16;
 constexpr uint32_t kGraphMaxNodes = 32;          // reference order: 10-12 kernels per frame; GSWT_ORDER_DEPTH: 19-23
 struct GraphRec {
     GraphNodeRec nodes[kGraphMaxNodes];

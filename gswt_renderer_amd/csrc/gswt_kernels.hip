@@ -1015,9 +1015,9 @@ __global__ __launch_bounds__(256 * HALVES) void k_project(
         block_sums[cid] = bsum;
         // two-level sums, spread over n_chunks / 256 addresses (a single hot counter serialises the whole grid);
         // k_totals folds them into counters[0] (visible splats) and counters[1] (pairs)
-        if (bsum) atomicAdd(&super_sums[cid >> 8], bsum);
+        if (bsum) atomicAdd(&super_sums[(cid >> 8) * kSuperStride], bsum);
         uint32_t v = s_wvis[w0] + s_wvis[w0 + 1u] + s_wvis[w0 + 2u] + s_wvis[w0 + 3u];
-        if (v) atomicAdd(&super_sums[n_super + (cid >> 8)], v);
+        if (v) atomicAdd(&super_sums[(n_super + (cid >> 8)) * kSuperStride], v);
     }
     GSWT_TR(6, GSWT_NOW())
 }
@@ -1049,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ sup
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t idx = min(i + (uint32_t)k, n_super - 1u);              // clamped, unmasked loads
-            const uint32_t pv = super_sums[idx], vv = super_sums[n_super + idx];
+            const uint32_t pv = super_sums[idx * kSuperStride], vv = super_sums[(n_super + idx) * kSuperStride];
             p[k] = i + k < n_super ? pv : 0u;
             v += i + k < n_super ? vv : 0u;
             sum += p[k];
@@ -2864,7 +2864,7 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
                     uint32_t* super_sums, unsigned long long* counters, Varyings* dbg, float4* col_f, uint32_t pair_cap, bool strict)
 {
     if (n_chunks == 0) return;
-    const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs][visible][exclusive pair prefix] x n_super, zeroed by the caller
+    const uint32_t n_super = n_chunks / 256u + 1u;      // super_sums = [pairs x 16 n_super][visible x 16 n_super][exclusive pair prefix x n_super] (kSuperStride), zeroed by the caller
     const bool full = f.surface_type == 2u || f.draw_mode != 0u;
     // GSWT_PROJECT_HALVES=2 (measurement only): 512-thread workgroups, two launch-list entries each.  Built in round 4 against the
     // "dispatch-bound" reading of the kernel's trace and LOST at every size, same bits: c3 83.4 us against 76.2, c3h 101.5 / 97.2,
@@ -2883,7 +2883,7 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     else { GSWT_LAUNCH_PROJECT(false, false); }
 #undef GSWT_LAUNCH_PROJECT
 #undef GSWT_LAUNCH_PROJECT_S
-    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, live_cnt);
+    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * kSuperStride * n_super, pair_cap, live_cnt);
 }
 
 // keys: tile ids, vals: slots.  GSWT_ORDER_DEPTH (dkeys != nullptr): also each pair's depth bits -> dkeys and the frame's key range -> krange.
@@ -2894,8 +2894,8 @@ void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* 
     if (n_chunks == 0) return;
     const uint32_t n_super = n_chunks / 256u + 1u;      // [pairs x n_super][visible x n_super][exclusive pair prefix x n_super]
     const dim3 grid((n_chunks + kEmitGroup - 1u) / kEmitGroup);
-    if (dkeys) GSWT_LAUNCH(k_emit<true>, grid, dim3(256), s, f, rects, block_sums, super_sums + 2u * n_super, n_chunks, pair_cap, counters, keys, vals, depths, dkeys, krange);
-    else GSWT_LAUNCH(k_emit<false>, grid, dim3(256), s, f, rects, block_sums, super_sums + 2u * n_super, n_chunks, pair_cap, counters, keys, vals,
+    if (dkeys) GSWT_LAUNCH(k_emit<true>, grid, dim3(256), s, f, rects, block_sums, super_sums + 2u * kSuperStride * n_super, n_chunks, pair_cap, counters, keys, vals, depths, dkeys, krange);
+    else GSWT_LAUNCH(k_emit<false>, grid, dim3(256), s, f, rects, block_sums, super_sums + 2u * kSuperStride * n_super, n_chunks, pair_cap, counters, keys, vals,
                      (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
 }
 
@@ -3136,7 +3136,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 // k_totals alone on caller-provided sums (unit test of the 64-bit pair count)
 void launch_totals(hipStream_t s, uint32_t* super_sums, uint32_t n_super, unsigned long long* counters, uint32_t pair_cap)
 {
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * n_super, pair_cap, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * kSuperStride * n_super, pair_cap, (uint32_t*)nullptr);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded, int band_px)
