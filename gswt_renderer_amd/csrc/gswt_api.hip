@@ -238,7 +238,7 @@ struct FrameSlot {
     DevBuf<uint2> rects;
     DevBuf<Rec> recs;
     DevBuf<uint4> live_tab;                // this frame's launch table of k_project: the chunks of the draws that survive k_cull
-    DevBuf<uint32_t> live_cnt;             // entries per XCD list of live_tab (8 words; zero between frames)
+    DevBuf<uint32_t> live_cnt;             // entries per XCD list of live_tab (8 words, a cache line apart; zero between frames)
     DevBuf<uint32_t> cell_culled;          // column-band shards: per map cell, 1 = no splat of that tile instance can reach the band
     DevBuf<uint32_t> block_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
     DevBuf<uint2> ranges;
@@ -1319,7 +1319,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         // (cleared ON THE SLOT'S STREAM: the slot streams are non-blocking, so a null-stream hipMemset -- asynchronous to the host for
         // device memory -- could land after this frame's k_cull had filled the counts: the slot's FIRST frame then projected nothing
         // and came back as background.  Seen once five slots made test_async_all_slots_in_flight_and_slot_reuse the first user of slot 4.)
-        if (!sl.live_cnt.p) { HIP_TRY(c, sl.live_cnt.ensure(8)); HIP_TRY(c, hipMemsetAsync(sl.live_cnt.p, 0, sl.live_cnt.cap * 4, s)); }
+        if (!sl.live_cnt.p) { HIP_TRY(c, sl.live_cnt.ensure(8 * kSuperStride)); HIP_TRY(c, hipMemsetAsync(sl.live_cnt.p, 0, sl.live_cnt.cap * 4, s)); }
         HIP_TRY(c, sl.draw_culled.ensure_roomy((size_t)D.n_draws + 1));
         if (su->draw_mode != 0u) HIP_TRY(c, sl.col_f.ensure(n_slots_all + 1));
         if (a.d_bgd || cfg->order_mode == GSWT_ORDER_DEPTH) HIP_TRY(c, sl.depths.ensure(n_slots_all + 1));

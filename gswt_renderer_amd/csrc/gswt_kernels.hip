@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
         }
     }
     __syncthreads();
-    if (threadIdx.x < 8u && s_cnt[threadIdx.x] != 0u) s_base[threadIdx.x] = atomicAdd(&live_cnt[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x < 8u && s_cnt[threadIdx.x] != 0u) s_base[threadIdx.x] = atomicAdd(&live_cnt[threadIdx.x * kSuperStride], s_cnt[threadIdx.x]);      // (a cache line per XCD's count: gswt_device.h)
     __syncthreads();
     if (live) live_tab[(size_t)(s_base[x] + rank) * 8u + x] = e;
 }
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256 * HALVES) void k_project(
         if (ct.y == 0xFFFFFFFFu) return;    // padding of a short per-XCD list
     } else {
         const uint32_t x = blockIdx.x & 7u, k0 = (blockIdx.x >> 3) * (uint32_t)HALVES;
-        const uint32_t n_live = live_cnt[x];
+        const uint32_t n_live = live_cnt[x * kSuperStride];
         if (k0 >= n_live) return;
         active = k0 + half < n_live;
         const uint4 lt = live_tab[(size_t)min(k0 + half, n_live - 1u) * 8u + x];
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ sup
 {
     // k_project is done with this frame's live-chunk counts: cleared here for the slot's next frame (k_cull both clears
     // buffers and adds to these counters, so it cannot clear them itself)
-    if (live_cnt && threadIdx.x < 8u) live_cnt[threadIdx.x] = 0u;
+    if (live_cnt && threadIdx.x < 8u) live_cnt[threadIdx.x * kSuperStride] = 0u;
     __shared__ unsigned long long s_v[4];
     __shared__ uint32_t s_w[4];
     unsigned long long v = 0;
