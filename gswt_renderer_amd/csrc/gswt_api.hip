@@ -46,7 +46,7 @@ int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_
                 const uint32_t* = nullptr, uint32_t* = nullptr, uint32_t* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
                       uint32_t, uint32_t, uint32_t*, uint4*, float4*, hipEvent_t, hipEvent_t, unsigned long long*, unsigned long long*, int, const uint32_t*, uint32_t, uint32_t*, bool, bool);
-void launch_tile_depth_sort(hipStream_t, const uint2*, uint32_t*, const uint32_t*, int, uint32_t*, unsigned long long*);
+void launch_tile_depth_sort(hipStream_t, const uint2*, uint32_t*, uint32_t*, uint32_t*, uint32_t*, int, uint32_t*, unsigned long long*);
 uint32_t tile_depth_sort_cap();
 void launch_unshard(hipStream_t, const float4*, float4*, int, int, int, int, int);
 void launch_skybox(hipStream_t, const float*, float, float, int, int, int, int, const float4*, float4*);
@@ -1407,8 +1407,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     sl.n_tiles = n_tiles;
     float4* const d_out = a.d_out;
     // (behind the per-tile ranges: one ticket word per tile for GSWT_OPT_COMPOSITE = 2, cleared with them by k_cull)
-    // (and behind those: the tile-local depth sort's list of long tiles, [0] = count, cleared likewise)
-    HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1 + ((size_t)n_tiles + 1) / 2 + 1 + ((size_t)n_tiles + 2) / 2 + 1));
+    // (and behind those: the tile-local depth sort's two lists of long tiles, each [0] = count + n_tiles entries, cleared likewise)
+    HIP_TRY(c, sl.ranges.ensure((size_t)n_tiles + 1 + ((size_t)n_tiles + 1) / 2 + 1 + 2 * (((size_t)n_tiles + 2) / 2 + 1)));
     uint32_t* const d_tile_tick = reinterpret_cast<uint32_t*>(sl.ranges.p + (size_t)n_tiles + 1);
     uint32_t* const d_long_tiles = d_tile_tick + n_tiles;
     const bool dbg = c->opt_debug_varyings != 0;
@@ -1434,7 +1434,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     sl.depth_passes = depth_order ? std::min<uint32_t>(std::max<uint32_t>(c->depth_passes, 1u), 4u) : 0u;
     // a re-run after the tile-local path flagged a list that does not fit takes the global passes (finish_frame raised depth_max_tile_len)
     // (GSWT_OPT_DEPTH_SORT: 0 = tile-local while the longest list fits its LDS buffer, 1 = always the global passes, 2 = as 0)
-    sl.depth_local = depth_order && c->opt_depth_sort != 1 && c->depth_max_tile_len <= tile_depth_sort_cap();
+    sl.depth_local = depth_order && c->opt_depth_sort != 1;      // (no list is too long for it: k_tile_depth_sort_xl)
     const int depth_bits = sl.depth_local ? 0 : 8 * (int)sl.depth_passes;
     if (depth_order) (sl.depth_local ? c->stat_depth_local : c->stat_depth_global)++;
     if (depth_order) { HIP_TRY(c, sl.aux_a.ensure_roomy((size_t)cap + 1)); HIP_TRY(c, sl.aux_b.ensure_roomy((size_t)cap + 1)); }
@@ -1484,7 +1484,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // part is contiguous with the head; the depth sort's (behind the pair sort's rows) is the kernel's second clear range.
     const size_t n_zero_a = 16 + n_super2 + rz_pair;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
-                reinterpret_cast<uint32_t*>(sl.ranges.p), ((uint32_t)n_tiles + 1u) * 2u + (uint32_t)n_tiles + 1u, sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
+                reinterpret_cast<uint32_t*>(sl.ranges.p), ((uint32_t)n_tiles + 1u) * 2u + (uint32_t)n_tiles + ((uint32_t)n_tiles + 2u), sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
                 d_radix_depth, (uint32_t)rz_depth, D.chunk_tab.p, D.n_chunks, c->static_boxes.p, c->opt_no_chunk_cull == 0 && !dbg);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
@@ -1506,7 +1506,8 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p, nullptr, sl.aux_a.p, sl.aux_b.p);
         uint32_t* const vals_t = where ? sl.vals_b.p : sl.vals_a.p;
-        launch_tile_depth_sort(s, sl.ranges.p, vals_t, where ? sl.aux_b.p : sl.aux_a.p, n_tiles, d_long_tiles, d_counters);
+        launch_tile_depth_sort(s, sl.ranges.p, vals_t, where ? sl.aux_b.p : sl.aux_a.p, where ? sl.vals_a.p : sl.vals_b.p, where ? sl.aux_a.p : sl.aux_b.p, n_tiles,
+                               d_long_tiles, d_counters);
         vals_sorted = vals_t;
     } else {
         launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.aux_a.p, sl.vals_a.p, sl.depths.p, sl.keys_a.p, d_krange);
@@ -2045,21 +2046,22 @@ try {
         at += lens[t];
     }
     if (at != n) return fail(c, GSWT_ERR_BAD_ARG, "gswt_debug_tile_depth_sort: the lengths sum to %zu, not %zu", at, n);
-    DevBuf<uint2> d_rg; DevBuf<uint32_t> d_vals, d_keys, d_long; DevBuf<unsigned long long> d_cnt;
-    HIP_TRY(c, d_rg.ensure(n_tiles)); HIP_TRY(c, d_vals.ensure(n + 1)); HIP_TRY(c, d_keys.ensure(n + 1)); HIP_TRY(c, d_long.ensure(n_tiles + 2)); HIP_TRY(c, d_cnt.ensure(8));
+    DevBuf<uint2> d_rg; DevBuf<uint32_t> d_vals, d_keys, d_vals2, d_keys2, d_long; DevBuf<unsigned long long> d_cnt;
+    HIP_TRY(c, d_rg.ensure(n_tiles)); HIP_TRY(c, d_vals.ensure(n + 1)); HIP_TRY(c, d_keys.ensure(n + 1)); HIP_TRY(c, d_vals2.ensure(n + 1)); HIP_TRY(c, d_keys2.ensure(n + 1));
+    HIP_TRY(c, d_long.ensure(2 * n_tiles + 4)); HIP_TRY(c, d_cnt.ensure(8));
     HIP_TRY(c, hipMemcpy(d_rg.p, rg.data(), n_tiles * 8, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d_vals.p, vals, n * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(d_keys.p, dkeys, n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(d_long.p, 0, (n_tiles + 2) * 4));
+    HIP_TRY(c, hipMemset(d_long.p, 0, (2 * n_tiles + 4) * 4));
     HIP_TRY(c, hipMemset(d_cnt.p, 0, 64));
-    launch_tile_depth_sort(c->stream, d_rg.p, d_vals.p, d_keys.p, (int)n_tiles, d_long.p, d_cnt.p);
+    launch_tile_depth_sort(c->stream, d_rg.p, d_vals.p, d_keys.p, d_vals2.p, d_keys2.p, (int)n_tiles, d_long.p, d_cnt.p);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned long long cnt[4];
     HIP_TRY(c, hipMemcpy(cnt, d_cnt.p, 32, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(vals, d_vals.p, n * 4, hipMemcpyDeviceToHost));
     if (flagged_out) *flagged_out = cnt[3] != 0ull;
-    d_rg.release(); d_vals.release(); d_keys.release(); d_long.release(); d_cnt.release();
+    d_rg.release(); d_vals.release(); d_keys.release(); d_vals2.release(); d_keys2.release(); d_long.release(); d_cnt.release();
     return GSWT_OK;
 } GSWT_CATCH("gswt_debug_tile_depth_sort")
 

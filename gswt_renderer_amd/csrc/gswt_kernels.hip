@@ -1734,8 +1734,8 @@ __device__ __forceinline__ void tls_sync()
 }
 template <int THREADS, int ROUNDS, bool LONG, bool WAVE = false>
 __device__ __forceinline__ void tile_depth_sort_one(uint32_t tile, const uint2* __restrict__ ranges, uint32_t* __restrict__ vals, const uint32_t* __restrict__ dkeys,
-                                                    uint32_t* __restrict__ long_list, unsigned long long* __restrict__ counters, uint32_t n_lo, bool push,
-                                                    uint2* s_kv, uint32_t (*s_h)[256], uint32_t* s_w, uint32_t* s_mn, uint32_t* s_mx)
+                                                    uint32_t* __restrict__ long_list, uint32_t* __restrict__ xl_list, unsigned long long* __restrict__ counters,
+                                                    uint32_t n_lo, bool push, uint2* s_kv, uint32_t (*s_h)[256], uint32_t* s_w, uint32_t* s_mn, uint32_t* s_mx)
 {
     constexpr uint32_t CAP = (uint32_t)(THREADS * ROUNDS);
     constexpr int NW = THREADS / 64;
@@ -1748,8 +1748,11 @@ __device__ __forceinline__ void tile_depth_sort_one(uint32_t tile, const uint2* 
     if (n <= max(n_lo, 1u)) return;                               // (a shorter list: the class below's)
     if (n > CAP) {                                                // workgroup-uniform
         if ((WAVE ? (threadIdx.x & 63u) : threadIdx.x) == 0u && (LONG || push)) {
-            if (LONG || n > kTileSortCap) counters[3] = 1ull;
-            else long_list[1u + atomicAdd(&long_list[0], 1u)] = tile;
+            if (LONG) counters[3] = 1ull;                         // (cannot happen: the list only holds what fits)
+            else {
+                uint32_t* const lst = n > kTileSortCap ? xl_list : long_list;      // beyond the LDS buffer: k_tile_depth_sort_xl
+                lst[1u + atomicAdd(&lst[0], 1u)] = tile;
+            }
         }
         return;
     }
@@ -1854,13 +1857,101 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_mn[NW], s_mx[NW];
     if (!LONG) {
-        if (blockIdx.x < n_tiles) tile_depth_sort_one<THREADS, ROUNDS, LONG>(blockIdx.x, ranges, vals, dkeys, long_list, counters, n_lo, push != 0u, s_kv, s_h, s_w, s_mn, s_mx);
+        if (blockIdx.x < n_tiles) tile_depth_sort_one<THREADS, ROUNDS, LONG>(blockIdx.x, ranges, vals, dkeys, long_list, long_list + n_tiles + 1u, counters, n_lo, push != 0u, s_kv, s_h, s_w, s_mn, s_mx);
     } else {
         const uint32_t n_long = min(long_list[0], n_tiles);      // written by the launch in front of this one
         for (uint32_t t = blockIdx.x; t < n_long; t += gridDim.x) {
-            tile_depth_sort_one<THREADS, ROUNDS, LONG>(long_list[1u + t], ranges, vals, dkeys, long_list, counters, n_lo, false, s_kv, s_h, s_w, s_mn, s_mx);
+            tile_depth_sort_one<THREADS, ROUNDS, LONG>(long_list[1u + t], ranges, vals, dkeys, long_list, long_list + n_tiles + 1u, counters, n_lo, false, s_kv, s_h, s_w, s_mn, s_mx);
             __syncthreads();                                      // the next list reuses the LDS
         }
+    }
+}
+
+// k_tile_depth_sort_xl: the lists that do not fit the LDS buffer (more than 16 384 pairs: c5's horizon tiles hold up to 27 908, a small
+// framebuffer in front of a big scene more).  One 1 024-thread workgroup per list (a fixed grid over xl_list, which the 256-thread class
+// fills), the same stable LSD passes on (key - the list's smallest key), but the items stay in global memory: a pass counts the digits of
+// the list wave by wave (wave w owns one contiguous sixteenth of it, so in-wave order = list order), scans (digit, wave) in LDS, and
+// scatters into the other half of the sort's ping-pong buffers (free once the tile passes are done) at the list's own offset; an odd
+// number of passes is followed by a copy back.  Two reads of the list per pass instead of none -- a few lists per frame, one per CU, in
+// place of three global passes over every pair of the frame (c5: 3 x (22 + 88) us), and no frame is ever re-run for the length of a list.
+__global__ __launch_bounds__(1024) void k_tile_depth_sort_xl(const uint2* __restrict__ ranges, uint32_t* vals_a, uint32_t* keys_a, uint32_t* vals_b,
+                                                             uint32_t* keys_b, uint32_t n_tiles, const uint32_t* __restrict__ long_list)
+{
+    constexpr uint32_t NW = 16u;
+    __shared__ uint32_t s_h[NW][256];
+    __shared__ uint32_t s_w[4], s_mn[NW], s_mx[NW];
+    const uint32_t* const xl_list = long_list + n_tiles + 1u;
+    const uint32_t n_xl = min(xl_list[0], n_tiles);                // written by the launch in front of this one
+    const uint32_t lane = threadIdx.x & 63u, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t t = blockIdx.x; t < n_xl; t += gridDim.x) {
+        const uint2 rgv = ranges[__builtin_amdgcn_readfirstlane(xl_list[1u + t])];
+        const uint32_t start = ~(uint32_t)__builtin_amdgcn_readfirstlane(rgv.x), n = (uint32_t)__builtin_amdgcn_readfirstlane(rgv.y) - start;
+        const uint32_t per = ((n + NW * 64u - 1u) / (NW * 64u)) * 64u;            // items per wave: whole 64-item rounds
+        const uint32_t lo = min(w * per, n), hi = min(lo + per, n);
+        // the list's key range
+        uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+        for (uint32_t i = lo + lane; i < hi; i += 64u) { const uint32_t k = keys_a[start + i]; mn = min(mn, k); mx = max(mx, k); }
+        for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); }
+        if (lane == 0u) { s_mn[w] = mn; s_mx[w] = mx; }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t q = 0; q < NW; q++) { mn = min(mn, s_mn[q]); mx = max(mx, s_mx[q]); }
+        mn = __builtin_amdgcn_readfirstlane(mn); mx = __builtin_amdgcn_readfirstlane(mx);
+        const uint32_t span = mx - mn;
+        uint32_t passes = 0, nb = 8u;
+        if (span != 0u) { const uint32_t bits = 32u - (uint32_t)__clz((int)span); passes = (bits + 7u) >> 3; nb = (bits + passes - 1u) / passes; }
+        const uint32_t dmask = (1u << nb) - 1u;
+        uint32_t* src_k = keys_a; uint32_t* src_v = vals_a; uint32_t* dst_k = keys_b; uint32_t* dst_v = vals_b;
+        for (uint32_t p = 0; p < passes; p++) {
+            const uint32_t shift = nb * p;
+            for (uint32_t q = threadIdx.x; q < NW * 256u; q += 1024u) (&s_h[0][0])[q] = 0u;
+            __syncthreads();
+            for (uint32_t r = lo; r < hi; r += 64u) {              // (wave-uniform bounds)
+                const bool valid = r + lane < hi;
+                const uint32_t dgt = ((src_k[start + min(r + lane, hi - 1u)] - mn) >> shift) & dmask;
+                const unsigned long long peers = match_digit(dgt, valid, nb);
+                if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+            }
+            __syncthreads();
+            // exclusive scan over (digit, wave): thread d < 256 owns digit d
+            uint32_t cnt[NW], tot = 0, inc = 0;
+            const bool dig = threadIdx.x < 256u;
+            const uint32_t d = threadIdx.x & 255u;
+            if (dig) {
+#pragma unroll
+                for (uint32_t q = 0; q < NW; q++) { cnt[q] = s_h[q][d]; tot += cnt[q]; }
+                inc = wave_incl_scan(tot, lane);
+                if (lane == 63u) s_w[w] = inc;
+            }
+            __syncthreads();
+            if (dig) {
+                uint32_t b = inc - tot;
+                for (uint32_t q = 0; q < w; q++) b += s_w[q];
+#pragma unroll
+                for (uint32_t q = 0; q < NW; q++) { s_h[q][d] = b; b += cnt[q]; }
+            }
+            __syncthreads();
+            for (uint32_t r = lo; r < hi; r += 64u) {
+                const bool valid = r + lane < hi;
+                const uint32_t i = start + min(r + lane, hi - 1u);
+                const uint32_t key = src_k[i], val = src_v[i];
+                const uint32_t dgt = ((key - mn) >> shift) & dmask;
+                const unsigned long long peers = match_digit(dgt, valid, nb);
+                const uint32_t rank = (uint32_t)__popcll(peers & lt);
+                uint32_t pos = 0;
+                if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+                pos = (uint32_t)__shfl((int)pos, valid ? (int)__ffsll((long long)peers) - 1 : (int)lane, 64) + rank;
+                if (valid) { dst_k[start + pos] = key; dst_v[start + pos] = val; }
+            }
+            __syncthreads();                                       // (the workgroup's global stores are visible to its own next pass)
+            uint32_t* tk = src_k; src_k = dst_k; dst_k = tk;
+            uint32_t* tv = src_v; src_v = dst_v; dst_v = tv;
+        }
+        if (passes & 1u) {                                         // the sorted slots lie in the other buffer: back to where the compositor reads
+            for (uint32_t i = threadIdx.x; i < n; i += 1024u) vals_a[start + i] = vals_b[start + i];
+        }
+        __syncthreads();
     }
 }
 
@@ -2984,15 +3075,17 @@ void launch_merge_copy(hipStream_t s, const MergeCopy* jobs, const uint2* blocks
 
 // GSWT_ORDER_DEPTH, tile-local path: depth-sorts every screen tile's slice of the (tile-sorted) pair list in LDS; dkeys = the pairs' depth
 // bits in the same order (the tile sort's payload)
-void launch_tile_depth_sort(hipStream_t s, const uint2* ranges, uint32_t* vals, const uint32_t* dkeys, int n_tiles, uint32_t* long_list,
-                            unsigned long long* counters)
+void launch_tile_depth_sort(hipStream_t s, const uint2* ranges, uint32_t* vals, uint32_t* dkeys, uint32_t* vals_scratch, uint32_t* dkeys_scratch, int n_tiles,
+                            uint32_t* long_list, unsigned long long* counters)
 {
     if (n_tiles <= 0) return;
-    // three size classes, one launch each: a wave per tile, a 256-thread workgroup per tile, a fixed grid over the list of still longer ones
+    // four size classes, one launch each: a wave per tile, a 256-thread workgroup per tile, a fixed grid over the list of still longer ones,
+    // and one over the list of those that do not fit LDS at all (long_list: [0] count, [1 .. n_tiles] tiles; the second list behind it)
     const uint32_t nt = (uint32_t)n_tiles;
-    GSWT_LAUNCH((k_tile_depth_sort<64, 8, false>), dim3(nt), dim3(64), s, ranges, vals, dkeys, nt, long_list, counters, 0u, 0u);
-    GSWT_LAUNCH((k_tile_depth_sort<256, 16, false>), dim3(nt), dim3(256), s, ranges, vals, dkeys, nt, long_list, counters, 512u, 1u);
-    GSWT_LAUNCH((k_tile_depth_sort<1024, 16, true>), dim3(kTileSortLongGrid), dim3(1024), s, ranges, vals, dkeys, nt, long_list, counters, 4096u, 0u);
+    GSWT_LAUNCH((k_tile_depth_sort<64, 8, false>), dim3(nt), dim3(64), s, ranges, vals, (const uint32_t*)dkeys, nt, long_list, counters, 0u, 0u);
+    GSWT_LAUNCH((k_tile_depth_sort<256, 16, false>), dim3(nt), dim3(256), s, ranges, vals, (const uint32_t*)dkeys, nt, long_list, counters, 512u, 1u);
+    GSWT_LAUNCH((k_tile_depth_sort<1024, 16, true>), dim3(kTileSortLongGrid), dim3(1024), s, ranges, vals, (const uint32_t*)dkeys, nt, long_list, counters, 4096u, 0u);
+    GSWT_LAUNCH(k_tile_depth_sort_xl, dim3(kTileSortLongGrid), dim3(1024), s, ranges, vals, dkeys, vals_scratch, dkeys_scratch, nt, (const uint32_t*)long_list);
 }
 uint32_t tile_depth_sort_cap() { return kTileSortCap; }
 

@@ -286,7 +286,8 @@ def test_radix_sort_is_stable_at_every_size(renderer, n, key_bits):
 @pytest.mark.gpu
 def test_tile_depth_sort_is_stable_at_every_class_boundary(renderer):
     """k_tile_depth_sort alone (gswt_debug_tile_depth_sort) against numpy's stable sort, slice by slice: empty tiles, one pair, the
-    boundaries of its three size classes (a wave up to 512 pairs, a 256-thread workgroup up to 4 096, the long-list grid up to 16 384),
+    boundaries of its four size classes (a wave up to 512 pairs, a 256-thread workgroup up to 4 096, the long-list grid up to 16 384 in LDS, beyond
+    that through global memory),
     ragged last rounds, one depth for a whole slice, spans of 1 .. 32 bits (one to four passes, digits of 1 .. 8 bits), many equal keys
     (ties keep the list's order: the order contract of scene.rs:685-695 inside a depth tie)."""
     import ctypes as C
@@ -319,13 +320,22 @@ def test_tile_depth_sort_is_stable_at_every_class_boundary(renderer):
         order = np.argsort(dk[at:at + m], kind="stable")
         assert np.array_equal(out[at:at + m], vals[at:at + m][order]), (i, m)
         at += m
-    # a slice beyond the LDS buffer is flagged (a frame would be re-run with the global passes); the others are still sorted
-    lens2 = np.asarray([100, 16385, 50], dtype=np.uint32)
-    n2 = int(lens2.sum())
-    dk2 = rng.integers(0, 1 << 20, size=n2, dtype=np.uint64).astype(np.uint32)
-    v2 = np.arange(n2, dtype=np.uint32)
+    # slices beyond the LDS buffer go through k_tile_depth_sort_xl (passes through global memory): odd and even pass counts, several per grid
+    lens2 = [100, 16385, 50, 40000, 0, 16384, 123457, 20000, 7]
+    spans = [12, 8, 5, 16, 1, 9, 24, 32, 3]
+    ks = []
+    for m, bits in zip(lens2, spans):
+        base = np.uint64(rng.integers(0, (1 << 32) - (1 << bits) + 1)) if bits < 32 else np.uint64(0)
+        ks.append((base + rng.integers(0, 1 << bits, size=m, dtype=np.uint64)).astype(np.uint32))
+    dk2 = np.concatenate(ks).astype(np.uint32)
+    n2 = int(dk2.size)
+    v2 = rng.permutation(n2).astype(np.uint32)
     o2 = v2.copy()
-    rc = lib.gswt_debug_tile_depth_sort(renderer._h, lens2.ctypes.data, lens2.size, o2.ctypes.data, dk2.ctypes.data, n2, C.byref(flagged))
-    assert rc == 0 and flagged.value == 1
-    assert np.array_equal(o2[:100], v2[:100][np.argsort(dk2[:100], kind="stable")])
-    assert np.array_equal(o2[-50:], v2[-50:][np.argsort(dk2[-50:], kind="stable")])
+    la2 = np.asarray(lens2, dtype=np.uint32)
+    rc = lib.gswt_debug_tile_depth_sort(renderer._h, la2.ctypes.data, la2.size, o2.ctypes.data, dk2.ctypes.data, n2, C.byref(flagged))
+    assert rc == 0 and flagged.value == 0
+    at = 0
+    for i, m in enumerate(lens2):
+        order = np.argsort(dk2[at:at + m], kind="stable")
+        assert np.array_equal(o2[at:at + m], v2[at:at + m][order]), (i, m)
+        at += m
