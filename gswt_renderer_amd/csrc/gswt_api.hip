@@ -335,8 +335,8 @@ struct gswt_ctx {
     uint32_t depth_passes = 3;
     uint32_t depth_passes_low_run = 0, depth_passes_low_max = 0;
     // ... or the tile-local path: tile passes first (depth bits as payload), then one kernel that depth-sorts each tile's slice in LDS.
-    // GSWT_OPT_DEPTH_SORT: 0 / 2 = tile-local while every screen tile's list fits k_tile_depth_sort's LDS buffer (k_items reports the longest;
-    // a frame that meets a longer one falls back by re-run), 1 = the global passes always.
+    // GSWT_OPT_DEPTH_SORT: 0 / 2 = tile-local (lists of any length: the ones beyond the LDS buffer go through global memory,
+    // k_tile_depth_sort_xl), 1 = the global passes.
     int opt_depth_sort = 0;
     int opt_item_order = 0;               // GSWT_OPT_ITEM_ORDER: 1 = the compositor's work items heaviest first (k_items)
     uint32_t depth_max_tile_len = 0;       // longest tile list of the last finished depth-ordered frame (0: none yet -- try tile-local)

@@ -1711,17 +1711,16 @@ __global__ __launch_bounds__(256) void k_mg_copy(const MergeCopy* __restrict__ j
 // 64-item rounds and ranks them with ballot match-any (in-wave order = list order), per-wave digit counters in LDS, one exclusive scan
 // over (digit, wave).  The digit width follows the tile's own key span: `passes` = ceil(bits / 8) digits of ceil(bits / passes) bits.
 //
-// Three size classes, one launch each (c3: 8 160 screen tiles, 4 679 of them sky; 2 133 lists of up to 512 pairs hold 18 % of the 2.66 M
+// Four size classes, one launch each (c3: 8 160 screen tiles, 4 679 of them sky; 2 133 lists of up to 512 pairs hold 18 % of the 2.66 M
 // pairs, 1 290 of 513 .. 4 096 hold 72 %, 58 longer ones 10 % -- tools/tile_lengths.py):
 //   <64, 8, false>    one WAVE per screen tile, lists of up to 512 pairs (5 KB of LDS, no barrier that costs anything)
 //   <256, 16, false>  one 256-thread workgroup per tile, 513 .. 4 096 pairs (36 KB); a longer list's tile id goes onto `long_list`
 //                     ([0] = count, cleared by k_cull)
 //   <1024, 16, true>  a fixed grid that walks long_list: up to 16 384 pairs per list (144 KB of LDS, one workgroup per CU)
+//   k_tile_depth_sort_xl (below)  lists beyond that: the same passes through global memory, one workgroup per list of a second list
 // (The first build -- one 512-thread / 64-KB workgroup for every tile, 32 unconditional loads per thread -- took 115 us at c3; the classes
 // as built here 12.6 + 27.9 + 16.0 us, each with ~4.8 us of launch floor, against 3 x (24.7 + 5.1) us for the global depth passes.  Other
 // cuts measured: profiles/r04_depth_sort_variants.txt.)
-// A list longer than that cannot be sorted here: the workgroup flags the frame (counters[3]), the host re-runs it with the global passes
-// and keeps them while k_items reports lists that long.
 // ------------------------------------------------------------------------------------
 constexpr uint32_t kTileSortCap = 16384u, kTileSortLongGrid = 256u;
 // WAVE: one wave of a larger workgroup sorts a list on its own (THREADS = 64): its LDS slices are private and a wave's LDS operations complete

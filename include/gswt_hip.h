@@ -202,10 +202,9 @@ enum { GSWT_OPT_NO_LOD_PREFILTER = 1, GSWT_OPT_DEBUG_VARYINGS = 2,
                                   are folded by whichever of their workgroups finishes last (agent-scope stores + a ticket per tile), tiles
                                   without pairs are work items: no k_combine launch behind the compositor.  Same image bit for bit */,
        GSWT_OPT_DEPTH_SORT = 14 /* how GSWT_ORDER_DEPTH orders the pairs: 0 (default) / 2 = tile passes first (depth bits as payload), then every
-                                   screen tile's slice is depth-sorted inside LDS (k_tile_depth_sort: lists up to 16 384 pairs; a frame with a
-                                   longer one is re-run with the global passes, and the frames after it take them until the lists are short
-                                   again); 1 = always global radix passes on the depth bits in front of the tile passes.  Same image bit for
-                                   bit */,
+                                   screen tile's slice is depth-sorted by one wave / workgroup (k_tile_depth_sort: inside LDS up to 16 384 pairs,
+                                   through global memory beyond); 1 = global radix passes on the depth bits in front of the tile passes.
+                                   Same image bit for bit */,
        GSWT_OPT_NO_CHUNK_CULL = 15 /* 1: the per-chunk frustum cull in front of the projection is off (every 256-entry chunk of a draw that
                                       survives the reference's tile cull is projected, as until round 3).  Same image bit for bit: the cull
                                       only leaves out chunks none of whose splats vs_main's own frustum test (gswt.wgsl:163-167) would keep */,
@@ -507,8 +506,8 @@ GSWT_API int gswt_debug_totals(gswt_ctx *ctx, const uint32_t *pair_sums, const u
 GSWT_API int gswt_debug_sort(gswt_ctx *ctx, uint32_t *keys, uint32_t *vals, size_t n, int key_bits);
 
 /* Test hook: the tile-local depth sort of GSWT_ORDER_DEPTH alone (k_tile_depth_sort).  lens[t] = length of screen tile t's slice of the pair
- * list (the slices lie back to back, n = their sum); every slice's vals are sorted by its dkeys, stably, in place.  *flagged_out = 1 when a
- * slice is longer than the kernel's LDS buffer holds (16 384 pairs: a frame would be re-run with the global depth passes).  Host pointers. */
+ * list (the slices lie back to back, n = their sum); every slice's vals are sorted by its dkeys, stably, in place (any length: slices of
+ * more than 16 384 pairs go through k_tile_depth_sort_xl).  *flagged_out: the frame-level error flag of the kernels (0).  Host pointers. */
 GSWT_API int gswt_debug_tile_depth_sort(gswt_ctx *ctx, const uint32_t *lens, size_t n_tiles, uint32_t *vals, const uint32_t *dkeys, size_t n,
                                         int *flagged_out);
 
