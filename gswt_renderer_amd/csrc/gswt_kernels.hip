@@ -1845,40 +1845,19 @@ __device__ __forceinline__ void tile_depth_sort_one(uint32_t tile, const uint2* 
     for (uint32_t i = tid; i < n; i += (uint32_t)THREADS) vals[start + i] = s_kv[i].y;
 }
 
-template <int THREADS, int ROUNDS, bool LONG>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 4 : 1, 8))) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* __restrict__ vals, const uint32_t* __restrict__ dkeys,
-                                                             uint32_t n_tiles, uint32_t* __restrict__ long_list, unsigned long long* __restrict__ counters,
-                                                             uint32_t n_lo, uint32_t push)
-{
-    constexpr int NW = THREADS / 64;
-    __shared__ uint2 s_kv[THREADS * ROUNDS];
-    __shared__ uint32_t s_h[NW][256];
-    __shared__ uint32_t s_w[4];
-    __shared__ uint32_t s_mn[NW], s_mx[NW];
-    if (!LONG) {
-        if (blockIdx.x < n_tiles) tile_depth_sort_one<THREADS, ROUNDS, LONG>(blockIdx.x, ranges, vals, dkeys, long_list, long_list + n_tiles + 1u, counters, n_lo, push != 0u, s_kv, s_h, s_w, s_mn, s_mx);
-    } else {
-        const uint32_t n_long = min(long_list[0], n_tiles);      // written by the launch in front of this one
-        for (uint32_t t = blockIdx.x; t < n_long; t += gridDim.x) {
-            tile_depth_sort_one<THREADS, ROUNDS, LONG>(long_list[1u + t], ranges, vals, dkeys, long_list, long_list + n_tiles + 1u, counters, n_lo, false, s_kv, s_h, s_w, s_mn, s_mx);
-            __syncthreads();                                      // the next list reuses the LDS
-        }
-    }
-}
-
-// k_tile_depth_sort_xl: the lists that do not fit the LDS buffer (more than 16 384 pairs: c5's horizon tiles hold up to 27 908, a small
+// tile_depth_sort_xl (k_tile_depth_sort_xl in the documents): the lists that do not fit the LDS buffer (more than 16 384 pairs: c5's horizon tiles hold up to 27 908, a small
 // framebuffer in front of a big scene more).  One 1 024-thread workgroup per list (a fixed grid over xl_list, which the 256-thread class
 // fills), the same stable LSD passes on (key - the list's smallest key), but the items stay in global memory: a pass counts the digits of
 // the list wave by wave (wave w owns one contiguous sixteenth of it, so in-wave order = list order), scans (digit, wave) in LDS, and
 // scatters into the other half of the sort's ping-pong buffers (free once the tile passes are done) at the list's own offset; an odd
 // number of passes is followed by a copy back.  Two reads of the list per pass instead of none -- a few lists per frame, one per CU, in
 // place of three global passes over every pair of the frame (c5: 3 x (22 + 88) us), and no frame is ever re-run for the length of a list.
-__global__ __launch_bounds__(1024) void k_tile_depth_sort_xl(const uint2* __restrict__ ranges, uint32_t* vals_a, uint32_t* keys_a, uint32_t* vals_b,
-                                                             uint32_t* keys_b, uint32_t n_tiles, const uint32_t* __restrict__ long_list)
+// Not a launch of its own: the long-list workgroups of k_tile_depth_sort<1024, 16, true> walk this list behind theirs (an empty launch is 4.8 us).
+__device__ __forceinline__ void tile_depth_sort_xl(const uint2* __restrict__ ranges, uint32_t* vals_a, uint32_t* keys_a, uint32_t* vals_b,
+                                                   uint32_t* keys_b, uint32_t n_tiles, const uint32_t* __restrict__ long_list,
+                                                   uint32_t (*s_h)[256], uint32_t* s_w, uint32_t* s_mn, uint32_t* s_mx)
 {
-    constexpr uint32_t NW = 16u;
-    __shared__ uint32_t s_h[NW][256];
-    __shared__ uint32_t s_w[4], s_mn[NW], s_mx[NW];
+    constexpr uint32_t NW = 16u;                                   // (called by the 1 024-thread long-list workgroups behind their own list)
     const uint32_t* const xl_list = long_list + n_tiles + 1u;
     const uint32_t n_xl = min(xl_list[0], n_tiles);                // written by the launch in front of this one
     const uint32_t lane = threadIdx.x & 63u, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1951,6 +1930,29 @@ __global__ __launch_bounds__(1024) void k_tile_depth_sort_xl(const uint2* __rest
             for (uint32_t i = threadIdx.x; i < n; i += 1024u) vals_a[start + i] = vals_b[start + i];
         }
         __syncthreads();
+    }
+}
+
+template <int THREADS, int ROUNDS, bool LONG>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(THREADS == 256 ? 4 : 1, 8))) void k_tile_depth_sort(const uint2* __restrict__ ranges, uint32_t* vals, uint32_t* dkeys,      // (no __restrict__: the last class writes both)
+                                                             uint32_t n_tiles, uint32_t* __restrict__ long_list, unsigned long long* __restrict__ counters,
+                                                             uint32_t n_lo, uint32_t push, uint32_t* vals_scratch, uint32_t* dkeys_scratch)
+{
+    constexpr int NW = THREADS / 64;
+    __shared__ uint2 s_kv[THREADS * ROUNDS];
+    __shared__ uint32_t s_h[NW][256];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_mn[NW], s_mx[NW];
+    if (!LONG) {
+        if (blockIdx.x < n_tiles) tile_depth_sort_one<THREADS, ROUNDS, LONG>(blockIdx.x, ranges, vals, dkeys, long_list, long_list + n_tiles + 1u, counters, n_lo, push != 0u, s_kv, s_h, s_w, s_mn, s_mx);
+    } else {
+        const uint32_t n_long = min(long_list[0], n_tiles);      // written by the launch in front of this one
+        for (uint32_t t = blockIdx.x; t < n_long; t += gridDim.x) {
+            tile_depth_sort_one<THREADS, ROUNDS, LONG>(long_list[1u + t], ranges, vals, dkeys, long_list, long_list + n_tiles + 1u, counters, n_lo, false, s_kv, s_h, s_w, s_mn, s_mx);
+            __syncthreads();                                      // the next list reuses the LDS
+        }
+        // ... and the lists beyond the LDS buffer, through global memory (dkeys is written there: the pass buffers alternate)
+        if (THREADS == 1024) tile_depth_sort_xl(ranges, vals, dkeys, vals_scratch, dkeys_scratch, n_tiles, long_list, s_h, s_w, s_mn, s_mx);
     }
 }
 
@@ -3078,13 +3080,13 @@ void launch_tile_depth_sort(hipStream_t s, const uint2* ranges, uint32_t* vals, 
                             uint32_t* long_list, unsigned long long* counters)
 {
     if (n_tiles <= 0) return;
-    // four size classes, one launch each: a wave per tile, a 256-thread workgroup per tile, a fixed grid over the list of still longer ones,
-    // and one over the list of those that do not fit LDS at all (long_list: [0] count, [1 .. n_tiles] tiles; the second list behind it)
+    // four size classes in three launches: a wave per tile, a 256-thread workgroup per tile, a fixed grid over the list of still longer ones
+    // which then also walks the list of those that do not fit LDS at all (long_list: [0] count, [1 .. n_tiles] tiles; the second list behind it)
     const uint32_t nt = (uint32_t)n_tiles;
-    GSWT_LAUNCH((k_tile_depth_sort<64, 8, false>), dim3(nt), dim3(64), s, ranges, vals, (const uint32_t*)dkeys, nt, long_list, counters, 0u, 0u);
-    GSWT_LAUNCH((k_tile_depth_sort<256, 16, false>), dim3(nt), dim3(256), s, ranges, vals, (const uint32_t*)dkeys, nt, long_list, counters, 512u, 1u);
-    GSWT_LAUNCH((k_tile_depth_sort<1024, 16, true>), dim3(kTileSortLongGrid), dim3(1024), s, ranges, vals, (const uint32_t*)dkeys, nt, long_list, counters, 4096u, 0u);
-    GSWT_LAUNCH(k_tile_depth_sort_xl, dim3(kTileSortLongGrid), dim3(1024), s, ranges, vals, dkeys, vals_scratch, dkeys_scratch, nt, (const uint32_t*)long_list);
+    GSWT_LAUNCH((k_tile_depth_sort<64, 8, false>), dim3(nt), dim3(64), s, ranges, vals, dkeys, nt, long_list, counters, 0u, 0u, vals_scratch, dkeys_scratch);
+    GSWT_LAUNCH((k_tile_depth_sort<256, 16, false>), dim3(nt), dim3(256), s, ranges, vals, dkeys, nt, long_list, counters, 512u, 1u, vals_scratch, dkeys_scratch);
+    GSWT_LAUNCH((k_tile_depth_sort<1024, 16, true>), dim3(kTileSortLongGrid), dim3(1024), s, ranges, vals, dkeys, nt, long_list, counters, 4096u, 0u,
+                vals_scratch, dkeys_scratch);
 }
 uint32_t tile_depth_sort_cap() { return kTileSortCap; }
 

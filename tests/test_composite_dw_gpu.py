@@ -85,6 +85,7 @@ def test_folded_combine_bit_identical_at_baseline_size(renderer, name, seg):
         for eps in (0.0, 1e-5):
             def frame():
                 out.fill_(-1.0)
+                torch.cuda.synchronize()           # (torch's stream: nothing orders its fill against the frame slot's stream)
                 renderer.render_wait(renderer.render_async(cu, su, W, Hh, out.data_ptr(), transmittance_eps=eps))
                 return out.cpu().numpy().copy(), renderer.timings()
             (a, ta) = _variant(renderer, 0, frame)

@@ -159,8 +159,10 @@ def test_depth_order_frames_replay_as_one_graph(renderer, depth_sort):
         g0 = renderer.graph_stats()
         renderer.set_option(L.GSWT_OPT_GRAPH, 1)
         tickets = []
-        for cu, o in zip(cams, outs):
+        for o in outs:
             o.zero_()
+        torch.cuda.synchronize()                        # (torch's fills run on ITS stream: nothing orders them against the frame slots' streams)
+        for cu, o in zip(cams, outs):
             if len(tickets) >= renderer.frame_slots():
                 renderer.render_wait(tickets.pop(0))
             tickets.append(renderer.render_async(cu, s["su"], W, Hh, o.data_ptr(), order_mode=L.GSWT_ORDER_DEPTH, transmittance_eps=1e-5))
@@ -172,8 +174,12 @@ def test_depth_order_frames_replay_as_one_graph(renderer, depth_sort):
         renderer.set_option(L.GSWT_OPT_TIMING, 2)
         renderer.set_option(L.GSWT_OPT_DEPTH_SORT, 0)
     assert g1[0] - g0[0] == len(cams)                   # every frame went through hipGraphLaunch
-    for a, o in zip(want, outs):
-        assert np.array_equal(a, o.cpu().numpy())
+    for i, (a, o) in enumerate(zip(want, outs)):
+        b = o.cpu().numpy()
+        if not np.array_equal(a, b):
+            dd = np.abs(a - b).max(axis=2)
+            ys, xs = np.nonzero(dd)
+            raise AssertionError(f"frame {i}: max diff {dd.max():.3e} at {len(ys)} pixels, screen tiles {sorted(set(zip((ys // 16).tolist(), (xs // 16).tolist())))[:8]}")
     assert not np.array_equal(want[0], want[-1])
 
 
