@@ -1114,7 +1114,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w /*
 // (what k_project does: 18 k of c3's 39 k chunks, 76 k of c5's 366 k; groups of 1 / 2 / 4 table entries): one more dependent load in
 // front of everything, 24 / 22 / 24 us at c3 and 223 / 170 / 143 us at c5 against 23 / 130 for four consecutive chunks (stage
 // events, gpurun_out s6) -- the workgroups of empty groups are not what the kernel's time is made of.
-// ... and neither is the barrier-separated walk over a workgroup's live chunks: ONE WAVE PER CHUNK (lane l owns slots 4 l .. 4 l + 3,
+// ... nor the rects read for chunks that turn out to have no pairs (round 4: the pair counts first, everything else only for the chunks
+// that have any -- c5 reads 750 MB of rects per frame for ~40 k of 366 k chunks: 131 us against 129, c3 18.5 either way);
+// and neither is the barrier-separated walk over a workgroup's live chunks: ONE WAVE PER CHUNK (lane l owns slots 4 l .. 4 l + 3,
 // offsets from one wave scan, the chunk's base from one wave reduction over its super-group's sums, no barrier, no LDS, the four
 // chunks of a workgroup side by side) ran in 20.6 us at c3 and 146 us at c5 against 19.9 / 127.
 constexpr uint32_t kEmitGroup = 4;
