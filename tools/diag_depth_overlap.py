@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Depth-ordered c3 frames one at a time against the same frames with every slot in flight (launch by launch and as one hipGraph per frame),
+after frames that leave the slots in other shapes (a dense scene, a small framebuffer with lists beyond the LDS buffer): prints every frame
+that differs and where.  usage: tools/diag_depth_overlap.py [first workload]   (GSWT_DIAG_REPS: repetitions, default 3)"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import bench
