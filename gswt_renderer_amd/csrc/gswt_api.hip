@@ -179,7 +179,7 @@ struct DrawSet {
     uint64_t longest = 0;
     Ref<DrawDev> draws;
     DevBuf<uint2> chunk_tab;
-    DevBuf<uint2> chunk_tab_xcd;           // chunk_tab in k_project's launch order: all chunks of a draw on XCD (draw % 8)
+    DevBuf<uint2> chunk_tab_xcd;           // chunk_tab in k_project's launch order: all chunks of a draw on one XCD (DrawDev::xcd)
     DevBuf<uint32_t> merged_list, merged_map;
     Ref<uint32_t> xcd_first;               // per draw: position of its first chunk in its XCD's launch list
     // what the merged arrays of this set hold, for the next sort event's reuse test (device-built sets only)
@@ -891,15 +891,21 @@ static int set_draws_impl(gswt_ctx* c, const gswt_draw* draws, int n_draws, cons
     if (entries >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: %llu list entries exceed 2^32", (unsigned long long)entries);
     // composite-order slots: the LAST draw is nearest (drawn last = on top), so it gets the lowest slots.  A chunk = 256 list
     // entries of one draw; chunk c of the frame = slot c * 256.  The two chunk tables (slot order; k_project's launch order:
-    // per-XCD lists, XCD = draw % 8, interleaved so that position p runs on XCD p % 8) are written on the DEVICE from the
+    // per-XCD lists, a draw's XCD = DrawDev::xcd, interleaved so that position p runs on XCD p % 8) are written on the DEVICE from the
     // draw records (k_chunk_tabs): the host only sums the O(#draws) counts, and a sort event uploads O(#draws) bytes.
     uint64_t slot = 0, per_xcd[8] = {};
     for (int i = n_draws - 1; i >= 0; i--) {
         DrawDev& d = dd[i];
         d.slot_base = (uint32_t)slot;
         const uint32_t nch = (d.count + kChunk - 1) / kChunk;
-        h_xcd_first[i] = (uint32_t)per_xcd[i & 7];
-        per_xcd[i & 7] += nch;
+        // all chunks of a draw on one XCD (its gathers stay in that XCD's L2): the least loaded one.  (draw % 8 until round 4: a few merged
+        // groups of ~190 chunks each made the longest of the eight lists 2.6 x the mean at c3 -- 42.8 k launch positions for 16.3 k chunks,
+        // and every position past an XCD's live count is a workgroup that starts, reads the count and leaves.)
+        int x = 0;
+        for (int q = 1; q < 8; q++) if (per_xcd[q] < per_xcd[x]) x = q;
+        d.xcd = (uint32_t)x;
+        h_xcd_first[i] = (uint32_t)per_xcd[x];
+        per_xcd[x] += nch;
         slot += (uint64_t)nch * kChunk;
     }
     if (slot >= 0xFFFFFFFFull) return fail(c, GSWT_ERR_CAPACITY, "gswt_set_draws: slot space exceeds 2^32");

@@ -35,6 +35,7 @@ struct DrawDev {
     uint32_t tile_view;       // tile_id.z (debug draw mode 4)
     uint32_t map_coord[2];    // TileUniforms.map_coord (sphere surface)
     uint32_t box_base;        // static draws: first chunk box of the draw's list (chunk k = the k-th 256 entries from the END of the list); ~0: none
+    uint32_t xcd;             // the XCD (0..7) all chunks of this draw are projected on (gswt_set_draws: the least loaded one when the draw is planned)
 };
 
 // Per-frame constants (kernel argument, by value).

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_chunk_tabs(const DrawDev* __restrict__ 
     for (uint32_t k = threadIdx.x; k < nch; k += 256u) {
         const uint2 e = make_uint2(d, k * (uint32_t)kChunk);
         chunk_tab[c0 + k] = e;
-        chunk_tab_xcd[(size_t)(x0 + k) * 8u + (d & 7u)] = e;
+        chunk_tab_xcd[(size_t)(x0 + k) * 8u + (draws[d].xcd & 7u)] = e;
     }
 }
 
@@ -372,7 +372,7 @@ __device__ __forceinline__ bool draw_is_culled(const Frame& f, const DrawDev& d)
 // k_cull (first kernel of the frame): clears the per-frame accumulators (saves three memset launches), fills the band-cull table of a
 // column-band shard, and builds the launch table of k_project for THIS frame, one thread per chunk (a chunk = 256 list entries of one draw): only the chunks of
 // the draws that survive the reference's per-draw cull (draw_is_culled: every chunk's thread evaluates its own draw's -- until late in round 4 a
-// kernel of its own in front of this one, one launch and ~6 us more), in the per-XCD layout of chunk_tab_xcd (position k * 8 + x runs on XCD x = draw % 8; the order inside an
+// kernel of its own in front of this one, one launch and ~6 us more), in the per-XCD layout of chunk_tab_xcd (position k * 8 + x runs on XCD x = the draw's DrawDev::xcd; the order inside an
 // XCD's list is the order of the atomic adds: irrelevant, a chunk's output slots are fixed).  An entry carries what the chunk's first load
 // needs -- the list position of its lane 0 and the list's length and arena -- so that k_project's list-word load does not wait for the draw record.
 // Round 4: CHUNK-LEVEL FRUSTUM CULL.  The reference culls whole tile draws on the CPU (renderer.rs:472-494: min |x|, min |y|, max z of the four
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
             }
             if (xp || xn || yp || yn || zn) live = false;
         }
-        x = ct.x & 7u;
+        x = d.xcd & 7u;
         if (live) {
             e = make_uint4(ct.x, ct.y, d.list_base + d.count - 1u - ct.y, d.count | (d.merged ? 0x80000000u : 0u));
             rank = atomicAdd(&s_cnt[x], 1u);
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256 * HALVES) void k_project(
     static_assert(HALVES == 1 || !DEBUG, "the debug-varyings build visits the static chunk table one entry per workgroup");
     __shared__ uint32_t s_wsum[4 * HALVES], s_wvis[4 * HALVES];
     // chunk_tab is in LAUNCH order, which is not slot order: workgroup b runs on XCD b % 8, and the table is laid out so
-    // that all chunks of a draw land on one XCD (draw % 8) -- a draw's gathers stay inside one tile type's 313 KB of the
+    // that all chunks of a draw land on one XCD (DrawDev::xcd) -- a draw's gathers stay inside one tile type's 313 KB of the
     // record table, so an XCD's 4 MB L2 then holds the few tile types it is working on instead of all 48 (6.6 MB).
     // The normal frame launches over k_cull's table of live chunks (same layout, culled draws left out; workgroups past an XCD's
     // live count exit after one cached scalar load); the debug-varyings build visits every chunk through the static table.
