@@ -1114,6 +1114,8 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w /*
 // (what k_project does: 18 k of c3's 39 k chunks, 76 k of c5's 366 k; groups of 1 / 2 / 4 table entries): one more dependent load in
 // front of everything, 24 / 22 / 24 us at c3 and 223 / 170 / 143 us at c5 against 23 / 130 for four consecutive chunks (stage
 // events, gpurun_out s6) -- the workgroups of empty groups are not what the kernel's time is made of.
+// (Round 4: nor the splats that cover many screen tiles -- a slot writing at most eight of its pairs itself and the workgroup the rest, 256
+// consecutive pairs per step, from a queue in LDS: c3 18.7 us either way, c5 165 against 124, the dense c3d 277 against 46.)
 // (Round 4, c5 again -- 366 k chunks, ~40 k with pairs: sixteen chunks per workgroup, the sixteen pair counts first and then each chunk that has
 // pairs with loads of its own: 180 us against 129, c3 36.7 against 18.7.)
 // ... nor the rects read for chunks that turn out to have no pairs (round 4: the pair counts first, everything else only for the chunks
