@@ -29,7 +29,7 @@
 
 namespace gswt {
 void launch_cull(hipStream_t, const Frame&, const DrawDev*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t*, uint32_t,
-                 uint32_t*, uint4*, uint32_t*, uint32_t, const uint2*, uint32_t, const float*, bool);
+                 uint32_t*, uint4*, uint32_t*, uint32_t, const uint2*, uint32_t, const float*, bool, uint32_t*);
 void launch_merge_copy(hipStream_t, const MergeCopy*, const uint2*, uint32_t, const uint2*, const MergeSources&, uint32_t*, uint32_t*);
 void launch_chunk_tabs(hipStream_t, const DrawDev*, const uint32_t*, uint32_t, uint2*, uint2*, const uint64_t*, uint64_t);
 size_t radix_ws_words(uint32_t, int);
@@ -41,7 +41,7 @@ void launch_project(hipStream_t, bool, const Frame&, const DrawDev*, const uint2
                     unsigned long long*, Varyings*, float4*, uint32_t, bool);
 void launch_totals(hipStream_t, uint32_t*, uint32_t, unsigned long long*, uint32_t);
 void launch_emit(hipStream_t, const Frame&, uint32_t, const uint2*, const uint32_t*, const uint32_t*, uint32_t, unsigned long long*,
-                 uint32_t*, uint32_t*, const float*, uint32_t*, uint32_t*);
+                 uint32_t*, uint32_t*, const float*, uint32_t*, uint32_t*, const uint32_t*, const uint32_t*, uint32_t);
 int launch_sort(hipStream_t, uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, const unsigned long long*, int, uint32_t*, uint2* = nullptr,
                 const uint32_t* = nullptr, uint32_t* = nullptr, uint32_t* = nullptr);
 void launch_composite(hipStream_t, const Frame&, const uint2*, const uint32_t*, const Rec*, const float*, const float4*, const float4*, const float*, float4*, int, int,
@@ -238,7 +238,8 @@ struct FrameSlot {
     DevBuf<uint2> rects;
     DevBuf<Rec> recs;
     DevBuf<uint4> live_tab;                // this frame's launch table of k_project: the chunks of the draws that survive k_cull
-    DevBuf<uint32_t> live_cnt;             // entries per XCD list of live_tab (8 words, a cache line apart; zero between frames)
+    DevBuf<uint32_t> live_cnt;             // entries per XCD list of live_tab (8 words, a cache line apart; zero between frames) + k_totals' copy for k_emit
+    DevBuf<uint32_t> live_cid;             // live_tab's chunks as chunk numbers in slot order (k_emit walks the same table)
     DevBuf<uint32_t> cell_culled;          // column-band shards: per map cell, 1 = no splat of that tile instance can reach the band
     DevBuf<uint32_t> block_sums, draw_culled, scan_ws, keys_a, keys_b, vals_a, vals_b, ghist;
     DevBuf<uint2> ranges;
@@ -266,7 +267,7 @@ struct FrameSlot {
     }
     void release_buffers()
     {
-        rects.release(); recs.release(); cell_culled.release(); live_tab.release(); live_cnt.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
+        rects.release(); recs.release(); cell_culled.release(); live_tab.release(); live_cid.release(); live_cnt.release(); block_sums.release(); draw_culled.release(); scan_ws.release(); keys_a.release();
         keys_b.release(); vals_a.release(); vals_b.release(); ghist.release(); ranges.release(); item_base.release();
         aux_a.release(); aux_b.release(); partials.release(); item_tab.release(); col_f.release(); depths.release();
     }
@@ -1322,10 +1323,11 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
         HIP_TRY(c, sl.recs.ensure(n_slots_all + 1));
         HIP_TRY(c, sl.block_sums.ensure_roomy((size_t)D.n_chunks + 1));
         HIP_TRY(c, sl.live_tab.ensure_roomy((size_t)D.n_launch + 8));
+        HIP_TRY(c, sl.live_cid.ensure_roomy((size_t)D.n_launch + 8));
         // (cleared ON THE SLOT'S STREAM: the slot streams are non-blocking, so a null-stream hipMemset -- asynchronous to the host for
         // device memory -- could land after this frame's k_cull had filled the counts: the slot's FIRST frame then projected nothing
         // and came back as background.  Seen once five slots made test_async_all_slots_in_flight_and_slot_reuse the first user of slot 4.)
-        if (!sl.live_cnt.p) { HIP_TRY(c, sl.live_cnt.ensure(8 * kSuperStride)); HIP_TRY(c, hipMemsetAsync(sl.live_cnt.p, 0, sl.live_cnt.cap * 4, s)); }
+        if (!sl.live_cnt.p) { HIP_TRY(c, sl.live_cnt.ensure(16 * kSuperStride)); HIP_TRY(c, hipMemsetAsync(sl.live_cnt.p, 0, sl.live_cnt.cap * 4, s)); }
         HIP_TRY(c, sl.draw_culled.ensure_roomy((size_t)D.n_draws + 1));
         if (su->draw_mode != 0u) HIP_TRY(c, sl.col_f.ensure(n_slots_all + 1));
         if (a.d_bgd || cfg->order_mode == GSWT_ORDER_DEPTH) HIP_TRY(c, sl.depths.ensure(n_slots_all + 1));
@@ -1491,7 +1493,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     const size_t n_zero_a = 16 + n_super2 + rz_pair;
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
                 reinterpret_cast<uint32_t*>(sl.ranges.p), ((uint32_t)n_tiles + 1u) * 2u + (uint32_t)n_tiles + ((uint32_t)n_tiles + 2u), sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
-                d_radix_depth, (uint32_t)rz_depth, D.chunk_tab.p, D.n_chunks, c->static_boxes.p, c->opt_no_chunk_cull == 0 && !dbg);
+                d_radix_depth, (uint32_t)rz_depth, D.chunk_tab.p, D.n_chunks, c->static_boxes.p, c->opt_no_chunk_cull == 0 && !dbg, sl.live_cid.p);
     launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p, sl.col_f.p, cap, sl.strict_vs);
@@ -1502,13 +1504,13 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // depths in composite order.  The last tile pass also leaves every screen tile's [start, end) of the sorted list in sl.ranges (zeroed by k_cull).
     const uint32_t* vals_sorted = nullptr;
     if (!depth_order) {
-        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, nullptr, nullptr, nullptr);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, nullptr, nullptr, nullptr, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, D.n_launch);
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p);
         vals_sorted = where ? sl.vals_b.p : sl.vals_a.p;
     } else if (sl.depth_local) {
         // tile-local path: tile ids are the sort key, the depth bits its payload; then every tile's slice is depth-sorted in LDS
-        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, sl.depths.p, sl.aux_a.p, nullptr);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, sl.depths.p, sl.aux_a.p, nullptr, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, D.n_launch);
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p, nullptr, sl.aux_a.p, sl.aux_b.p);
         uint32_t* const vals_t = where ? sl.vals_b.p : sl.vals_a.p;
@@ -1516,7 +1518,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
                                d_long_tiles, d_counters);
         vals_sorted = vals_t;
     } else {
-        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.aux_a.p, sl.vals_a.p, sl.depths.p, sl.keys_a.p, d_krange);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.aux_a.p, sl.vals_a.p, sl.depths.p, sl.keys_a.p, d_krange, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, D.n_launch);
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int wd = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, depth_bits, d_radix_depth, nullptr, d_krange, sl.aux_a.p, sl.aux_b.p);
         // (the depth keys are dead now: keys_a serves as the other half of the tile-key ping-pong)

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
                                               uint32_t* __restrict__ zero_a, uint32_t n_zero_a, uint32_t* __restrict__ zero_b, uint32_t n_zero_b,
                                               uint32_t* __restrict__ zero_c, uint32_t n_zero_c, uint32_t* __restrict__ zero_d, uint32_t n_zero_d,
                                               const uint2* __restrict__ chunk_tab, uint32_t n_chunks, const float* __restrict__ boxes, uint32_t chunk_cull,
-                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab)
+                                              uint32_t* __restrict__ live_cnt, uint4* __restrict__ live_tab, uint32_t* __restrict__ live_cid)
 {
     __shared__ uint32_t s_cnt[8], s_base[8];
     if (threadIdx.x < 8u) s_cnt[threadIdx.x] = 0u;
@@ -469,7 +469,10 @@ __global__ __launch_bounds__(256) void k_cull(const Frame f, const DrawDev* __re
     __syncthreads();
     if (threadIdx.x < 8u && s_cnt[threadIdx.x] != 0u) s_base[threadIdx.x] = atomicAdd(&live_cnt[threadIdx.x * kSuperStride], s_cnt[threadIdx.x]);      // (a cache line per XCD's count: gswt_device.h)
     __syncthreads();
-    if (live) live_tab[(size_t)(s_base[x] + rank) * 8u + x] = e;
+    if (live) {
+        live_tab[(size_t)(s_base[x] + rank) * 8u + x] = e;
+        live_cid[(size_t)(s_base[x] + rank) * 8u + x] = c;       // the chunk's number in slot order (k_emit walks the same table)
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1034,7 +1037,10 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ sup
 {
     // k_project is done with this frame's live-chunk counts: cleared here for the slot's next frame (k_cull both clears
     // buffers and adds to these counters, so it cannot clear them itself)
-    if (live_cnt && threadIdx.x < 8u) live_cnt[threadIdx.x * kSuperStride] = 0u;
+    if (live_cnt && threadIdx.x < 8u) {
+        live_cnt[(8u + threadIdx.x) * kSuperStride] = live_cnt[threadIdx.x * kSuperStride];      // (k_emit runs behind this kernel and walks the same table)
+        live_cnt[threadIdx.x * kSuperStride] = 0u;
+    }
     __shared__ unsigned long long s_v[4];
     __shared__ uint32_t s_w[4];
     unsigned long long v = 0;
@@ -1148,23 +1154,48 @@ __device__ __forceinline__ uint32_t block_scan_and_sum(uint32_t v, uint32_t r, u
 // depths in composite order.  Round 4's first version sorted the emitting SPLATS by depth and emitted the pairs in that order (compaction,
 // three passes with the tile rect as payload, per-group pair counts, a scan, the emission: five more kernels and 111 us per c3 frame);
 // keying the PAIRS costs one more 4-byte word per pair in k_emit and in the depth passes and needs none of that.
-template <bool DEPTH>
+// TAB (the default since the end of round 4; GSWT_EMIT_TAB=0: four consecutive chunks of the frame): the workgroup takes four entries of k_cull's table of live chunks (k_project's launch table: one XCD's list, so the chunks are not
+// neighbours in slot order -- they need not be: a chunk's first pair comes from the prefix arrays) instead of four consecutive chunks of
+// the frame.  At c3 73 % of the chunks are not live, and 39 % of this kernel's workgroup-time was workgroups that loaded four zeros and left
+// (tools/emit_trace.py); the price is one more dependent load in front of everything.  One frame at a time the kernel takes what it took (c3 18.9
+// against 18.7 us, c5 125 against 124 -- as in round 2, when the table held 46 % of the chunks), but with frames in flight the workgroups that
+// are no longer launched leave their slots to the other frames' kernels: c5 fly path 719-720 against 692-698 frames/s, c3 the same.
+template <bool DEPTH, bool TAB>
 __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __restrict__ rects,
                                               const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ super_excl,
                                               uint32_t n_chunks, uint32_t pair_cap, unsigned long long* __restrict__ counters,
                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                              const float* __restrict__ depths, uint32_t* __restrict__ dkeys, uint32_t* __restrict__ krange)
+                                              const float* __restrict__ depths, uint32_t* __restrict__ dkeys, uint32_t* __restrict__ krange,
+                                              const uint32_t* __restrict__ live_cnt2, const uint32_t* __restrict__ live_cid)
 {
     __shared__ uint32_t s_w[8];
     __shared__ uint32_t s_mn[DEPTH ? 4 : 1], s_mx[DEPTH ? 4 : 1];
+#ifdef GSWT_TRACE
+    // phase stamps of k_emit (tools/emit_trace.py), rows 81920 + workgroup: [0] entry, [1] every load has arrived, [2] exit, [3] chunks with pairs, [4] pairs
+    const bool tr_on = threadIdx.x == 0 && blockIdx.x < 8192u;
+    const uint32_t tr_item = 81920u + blockIdx.x;
+    uint32_t tr_live = 0, tr_pairs = 0;
+    GSWT_TR(0, GSWT_NOW())
+    GSWT_TR(2, 0ull)
+#endif
     uint32_t cid[kEmitGroup], sums[kEmitGroup], bs[kEmitGroup], sbase[kEmitGroup];
     uint2 rcs[kEmitGroup];
     float dep[kEmitGroup];
     uint32_t kmn = 0xFFFFFFFFu, kmx = 0u;
-    const uint32_t c0 = blockIdx.x * kEmitGroup;
-    const uint32_t n_mine = min(kEmitGroup, n_chunks - c0);
+    uint32_t n_mine;
+    if (TAB) {
+        const uint32_t x = blockIdx.x & 7u, k0 = (blockIdx.x >> 3) * kEmitGroup;
+        const uint32_t n_live = live_cnt2[x * kSuperStride];
+        if (k0 >= n_live) return;
+        n_mine = min(kEmitGroup, n_live - k0);
 #pragma unroll
-    for (uint32_t k = 0; k < kEmitGroup; k++) cid[k] = min(c0 + k, n_chunks - 1u);
+        for (uint32_t k = 0; k < kEmitGroup; k++) cid[k] = min(live_cid[(size_t)min(k0 + k, n_live - 1u) * 8u + x], n_chunks - 1u);
+    } else {
+        const uint32_t c0 = blockIdx.x * kEmitGroup;
+        n_mine = min(kEmitGroup, n_chunks - c0);
+#pragma unroll
+        for (uint32_t k = 0; k < kEmitGroup; k++) cid[k] = min(c0 + k, n_chunks - 1u);
+    }
     // All loads are issued together with clamped indices (masked loads are waited for one at a time): the chunks' pair counts, the
     // sums of the chunks in front of each inside its super-group, the super-group prefixes and the tile rects of this thread's slot
     // in every chunk.
@@ -1179,6 +1210,14 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
     uint32_t any = 0;
 #pragma unroll
     for (uint32_t k = 0; k < kEmitGroup; k++) { if (k >= n_mine) sums[k] = 0u; any |= sums[k]; }
+#ifdef GSWT_TRACE
+    { unsigned long long sink = sums[0] + bs[0] + sbase[3] + rcs[0].x + rcs[3].y; asm volatile("" :: "v"(sink)); }
+    GSWT_TR(1, GSWT_NOW())
+    for (uint32_t k = 0; k < kEmitGroup; k++) { tr_live += sums[k] ? 1u : 0u; tr_pairs += sums[k]; }
+    GSWT_TR(3, tr_live)
+    GSWT_TR(4, tr_pairs)
+    if (any == 0u) { GSWT_TR(2, GSWT_NOW()) }
+#endif
     if (any == 0u) return;
     const int sc = f.shard_count <= 1 ? 1 : f.shard_count;
 #pragma unroll
@@ -1226,6 +1265,7 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
             }
         }
     }
+    GSWT_TR(2, GSWT_NOW())
     if (DEPTH && krange) {                                      // (the tile-local depth sort takes each tile's own range: no krange)
         // key range of the frame: one guarded atomic pair per workgroup.  (One pair per WAVE on the two words is tens of thousands of
         // atomics on two addresses, which the memory side serialises at ~8 ns each.)  The words only grow ([0] holds ~min), so a stale read
@@ -2947,13 +2987,13 @@ GraphRec*& graph_recorder()
 void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, uint32_t* cell_culled, uint32_t n_cells,
                  uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b, uint32_t* zero_c, uint32_t n_zero_c,
                  uint32_t* live_cnt, uint4* live_tab, uint32_t* zero_d, uint32_t n_zero_d,
-                 const uint2* chunk_tab, uint32_t n_chunks, const float* boxes, bool chunk_cull)
+                 const uint2* chunk_tab, uint32_t n_chunks, const float* boxes, bool chunk_cull, uint32_t* live_cid)
 {
     (void)n_draws;
     uint32_t grid = (n_chunks + 255u) / 256u;              // one thread per chunk; the clears and the cell table stride over the grid
     if (grid < 32) grid = 32;
     GSWT_LAUNCH(k_cull, dim3(grid), dim3(256), s, f, draws, draw_culled, cell_culled, n_cells, zero_a, n_zero_a, zero_b, n_zero_b, zero_c, n_zero_c, zero_d, n_zero_d,
-                chunk_tab, n_chunks, boxes, chunk_cull && boxes ? 1u : 0u, live_cnt, live_tab);
+                chunk_tab, n_chunks, boxes, chunk_cull && boxes ? 1u : 0u, live_cnt, live_tab, live_cid);
 }
 
 void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* draws, const uint2* chunk_tab, uint32_t n_launch, uint32_t n_chunks,
@@ -2987,14 +3027,25 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
 // keys: tile ids, vals: slots.  GSWT_ORDER_DEPTH (dkeys != nullptr): also each pair's depth bits -> dkeys and the frame's key range -> krange.
 void launch_emit(hipStream_t s, const Frame& f, uint32_t n_chunks, const uint2* rects, const uint32_t* block_sums,
                  const uint32_t* super_sums, uint32_t pair_cap, unsigned long long* counters, uint32_t* keys, uint32_t* vals,
-                 const float* depths, uint32_t* dkeys, uint32_t* krange)
+                 const float* depths, uint32_t* dkeys, uint32_t* krange, const uint32_t* live_cnt, const uint32_t* live_cid, uint32_t n_launch)
 {
     if (n_chunks == 0) return;
     const uint32_t n_super = n_chunks / 256u + 1u;      // [pairs x n_super][visible x n_super][exclusive pair prefix x n_super]
-    const dim3 grid((n_chunks + kEmitGroup - 1u) / kEmitGroup);
-    if (dkeys) GSWT_LAUNCH(k_emit<true>, grid, dim3(256), s, f, rects, block_sums, super_sums + 2u * kSuperStride * n_super, n_chunks, pair_cap, counters, keys, vals, depths, dkeys, krange);
-    else GSWT_LAUNCH(k_emit<false>, grid, dim3(256), s, f, rects, block_sums, super_sums + 2u * kSuperStride * n_super, n_chunks, pair_cap, counters, keys, vals,
-                     (const float*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    const uint32_t* const excl = super_sums + 2u * kSuperStride * n_super;
+    const float* const no_f = nullptr; uint32_t* const no_u = nullptr;
+    // over k_cull's table of live chunks (GSWT_EMIT_TAB=0: over every chunk of the frame, four consecutive ones per workgroup)
+    static const bool tab = !(getenv("GSWT_EMIT_TAB") && atoi(getenv("GSWT_EMIT_TAB")) == 0);
+    if (tab && live_cnt && live_cid && n_launch) {
+        const uint32_t* const cnt2 = live_cnt + 8u * kSuperStride;               // k_totals' copy of the live counts
+        const dim3 grid(((n_launch / 8u + kEmitGroup - 1u) / kEmitGroup) * 8u);
+        if (dkeys) GSWT_LAUNCH((k_emit<true, true>), grid, dim3(256), s, f, rects, block_sums, excl, n_chunks, pair_cap, counters, keys, vals, depths, dkeys, krange, cnt2, live_cid);
+        else GSWT_LAUNCH((k_emit<false, true>), grid, dim3(256), s, f, rects, block_sums, excl, n_chunks, pair_cap, counters, keys, vals, no_f, no_u, no_u, cnt2, live_cid);
+    } else {
+        const dim3 grid((n_chunks + kEmitGroup - 1u) / kEmitGroup);
+        const uint32_t* const no_c = nullptr;
+        if (dkeys) GSWT_LAUNCH((k_emit<true, false>), grid, dim3(256), s, f, rects, block_sums, excl, n_chunks, pair_cap, counters, keys, vals, depths, dkeys, krange, no_c, no_c);
+        else GSWT_LAUNCH((k_emit<false, false>), grid, dim3(256), s, f, rects, block_sums, excl, n_chunks, pair_cap, counters, keys, vals, no_f, no_u, no_u, no_c, no_c);
+    }
 }
 
 // Sorts (keys, vals) by key bits [0, key_bits); the pair count is read on the device (*n_ptr), grids are
