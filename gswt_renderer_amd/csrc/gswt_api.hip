@@ -249,6 +249,8 @@ struct FrameSlot {
     bool strict_vs = false;                // GSWT_OPT_STRICT_VS as it stood when the frame was submitted (a re-run keeps it)
     uint32_t depth_passes = 0;             // GSWT_ORDER_DEPTH: radix passes this frame's depth sort was launched with
     bool depth_local = false;              // ... or the tile-local depth sort (k_tile_depth_sort)
+    bool full_grid = false;                // this (re-run) frame launches k_project / k_emit over the whole launch table, whatever the hint says
+    uint32_t n_launch_eff = 0;             // positions of the launch table this frame's grids cover
     DevBuf<float4> partials;
     DevBuf<float4> col_f;                  // debug draw modes: float colours per slot
     DevBuf<float> depths;                  // per-slot depth: frames with a proxy depth buffer or GSWT_ORDER_DEPTH only
@@ -340,6 +342,15 @@ struct gswt_ctx {
     // k_tile_depth_sort_xl), 1 = the global passes.
     int opt_depth_sort = 0;
     int opt_item_order = 0;               // GSWT_OPT_ITEM_ORDER: 1 = the compositor's work items heaviest first (k_items)
+    // Launch grids of k_project / k_emit: the launch table has a position for every chunk of the draw list, the frame's live chunks fill its
+    // head (k_cull), and every position past an XCD's live count is a workgroup that starts, reads the count and leaves -- 300 k of them at c5.
+    // The grids cover the longest live list of the last finished frame (k_totals reports it) + 50 % + 256; a frame whose own lists turn out
+    // longer is flagged by k_totals and re-run with the full grid, like a pair overflow.  (+ 25 % + 64 was too tight on c3's fly path: a sort
+    // event re-balances the lists, frames were re-run, 5 250-5 310 against 5 440-5 470 frames/s; with + 50 % c3's grid is the whole table again
+    // -- 17.8 k positions for 10.7 k live chunks -- and c5's is 80 k of 366 k: 736-742 against 723-728 frames/s.  The cut is only taken where it
+    // removes at least half of the grid.)
+    uint32_t live_hint = 0;                // longest live list (per XCD) of the last finished frame; 0: none yet
+    int opt_no_grid_hint = 0;              // GSWT_NO_GRID_HINT=1 (environment): always the full grid
     uint32_t depth_max_tile_len = 0;       // longest tile list of the last finished depth-ordered frame (0: none yet -- try tile-local)
     unsigned long long stat_depth_local = 0, stat_depth_global = 0;     // depth-ordered frames enqueued on either path (re-runs included)
     int last_slot = 0;
@@ -548,6 +559,7 @@ try {
     // streams that share a queue run one behind the other.  The layout string names the order: c = ctx stream, 0-4 = frame slot
     // streams, s = the stream of the sort-event builds, p = a placeholder that is never used; a slot stream the string leaves out is
     // created when that slot is first used.  (GSWT_STREAM_LAYOUT overrides it: tuning only.)
+    c->opt_no_grid_hint = getenv("GSWT_NO_GRID_HINT") && atoi(getenv("GSWT_NO_GRID_HINT")) != 0;
     const char* layout = getenv("GSWT_STREAM_LAYOUT");
     if (!layout || !*layout) layout = kStreamLayout;
     for (const char* q = layout; *q; q++) {
@@ -1494,7 +1506,15 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     launch_cull(s, f, D.draws.p, D.n_draws, sl.draw_culled.p, sl.cell_culled.p, n_cells, zero_a, (uint32_t)n_zero_a,
                 reinterpret_cast<uint32_t*>(sl.ranges.p), ((uint32_t)n_tiles + 1u) * 2u + (uint32_t)n_tiles + ((uint32_t)n_tiles + 2u), sl.block_sums.p, D.n_chunks, sl.live_cnt.p, sl.live_tab.p,
                 d_radix_depth, (uint32_t)rz_depth, D.chunk_tab.p, D.n_chunks, c->static_boxes.p, c->opt_no_chunk_cull == 0 && !dbg, sl.live_cid.p);
-    launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, D.n_launch, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
+    {
+        uint64_t eff = D.n_launch;
+        if (!dbg && !sl.full_grid && !c->opt_no_grid_hint && c->live_hint) {
+            const uint64_t cut = 8ull * ((uint64_t)c->live_hint + c->live_hint / 2 + 256);
+            if (cut * 2 <= eff) eff = cut;                     // (only where it removes most of the grid: a re-run costs a frame)
+        }
+        sl.n_launch_eff = (uint32_t)eff;
+    }
+    launch_project(s, dbg, f, D.draws.p, D.chunk_tab_xcd.p, sl.n_launch_eff, D.n_chunks, c->static_list.p, D.merged_list.p, D.merged_map.p,
                    c->tex.p, c->hmap.p, sl.draw_culled.p, sl.cell_culled.p, sl.live_cnt.p, sl.live_tab.p, sl.rects.p, sl.recs.p, need_depths ? sl.depths.p : nullptr, sl.block_sums.p, d_super,
                    d_counters, c->dbg.p, sl.col_f.p, cap, sl.strict_vs);
     if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[1], s));
@@ -1504,13 +1524,13 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     // depths in composite order.  The last tile pass also leaves every screen tile's [start, end) of the sorted list in sl.ranges (zeroed by k_cull).
     const uint32_t* vals_sorted = nullptr;
     if (!depth_order) {
-        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, nullptr, nullptr, nullptr, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, D.n_launch);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, nullptr, nullptr, nullptr, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, sl.n_launch_eff);
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p);
         vals_sorted = where ? sl.vals_b.p : sl.vals_a.p;
     } else if (sl.depth_local) {
         // tile-local path: tile ids are the sort key, the depth bits its payload; then every tile's slice is depth-sorted in LDS
-        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, sl.depths.p, sl.aux_a.p, nullptr, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, D.n_launch);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.keys_a.p, sl.vals_a.p, sl.depths.p, sl.aux_a.p, nullptr, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, sl.n_launch_eff);
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int where = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, key_bits, d_radix, sl.ranges.p, nullptr, sl.aux_a.p, sl.aux_b.p);
         uint32_t* const vals_t = where ? sl.vals_b.p : sl.vals_a.p;
@@ -1518,7 +1538,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
                                d_long_tiles, d_counters);
         vals_sorted = vals_t;
     } else {
-        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.aux_a.p, sl.vals_a.p, sl.depths.p, sl.keys_a.p, d_krange, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, D.n_launch);
+        launch_emit(s, f, D.n_chunks, sl.rects.p, sl.block_sums.p, d_super, cap, d_counters, sl.aux_a.p, sl.vals_a.p, sl.depths.p, sl.keys_a.p, d_krange, dbg ? nullptr : sl.live_cnt.p, sl.live_cid.p, sl.n_launch_eff);
         if (c->opt_timing >= 2) HIP_TRY(c, hipEventRecord(ev[3], s));
         const int wd = launch_sort(s, sl.keys_a.p, sl.vals_a.p, sl.keys_b.p, sl.vals_b.p, cap, d_P, depth_bits, d_radix_depth, nullptr, d_krange, sl.aux_a.p, sl.aux_b.p);
         // (the depth keys are dead now: keys_a serves as the other half of the tile-key ping-pong)
@@ -1547,7 +1567,7 @@ static int enqueue_frame(gswt_ctx* c, FrameSlot& sl)
     HIP_TRY(c, hipGetLastError());
     // k_combine (the frame's last kernel) stores the result counters into the pinned host words itself; only a frame
     // without screen tiles has no such launch
-    if (n_tiles == 0 || !sl.hc_dev) HIP_TRY(c, hipMemcpyAsync(sl.hc, d_counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (n_tiles == 0 || !sl.hc_dev) HIP_TRY(c, hipMemcpyAsync(sl.hc, d_counters, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipEventRecord(ev[9], s));
     sl.timing_level = c->opt_timing;
     return GSWT_OK;
@@ -1561,7 +1581,7 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
         const unsigned long long P64 = sl.hc[1];
         if (P64 >= 0xFFFFFF00ull) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: %llu pairs exceed 2^32", P64);
         if (sl.hc[3] == 0 && P64 <= sl.cap) break;
-        if (attempt >= 2) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");
+        if (attempt >= 3) return fail(c, GSWT_ERR_CAPACITY, "gswt_render: pair capacity did not converge");      // (a short launch grid, a pair overflow and a depth-pass shortfall can each cost one re-run)
         if (P64 > sl.cap || sl.args.cfg.order_mode != GSWT_ORDER_DEPTH)
             c->pair_cap = std::max<uint32_t>(c->pair_cap, (uint32_t)std::min<uint64_t>(P64 + P64 / 2 + 4096, 0xFFFFFF00ull));
         if (sl.args.cfg.order_mode == GSWT_ORDER_DEPTH) {
@@ -1571,9 +1591,13 @@ static int finish_frame(gswt_ctx* c, FrameSlot& sl)
             // seen the whole frame's lengths yet when the flag was raised, so at least cap + 1)
             if (sl.depth_local) c->depth_max_tile_len = std::max<uint32_t>(std::max<uint32_t>(max_len, c->depth_max_tile_len), tile_depth_sort_cap() + 1u);
         }
+        sl.full_grid = true;                                   // (whatever flagged it: the re-run covers the whole launch table)
+        c->live_hint = std::max<uint32_t>(c->live_hint, (uint32_t)std::min<unsigned long long>(sl.hc[4], 0xFFFFFFFFull));
         int rc = enqueue_frame(c, sl);
+        sl.full_grid = false;
         if (rc != GSWT_OK) return rc;
     }
+    c->live_hint = (uint32_t)std::min<unsigned long long>(sl.hc[4], 0xFFFFFFFFull);
     const uint32_t P = (uint32_t)sl.hc[1];
     // keep 25-50 % headroom over the running pair count without shrinking on every small dip
     if (!c->opt_fixed_pair_cap && (uint64_t)P + P / 4 > c->pair_cap) c->pair_cap = (uint32_t)std::min<uint64_t>((uint64_t)P + P / 2 + 4096, 0xFFFFFF00ull);

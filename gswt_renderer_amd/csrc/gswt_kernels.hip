@@ -1033,13 +1033,23 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
 // in front of it, workgroup 0 leaves the totals -- was measured: k_emit +6 us for the 4.6 us saved, 4015 -> 3881 frames/s.)
 __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ super_sums, uint32_t n_super,
                                                 unsigned long long* __restrict__ counters, uint32_t* __restrict__ super_excl, uint32_t pair_cap,
-                                                uint32_t* __restrict__ live_cnt)
+                                                uint32_t* __restrict__ live_cnt, uint32_t launched_per_xcd)
 {
     // k_project is done with this frame's live-chunk counts: cleared here for the slot's next frame (k_cull both clears
     // buffers and adds to these counters, so it cannot clear them itself)
-    if (live_cnt && threadIdx.x < 8u) {
-        live_cnt[(8u + threadIdx.x) * kSuperStride] = live_cnt[threadIdx.x * kSuperStride];      // (k_emit runs behind this kernel and walks the same table)
-        live_cnt[threadIdx.x * kSuperStride] = 0u;
+    if (live_cnt && threadIdx.x < 64u) {
+        // the longest of the eight live lists: the host sizes the next frames' launch grids by it (counters[4]); a frame whose grid was cut
+        // shorter than its own lists has chunks that nobody projected: flagged, the host re-runs it with the full grid (gswt_api.hip, live_hint)
+        uint32_t v = threadIdx.x < 8u ? live_cnt[threadIdx.x * kSuperStride] : 0u;
+        if (threadIdx.x < 8u) {
+            live_cnt[(8u + threadIdx.x) * kSuperStride] = v;      // (k_emit runs behind this kernel and walks the same table)
+            live_cnt[threadIdx.x * kSuperStride] = 0u;
+        }
+        for (int o = 4; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+        if (threadIdx.x == 0u) {
+            counters[4] = v;
+            if (v > launched_per_xcd) counters[3] = 1ull;
+        }
     }
     __shared__ unsigned long long s_v[4];
     __shared__ uint32_t s_w[4];
@@ -2495,7 +2505,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     const uint32_t n_items = item_base[n_tiles];
     const uint4 it = item_tab[item];                 // (in flight together with n_items; garbage past n_items, unused)
     // FOLD: this is the frame's last kernel -- the four result counters go straight into the slot's pinned host words
-    if (FOLD && item == 0u && threadIdx.x < 4u && host_counters) host_counters[threadIdx.x] = counters[threadIdx.x];
+    if (FOLD && item == 0u && threadIdx.x < 5u && host_counters) host_counters[threadIdx.x] = counters[threadIdx.x];
     if (item >= n_items) return;
     GSWT_TR(1, GSWT_NOW())
     GSWT_TR(4, it.w - it.z)
@@ -2907,7 +2917,7 @@ __global__ __launch_bounds__(256) void k_combine(const Frame f, const uint32_t* 
     const int tile = blockIdx.x;
     // last kernel of the frame: the four result counters go straight into the slot's pinned host words (instead of a
     // separate 32-byte device-to-host copy, ~4 us of stream time and one more API call per frame)
-    if (tile == 0 && threadIdx.x < 4u && host_counters) host_counters[threadIdx.x] = counters[threadIdx.x];
+    if (tile == 0 && threadIdx.x < 5u && host_counters) host_counters[threadIdx.x] = counters[threadIdx.x];
     const uint32_t i0 = item_base[tile], n_seg = item_base[tile + 1] - i0;
     if (n_seg == 1u) return;                      // the tile's only work item wrote the pixels itself; n_seg == 0: no pairs, background only
     int tx, tyl;
@@ -3021,7 +3031,7 @@ void launch_project(hipStream_t s, bool debug, const Frame& f, const DrawDev* dr
     else { GSWT_LAUNCH_PROJECT(false, false); }
 #undef GSWT_LAUNCH_PROJECT
 #undef GSWT_LAUNCH_PROJECT_S
-    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * kSuperStride * n_super, pair_cap, live_cnt);
+    GSWT_LAUNCH(k_totals, dim3(1), dim3(256), s, super_sums, n_super, counters, super_sums + 2u * kSuperStride * n_super, pair_cap, live_cnt, n_launch / 8u);
 }
 
 // keys: tile ids, vals: slots.  GSWT_ORDER_DEPTH (dkeys != nullptr): also each pair's depth bits -> dkeys and the frame's key range -> krange.
@@ -3287,7 +3297,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 // k_totals alone on caller-provided sums (unit test of the 64-bit pair count)
 void launch_totals(hipStream_t s, uint32_t* super_sums, uint32_t n_super, unsigned long long* counters, uint32_t pair_cap)
 {
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * kSuperStride * n_super, pair_cap, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(256), 0, s, super_sums, n_super, counters, super_sums + 2u * kSuperStride * n_super, pair_cap, (uint32_t*)nullptr, 0xFFFFFFFFu);
 }
 
 void launch_unshard(hipStream_t s, const float4* gathered, float4* out, int width, int height, int shard_count, int rows_padded, int band_px)
