@@ -339,3 +339,43 @@ def test_tile_depth_sort_is_stable_at_every_class_boundary(renderer):
         order = np.argsort(dk2[at:at + m], kind="stable")
         assert np.array_equal(o2[at:at + m], v2[at:at + m][order]), (i, m)
         at += m
+
+
+@pytest.mark.gpu
+def test_frame_whose_live_chunks_outgrow_its_launch_grid_is_rerun(renderer):
+    """The launch grids of k_project / k_emit follow the longest live-chunk list of the last finished frame (+ 50 % + 256, and only where that
+    removes at least half of the launch table).  A camera that sees almost nothing, then one that sees the scene: the second frame's lists
+    outgrow its grid, k_totals flags it, the host re-runs it over the whole table -- the image and the counts are the full frame's."""
+    import bench
+    from gswt_renderer_amd import host, workloads
+    w, wang, cu, vp, sort = bench.build_workload("c3")
+    W, Hh = w["width"], w["height"]
+    su = wang.scene_uniforms()
+    wang.upload_to(renderer)
+    renderer.configure(None)
+    renderer.set_draws(sort.draws, sort.merged_gs_index, sort.merged_map_id, sort.merged_lod_id)
+    cam = workloads.camera_for("c3")
+    pos = cam["pos"]
+    up_cu, _ = host.camera_uniforms(pos, (pos[0] + 0.3, pos[1] + 0.2, pos[2] + 10.0), cam["up"], cam["fovy"], cam["near"], cam["far"], W, Hh)      # at the sky
+    want = renderer.render(cu, su, W, Hh)
+    t0 = renderer.timings()
+    assert t0["n_visible"] > 1_000_000
+    for order in (L.GSWT_ORDER_REFERENCE, L.GSWT_ORDER_DEPTH):
+        ref = want if order == L.GSWT_ORDER_REFERENCE else renderer.render(cu, su, W, Hh, order_mode=order)
+        sky = renderer.render(up_cu, su, W, Hh, order_mode=order)
+        ts = renderer.timings()
+        assert ts["n_visible"] < t0["n_visible"] // 20, ts["n_visible"]                 # a short live list: the next frame's grid is cut
+        img = renderer.render(cu, su, W, Hh, order_mode=order)
+        t1 = renderer.timings()
+        assert (t1["n_visible"], t1["n_pairs"]) == (t0["n_visible"], t0["n_pairs"])
+        assert np.array_equal(img, ref)
+        # ... and with several frames in flight behind the short one
+        import torch
+        outs = [torch.empty((Hh, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
+        renderer.render(up_cu, su, W, Hh, order_mode=order)
+        tickets = [renderer.render_async(cu, su, W, Hh, o.data_ptr(), order_mode=order) for o in outs]
+        for tk in tickets:
+            renderer.render_wait(tk)
+        for o in outs:
+            assert np.array_equal(o.cpu().numpy(), ref)
+        assert sky[..., 3].max() <= want[..., 3].max()
