@@ -817,8 +817,12 @@ def main():
                          "kernel_ms_min_slot": comp * 1e3, "kernel_ms": comp * 1e3, "kernel_ms_samples": len(by_slot.get(best_slot, st["comp_ms"])), "timed_every": (None if args.timing_every >= (1 << 30) else max(1, args.timing_every)),
                          "kernel_ms_by_slot": {str(k): round(v, 5) for k, v in slot_means.items()}, "kernel_ms_slot": best_slot, "kernel_ms_all_slots": comp_all * 1e3,
                          "frac_all_slots": achieved_all / HBM_PEAK_GBS,
-                         "frac_note": "`achieved` / `frac` use kernel_ms_min_slot: the hipEvent bracket of the frame slot whose stream has a hardware queue of its own (the other "
-                                      "slots' brackets also time kernels of the frames that share their queue); frac_all_slots uses the mean over every sample",
+                         "kernel_ms_method": ("start / stop events bound to the k_composite dispatch itself (hipExtLaunchKernelGGL): the kernel's own begin -> end on the device, "
+                                              "the interval rocprofv3 --kernel-trace reports for it" if os.environ.get("GSWT_KERNEL_EVENTS", "1") != "0" else
+                                              "hipEventRecord in front of and behind the launch (GSWT_KERNEL_EVENTS=0): previous command done -> kernel done, which also "
+                                              "holds the time the dispatch waited for other frames' workgroups"),
+                         "frac_note": "`achieved` / `frac` use kernel_ms_min_slot, the mean over the frame slot with the lowest one; frac_all_slots uses the mean over every sample "
+                                      "(with events bound to the dispatch the slots read alike; with GSWT_KERNEL_EVENTS=0 a slot that shares its hardware queue also times its neighbours' kernels)",
                          "bytes_moved_by_design": moved_bytes, "frac_bytes_moved": (moved_bytes / comp / 1e9) / HBM_PEAK_GBS if comp > 0 else None,
                          "kernel_ms_isolated": iso_ms, "frac_isolated": (algo_bytes / (iso_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if iso_ms > 0 else None,
                          "limiter": "instruction issue + latency, not HBM: BASELINE.json asks for the HBM fraction of the compositing kernel, so that is what `frac` is; "

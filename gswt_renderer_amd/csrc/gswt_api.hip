@@ -1123,7 +1123,7 @@ try {
             if (match_rank > 0) c->stat_groups_reused_deep++;
         } else if (len) {
             MergeGroup& B = grp[n_build];
-            B.base = (uint32_t)build_total; B.len = (uint32_t)len; B.mn = 0; B.mx = 0; B.out_base = (uint32_t)total; B._pad[0] = B._pad[1] = B._pad[2] = 0;
+            B.base = (uint32_t)build_total; B.len = (uint32_t)len; B.mn = 2147483647; B.mx = -2147483647 - 1; B.out_base = (uint32_t)total; B._pad[0] = B._pad[1] = B._pad[2] = 0;
             for (uint32_t m = 0; m < G.n_members; m++) {
                 const gswt_merge_member& M = members[G.first_member + m];
                 const int lods[2] = {(int)M.lod, M.other_lod};

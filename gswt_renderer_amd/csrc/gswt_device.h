@@ -2,6 +2,7 @@
 // Internal to libgswt_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <string.h>
@@ -205,6 +206,25 @@ inline void graph_record(GraphRec* rec, void (*k)(KA...), dim3 g, dim3 b, A&&...
     do {                                                                                                 \
         if (GraphRec* rec_ = graph_recorder()) graph_record(rec_, K, G, B, __VA_ARGS__);                 \
         else hipLaunchKernelGGL(K, G, B, 0, S, __VA_ARGS__);                                             \
+    } while (0)
+
+// A launch that carries its own pair of timing events (E0, E1 non-null, no graph recorder): hipExtLaunchKernelGGL binds both to the DISPATCH,
+// so hipEventElapsedTime(E0, E1) is the kernel's own begin -> end on the device -- the interval rocprofv3 --kernel-trace reports -- rather than
+// "previous command of the stream done -> this kernel done" of two hipEventRecord calls (GSWT_KERNEL_EVENTS=0).  Measured at the end of round 4
+// (profiles/r04_kernel_events.txt): the two read alike (c3 fly path, k_composite 0.104-0.106 against 0.100-0.114 ms, frame rate unchanged), and
+// under rocprofv3 either agrees with the profiler's own average of the same run (0.0907 / 0.0919 against 0.0909 / 0.0969 ms): what separates the
+// bench line's kernel time (0.105 ms) from a rocprofv3 summary (0.089-0.097) is the run -- under the profiler fewer frames overlap (4 090-4 750
+// against 5 450 frames/s) and the kernel shares the chip with less -- not the events.
+bool kernel_events_enabled();
+#define GSWT_LAUNCH_TIMED(K, G, B, S, E0, E1, ...)                                                       \
+    do {                                                                                                 \
+        if ((E0) && (E1) && !graph_recorder() && kernel_events_enabled())                                \
+            hipExtLaunchKernelGGL(K, G, B, 0, S, E0, E1, 0, __VA_ARGS__);                                \
+        else {                                                                                           \
+            if (E0) hipEventRecord(E0, S);                                                               \
+            GSWT_LAUNCH(K, G, B, S, __VA_ARGS__);                                                        \
+            if (E1) hipEventRecord(E1, S);                                                               \
+        }                                                                                                \
     } while (0)
 
 }  // namespace gswt

@@ -1658,12 +1658,8 @@ __device__ __forceinline__ uint32_t mg_find_seg(const MergeSeg* __restrict__ seg
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_mg_init(MergeGroup* __restrict__ groups, uint32_t n_groups)
-{
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g < n_groups) { groups[g].mn = 2147483647; groups[g].mx = -2147483647 - 1; }
-}
-
+// (a group's mn / mx arrive as INT_MAX / INT_MIN with the event's upload: gswt_set_draws_merge_groups -- until the end of round 4 a
+// kernel of its own, k_mg_init, set them: one launch per sort event)
 // Both passes over the concatenation run on a block table built with the segments: block = (segment, first entry of up to
 // 1024 inside it), so a workgroup reads ONE segment record instead of binary-searching the segment of every entry
 // (k_mg_minmax was 75 us for 1.24 M entries that way: nine dependent loads per entry plus per-lane atomics).
@@ -2994,6 +2990,12 @@ GraphRec*& graph_recorder()
     return rec;
 }
 
+bool kernel_events_enabled()
+{
+    static const bool on = !(getenv("GSWT_KERNEL_EVENTS") && atoi(getenv("GSWT_KERNEL_EVENTS")) == 0);
+    return on;
+}
+
 void launch_cull(hipStream_t s, const Frame& f, const DrawDev* draws, uint32_t n_draws, uint32_t* draw_culled, uint32_t* cell_culled, uint32_t n_cells,
                  uint32_t* zero_a, uint32_t n_zero_a, uint32_t* zero_b, uint32_t n_zero_b, uint32_t* zero_c, uint32_t n_zero_c,
                  uint32_t* live_cnt, uint4* live_tab, uint32_t* zero_d, uint32_t n_zero_d,
@@ -3125,7 +3127,6 @@ void launch_merge_build(hipStream_t s, const MergeSeg* segs, uint32_t n_segs, co
                         uint32_t* kb, uint32_t* vb, uint32_t* radix_ws, int group_bits, uint32_t* merged_list, uint32_t* merged_map)
 {
     if (n_total == 0 || n_groups == 0 || n_blocks == 0) return;
-    hipLaunchKernelGGL(k_mg_init, dim3((n_groups + 255) / 256), dim3(256), 0, s, groups, n_groups);
     hipLaunchKernelGGL(k_mg_minmax, dim3(n_blocks), dim3(256), 0, s, segs, blocks, raw, groups);
     hipLaunchKernelGGL(k_mg_keys, dim3(n_blocks), dim3(256), 0, s, segs, blocks, raw, groups, ka, va);
     const int where = launch_sort(s, ka, va, kb, vb, n_total, n_total_dev, 16 + group_bits, radix_ws);
@@ -3181,8 +3182,9 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
                 fold ? 1u : 0u, report_max ? 1u : 0u);
     }
     const bool early = f.t_eps > 0.0f, depth = f.has_depth != 0, colf = f.draw_mode != 0u;
-    if (ev_begin) hipEventRecord(ev_begin, s);
+    // (the shipped compositors carry ev_begin / ev_end themselves: GSWT_LAUNCH_TIMED; the experiment variants record them around the launch)
 #ifdef GSWT_EXPERIMENTS
+    if (ev_begin && (f.dbg_flags & (0x20000 | 0x4000 | 0x1000))) hipEventRecord(ev_begin, s);
     if (f.dbg_flags & 0x20000) {         // experiment: two packed waves per item with shared staging (0x2000: 256-pair batches instead of 128)
 #define GSWT_LAUNCH_COMPOSITE_P2(E, D, C, NB2, OCC)                                                                             \
         GSWT_LAUNCH((k_composite_p2<E, D, C, NB2, OCC>), dim3(max_items), dim3(128), s, f, item_base, item_tab, vals, recs, depths, col_f, \
@@ -3246,7 +3248,7 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
 #endif
     if (variant == 1) {                  // GSWT_OPT_COMPOSITE = 1: decoupled waves (k_composite_dw), same image bit for bit
 #define GSWT_LAUNCH_COMPOSITE_DW(E, D, C)                                                                                      \
-        GSWT_LAUNCH((k_composite_dw<E, D, C>), dim3(max_items), dim3(256), s, f, item_base, item_tab, vals, recs,              \
+        GSWT_LAUNCH_TIMED((k_composite_dw<E, D, C>), dim3(max_items), dim3(256), s, ev_begin, ev_end, f, item_base, item_tab, vals, recs, \
                            depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows)
         if (colf) { if (depth) GSWT_LAUNCH_COMPOSITE_DW(false, true, true); else GSWT_LAUNCH_COMPOSITE_DW(false, false, true); }
         else if (early && depth) GSWT_LAUNCH_COMPOSITE_DW(true, true, false);
@@ -3254,13 +3256,12 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         else if (depth) GSWT_LAUNCH_COMPOSITE_DW(false, true, false);
         else GSWT_LAUNCH_COMPOSITE_DW(false, false, false);
 #undef GSWT_LAUNCH_COMPOSITE_DW
-        if (ev_end) hipEventRecord(ev_end, s);
         GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, (const unsigned long long*)counters, host_counters);
         return;
     }
     if (fold) {
 #define GSWT_LAUNCH_COMPOSITE_F(E, D, C)                                                                                       \
-        GSWT_LAUNCH((k_composite<E, D, C, false, false, true>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
+        GSWT_LAUNCH_TIMED((k_composite<E, D, C, false, false, true>), dim3(max_items), dim3(256), s, ev_begin, ev_end, f, ranges, item_base, item_tab, seg, vals, recs, \
                            depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows, tile_tick, (const unsigned long long*)counters, host_counters)
         if (colf) { if (depth) GSWT_LAUNCH_COMPOSITE_F(false, true, true); else GSWT_LAUNCH_COMPOSITE_F(false, false, true); }
         else if (early && depth) GSWT_LAUNCH_COMPOSITE_F(true, true, false);
@@ -3268,11 +3269,10 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
         else if (depth) GSWT_LAUNCH_COMPOSITE_F(false, true, false);
         else GSWT_LAUNCH_COMPOSITE_F(false, false, false);
 #undef GSWT_LAUNCH_COMPOSITE_F
-        if (ev_end) hipEventRecord(ev_end, s);
         return;
     }
 #define GSWT_LAUNCH_COMPOSITE_K(E, D, C, PK, DW)                                                                               \
-    GSWT_LAUNCH((k_composite<E, D, C, PK, DW>), dim3(max_items), dim3(256), s, f, ranges, item_base, item_tab, seg, vals, recs, \
+    GSWT_LAUNCH_TIMED((k_composite<E, D, C, PK, DW>), dim3(max_items), dim3(256), s, ev_begin, ev_end, f, ranges, item_base, item_tab, seg, vals, recs, \
                        depths, col_f, bg_rgba, bg_depth, out, partials, n_tiles, out_rows, (uint32_t*)nullptr, (const unsigned long long*)nullptr, (unsigned long long*)nullptr)
 #ifdef GSWT_EXPERIMENTS      // measured and slower (profiles/r03_composite_variants.txt): 0x80000 the packed-coordinate step (15 VALU instead of 19), 0x100000 the register-broadcast (DPP) walk
 #define GSWT_LAUNCH_COMPOSITE(E, D, C) do { if ((f.dbg_flags & 0x180000) == 0x180000) GSWT_LAUNCH_COMPOSITE_K(E, D, C, true, true); /* 0x180000: the scalar step with the blend predicated by v_cndmask behind a ballot test (round 2's form) instead of EXEC masking */ \
@@ -3290,7 +3290,6 @@ void launch_composite(hipStream_t s, const Frame& f, const uint2* ranges, const 
     else GSWT_LAUNCH_COMPOSITE(false, false, false);
 #undef GSWT_LAUNCH_COMPOSITE
 #undef GSWT_LAUNCH_COMPOSITE_K
-    if (ev_end) hipEventRecord(ev_end, s);
     GSWT_LAUNCH(k_combine, dim3(n_tiles), dim3(256), s, f, item_base, partials, bg_rgba, out, n_tiles, out_rows, (const unsigned long long*)counters, host_counters);
 }
 
