@@ -2488,6 +2488,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     __shared__ float4 s_q2[COLF ? 257 : 1];
     __shared__ float s_dep[DEPTH ? 257 : 1];
     __shared__ uint16_t s_list[4][4][kListStride];     // [wave][sub-block][i] -> LDS byte offset of the i-th hit's record
+    __shared__ uint4 s_dead;                           // EARLY: .x .. .w = wave 0 .. 3 has no pixel with T >= t_eps left
     // work item -> (tile, segment) through the table k_items left behind.  Consecutive items are dealt
     // round-robin over the 8 XCDs by the dispatcher, which balances the skewed tile-list lengths.
     const uint32_t item = blockIdx.x;
@@ -2542,6 +2543,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
     bool wave_live = true;
     // the null record: p.x = +inf for every pixel (0 * l + inf), so r^2 = +inf and no pixel is ever inside
     if (tid == 0) {
+        if (EARLY) s_dead = make_uint4(0u, 0u, 0u, 0u);
         s_q0[kNullRec] = (PK && !DPPW) ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, __builtin_inff(), 0.f);
         s_q1[kNullRec] = (PK && !DPPW) ? make_float4(__builtin_inff(), 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (DEPTH) s_dep[DEPTH ? kNullRec : 0u] = 0.0f;
@@ -2631,8 +2633,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((DEPTH || C
         tr_walk += GSWT_NOW() - tr_t0;
 #endif
         if (base + 256u >= rg.y) break;                     // last batch of the item: nothing is staged after it, no barrier needed
-        if (EARLY) { if (__syncthreads_and(wave_live ? 0 : 1)) break; }
-        else __syncthreads();
+        // EARLY: the item ends once all four strips are saturated.  A saturated wave leaves a flag in LDS in front of the batch's closing
+        // barrier and everybody reads the four flags behind it (flags are written between a batch's two barriers and read between
+        // batches: no race; they never go back to 0).  Until the end of round 4 this was __syncthreads_and(): a workgroup reduction with
+        // a second barrier per batch, which made the early-out cost 1.5 % of c3's frame rate, where it saves nothing.
+        if (EARLY && !wave_live && lane == 0u) (&s_dead.x)[wave] = 1u;
+        __syncthreads();
+        if (EARLY) {
+            const uint4 dd = s_dead;
+            if (__builtin_amdgcn_readfirstlane((int)(dd.x & dd.y & dd.z & dd.w)) != 0) break;
+        }
     }
     GSWT_TR(3, GSWT_NOW())
     GSWT_TR(6, tr_walk)

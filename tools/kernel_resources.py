@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel register / LDS / scratch use of a built libgswt_hip*.so, from the code object's notes.
-usage: tools/kernel_resources.py [lib] [regex]"""
+usage: tools/kernel_resources.py [lib] [regex] [target, default gfx950; e.g. gfx950:xnack-]"""
 import re
 import subprocess
 import sys
@@ -8,11 +8,12 @@ import tempfile
 
 lib = sys.argv[1] if len(sys.argv) > 1 else "gswt_renderer_amd/lib/libgswt_hip.so"
 filt = re.compile(sys.argv[2] if len(sys.argv) > 2 else ".")
+ARCH = sys.argv[3] if len(sys.argv) > 3 else "gfx950"
 LLVM = "/opt/rocm/lib/llvm/bin/"
 with tempfile.TemporaryDirectory() as t:
     co, fb = t + "/co", t + "/fatbin"
     subprocess.run([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fb, lib], check=True, capture_output=True)
-    subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+    subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--" + ARCH,
                     "--input=" + fb, "--output=" + co], check=True, capture_output=True)
     txt = subprocess.run([LLVM + "llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
 rows = []
