@@ -25,6 +25,41 @@ namespace gswt {
 // Lane mask of a predicate.  (Not __ballot(int): its argument is an int, so the compiler first materialises the predicate as 0 / 1 in a
 // vector register and compares that again -- two vector instructions per ballot that v_cmp had already answered.)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// bits of a lane mask below the calling lane (v_mbcnt_lo / _hi): a lane's rank among the lanes the mask names
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Wave-wide scans and sums through DPP (data-parallel primitives: the neighbour's register arrives with the VALU instruction) instead of
+// __shfl_up / __shfl_down, which compile to ds_bpermute_b32 -- an LDS-crossbar round trip per step, six of them in a dependent chain per
+// scan.  row_shr:1 / 2 / 4 / 8 make the inclusive scan of every 16-lane row (a lane whose source lies outside its row adds 0),
+// row_bcast:15 on rows 1 and 3 adds the row in front, row_bcast:31 on rows 2 and 3 the first half of the wave: the GFX9 sequence of
+// rocPRIM's warp scan.  Every lane of the wave must be active (it was so with the shuffles: a lane that has left reads as undefined there).
+// Integer adds: the same values bit for bit.  (End of round 4: the scans of k_radix_scatter / k_emit / k_items / k_totals / the tile-local
+// depth sort and the sums of k_project; profiles/r04_dpp_scans.txt.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
+{
+    (void)lane;
+    v += dpp_or_zero<0x111, 0xF>(v);          // row_shr:1
+    v += dpp_or_zero<0x112, 0xF>(v);          // row_shr:2
+    v += dpp_or_zero<0x114, 0xF>(v);          // row_shr:4
+    v += dpp_or_zero<0x118, 0xF>(v);          // row_shr:8
+    v += dpp_or_zero<0x142, 0xA>(v);          // row_bcast:15 -> rows 1, 3
+    v += dpp_or_zero<0x143, 0xC>(v);          // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// the wave's sum, in every lane (uniform: a scalar register)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0u), 63);
+}
+
 
 __device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ float clampf(float e, float lo, float hi) { return fminf(fmaxf(e, lo), hi); }
@@ -994,11 +1029,7 @@ __global__ __launch_bounds__(256 * HALVES) void k_project(
     GSWT_TR(4, GSWT_NOW())
 
     // workgroup sums: pairs and visible splats
-    uint32_t wsum = count, wvis = visible ? 1u : 0u;
-    for (int off = 32; off > 0; off >>= 1) {
-        wsum += __shfl_down(wsum, off, 64);
-        wvis += __shfl_down(wvis, off, 64);
-    }
+    const uint32_t wsum = wave_sum(count), wvis = (uint32_t)__popcll(ballot64(visible));
     // (Round 4, measured and reverted: no barrier here -- every wave adding its own sums with fire-and-forget atomics (12 per workgroup
     // instead of 2 + a store, the rects stored whether or not the chunk emits pairs): k_project 57 -> 183 us at c3, 379 -> 561 at c5.  The
     // device-scope atomics of a kernel retire at ~1 per ns chip-wide whatever their addresses: 107 k more of them cost 125 us.)
@@ -1083,22 +1114,13 @@ __global__ __launch_bounds__(256) void k_totals(const uint32_t* __restrict__ sup
         carry += s_v[0] + s_v[1] + s_v[2] + s_v[3];
         __syncthreads();
     }
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v = wave_sum(v);
     if ((threadIdx.x & 63u) == 0) s_v[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
         counters[1] = carry; counters[0] = s_v[0] + s_v[1] + s_v[2] + s_v[3];
         if (carry > (unsigned long long)pair_cap) counters[3] = 1ull;       // pair buffers too small: the host re-runs the frame
     }
-}
-
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
-{
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t n = __shfl_up(v, off, 64);
-        if (lane >= (uint32_t)off) v += n;
-    }
-    return v;
 }
 
 // block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix,
@@ -1146,7 +1168,7 @@ __device__ __forceinline__ uint32_t block_scan_and_sum(uint32_t v, uint32_t r, u
 {
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     const uint32_t inc = wave_incl_scan(v, lane);
-    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off, 64);
+    r = wave_sum(r);
     if (lane == 63u) s_w[w] = inc;
     if (lane == 0u) s_w[4u + w] = r;
     __syncthreads();
@@ -1403,7 +1425,7 @@ __global__ __launch_bounds__(kSortThreads) void k_radix_hist(const uint32_t* __r
         for (int k = 0; k < kSortItems; k++) {
             const bool valid = base + (uint32_t)k * 64u + lane < n;           // valid lanes are a prefix of the wave
             const uint32_t dgt = ((key[k] - kmin) >> shift) & mask;
-            const uint32_t prev = (uint32_t)__shfl_up((int)dgt, 1, 64);
+            const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)dgt, 0x138, 0xF, 0xF, true);      // wave_shr:1 (lane 0 is a head anyway)
             const unsigned long long heads = ballot64(valid && (lane == 0u || prev != dgt));
             const unsigned long long vmask = ballot64(valid);
             if ((heads >> lane) & 1ull) {
@@ -1447,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_radix_supscan(uint32_t* __restrict__ gs
             const uint32_t x = g < nsup ? v[k] : 0u;
             const uint32_t inc = wave_incl_scan(x, lane);
             if (g < nsup) gsup[(size_t)g * 256u + d] = carry + inc - x;
-            carry += (uint32_t)__shfl((int)inc, 63, 64);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         }
     }
     if (lane == 0u) gtot[d] = carry;
@@ -1549,7 +1571,7 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu((k
 #endif
     // per-wave digit counts: one LDS add per distinct digit of a 64-item round (see k_radix_hist); the peer masks are kept for
     // the ranking below
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    // (a lane's rank among its peers = the peers below it: v_mbcnt on the mask, no (1 << lane) - 1 kept in two registers across the kernel)
     constexpr bool kCachePeers = kSortItems <= 8;       // 16 rounds of masks would cost the 256-thread build a wave per SIMD
     unsigned long long pm[kCachePeers ? kSortItems : 1];
 #pragma unroll
@@ -1558,7 +1580,7 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu((k
         const uint32_t dgt = ((key[k] - kmin) >> shift) & mask;
         const unsigned long long peers = match_digit(dgt, valid, nbits);
         if (kCachePeers) pm[k] = peers;
-        if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+        if (valid && lanes_below(peers) == 0u) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
     }
     GSWT_TR(2, GSWT_NOW())
     {
@@ -1602,7 +1624,7 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu((k
         bool valid = i < n;
         uint32_t dgt = valid ? (((key[k] - kmin) >> shift) & mask) : 0u;
         const unsigned long long peers = kCachePeers ? pm[kCachePeers ? k : 0] : match_digit(dgt, valid, nbits);
-        const uint32_t rank = __popcll(peers & lt);
+        const uint32_t rank = lanes_below(peers);
         uint32_t pos = 0;
         if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
         const int leader = valid ? (int)__ffsll((long long)peers) - 1 : (int)lane;
@@ -1811,7 +1833,6 @@ __device__ __forceinline__ void tile_depth_sort_one(uint32_t tile, const uint2* 
     const uint32_t lane = threadIdx.x & 63u, w = WAVE ? 0u : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), tid = WAVE ? lane : threadIdx.x;
     const uint32_t rounds = (n + 63u) >> 6, rpw = (rounds + (uint32_t)NW - 1u) / (uint32_t)NW;   // wave w owns rounds [w rpw, (w + 1) rpw)
     const uint32_t base_w = w * rpw * 64u;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t key[ROUNDS], val[ROUNDS];
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
 #pragma unroll
@@ -1846,7 +1867,7 @@ __device__ __forceinline__ void tile_depth_sort_one(uint32_t tile, const uint2* 
             const bool valid = base_w + (uint32_t)k * 64u + lane < n;
             const uint32_t dgt = (key[k] >> shift) & dmask;
             const unsigned long long peers = match_digit(dgt, valid, nb);
-            const uint32_t rank = (uint32_t)__popcll(peers & lt), cnt = (uint32_t)__popcll(peers);
+            const uint32_t rank = lanes_below(peers), cnt = (uint32_t)__popcll(peers);
             pm[k] = rank | (valid ? (uint32_t)(__ffsll((long long)peers) - 1) : lane) << 8 | cnt << 16;
             if (valid && rank == 0u) atomicAdd(&s_h[w][dgt], cnt);
         }
@@ -1913,7 +1934,6 @@ __device__ __forceinline__ void tile_depth_sort_xl(const uint2* __restrict__ ran
     const uint32_t* const xl_list = long_list + n_tiles + 1u;
     const uint32_t n_xl = min(xl_list[0], n_tiles);                // written by the launch in front of this one
     const uint32_t lane = threadIdx.x & 63u, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned long long lt = (1ull << lane) - 1ull;
     for (uint32_t t = blockIdx.x; t < n_xl; t += gridDim.x) {
         const uint2 rgv = ranges[__builtin_amdgcn_readfirstlane(xl_list[1u + t])];
         const uint32_t start = ~(uint32_t)__builtin_amdgcn_readfirstlane(rgv.x), n = (uint32_t)__builtin_amdgcn_readfirstlane(rgv.y) - start;
@@ -1941,7 +1961,7 @@ __device__ __forceinline__ void tile_depth_sort_xl(const uint2* __restrict__ ran
                 const bool valid = r + lane < hi;
                 const uint32_t dgt = ((src_k[start + min(r + lane, hi - 1u)] - mn) >> shift) & dmask;
                 const unsigned long long peers = match_digit(dgt, valid, nb);
-                if (valid && (peers & lt) == 0ull) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
+                if (valid && lanes_below(peers) == 0u) atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
             }
             __syncthreads();
             // exclusive scan over (digit, wave): thread d < 256 owns digit d
@@ -1968,7 +1988,7 @@ __device__ __forceinline__ void tile_depth_sort_xl(const uint2* __restrict__ ran
                 const uint32_t key = src_k[i], val = src_v[i];
                 const uint32_t dgt = ((key - mn) >> shift) & dmask;
                 const unsigned long long peers = match_digit(dgt, valid, nb);
-                const uint32_t rank = (uint32_t)__popcll(peers & lt);
+                const uint32_t rank = lanes_below(peers);
                 uint32_t pos = 0;
                 if (valid && rank == 0u) pos = atomicAdd(&s_h[w][dgt], (uint32_t)__popcll(peers));
                 pos = (uint32_t)__shfl((int)pos, valid ? (int)__ffsll((long long)peers) - 1 : (int)lane, 64) + rank;
