@@ -54,6 +54,25 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
     v += dpp_or_zero<0x143, 0xC>(v);          // row_bcast:31 -> rows 2, 3
     return v;
 }
+// the wave's smallest / largest value, in every lane (uniform): the same six DPP steps with min / max; a lane whose source lies outside its row
+// (or whose row the step does not address) compares with itself
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_self(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
+{
+    v = min(v, dpp_or_self<0x111, 0xF>(v)); v = min(v, dpp_or_self<0x112, 0xF>(v)); v = min(v, dpp_or_self<0x114, 0xF>(v));
+    v = min(v, dpp_or_self<0x118, 0xF>(v)); v = min(v, dpp_or_self<0x142, 0xA>(v)); v = min(v, dpp_or_self<0x143, 0xC>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+    v = max(v, dpp_or_self<0x111, 0xF>(v)); v = max(v, dpp_or_self<0x112, 0xF>(v)); v = max(v, dpp_or_self<0x114, 0xF>(v));
+    v = max(v, dpp_or_self<0x118, 0xF>(v)); v = max(v, dpp_or_self<0x142, 0xA>(v)); v = max(v, dpp_or_self<0x143, 0xC>(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 // the wave's sum, in every lane (uniform: a scalar register)
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
@@ -1302,7 +1321,7 @@ __global__ __launch_bounds__(256) void k_emit(const Frame f, const uint2* __rest
         // key range of the frame: one guarded atomic pair per workgroup.  (One pair per WAVE on the two words is tens of thousands of
         // atomics on two addresses, which the memory side serialises at ~8 ns each.)  The words only grow ([0] holds ~min), so a stale read
         // can only cause a redundant atomic, never a missed one.
-        for (int o = 32; o > 0; o >>= 1) { kmn = min(kmn, (uint32_t)__shfl_down((int)kmn, o, 64)); kmx = max(kmx, (uint32_t)__shfl_down((int)kmx, o, 64)); }
+        kmn = wave_min(kmn); kmx = wave_max(kmx);
         if ((threadIdx.x & 63u) == 0u) { s_mn[DEPTH ? threadIdx.x >> 6 : 0u] = kmn; s_mx[DEPTH ? threadIdx.x >> 6 : 0u] = kmx; }
         __syncthreads();
         if (threadIdx.x == 0u) {
@@ -1844,7 +1863,7 @@ __device__ __forceinline__ void tile_depth_sort_one(uint32_t tile, const uint2* 
         val[k] = vals[start + i];
         mn = min(mn, key[k]); mx = max(mx, key[k]);
     }
-    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); }
+    mn = wave_min(mn); mx = wave_max(mx);
     if (lane == 0u) { s_mn[w] = mn; s_mx[w] = mx; }
     tls_sync<WAVE>();
 #pragma unroll
@@ -1942,7 +1961,7 @@ __device__ __forceinline__ void tile_depth_sort_xl(const uint2* __restrict__ ran
         // the list's key range
         uint32_t mn = 0xFFFFFFFFu, mx = 0u;
         for (uint32_t i = lo + lane; i < hi; i += 64u) { const uint32_t k = keys_a[start + i]; mn = min(mn, k); mx = max(mx, k); }
-        for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64)); mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64)); }
+        mn = wave_min(mn); mx = wave_max(mx);
         if (lane == 0u) { s_mn[w] = mn; s_mx[w] = mx; }
         __syncthreads();
 #pragma unroll
@@ -2105,7 +2124,7 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
         uint32_t mx = 0;
 #pragma unroll
         for (int j = 0; j < kPer; j++) mx = max(mx, base + j * 1024 + (int)threadIdx.x < n_tiles ? r[j].y - r[j].x : 0u);
-        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_down((int)mx, o, 64));
+        mx = wave_max(mx);
         if (lane == 0u && mx) atomicMax(reinterpret_cast<uint32_t*>(counters + 2) + 1, mx);        // <= 16 per workgroup, <= 4 workgroups
     }
     uint32_t cnt[kPer], inc[kPer];
@@ -2168,7 +2187,7 @@ __global__ __launch_bounds__(1024) void k_items(const uint2* __restrict__ ranges
 #pragma unroll
         for (int j = 0; j < kPer; j++) {
             uint32_t fs = full[j];
-            for (int o = 32; o > 0; o >>= 1) fs += (uint32_t)__shfl_down((int)fs, o, 64);
+            fs = wave_sum(fs);
             if (lane == 0u && fs) atomicAdd(&s_cls[0], fs);
             unsigned long long left = ballot64(rcls[j] < kCls);
             while (left) {
