@@ -12,7 +12,7 @@ ARCH = sys.argv[3] if len(sys.argv) > 3 else "gfx950"
 LLVM = "/opt/rocm/lib/llvm/bin/"
 with tempfile.TemporaryDirectory() as t:
     co, fb = t + "/co", t + "/fatbin"
-    subprocess.run([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fb, lib], check=True, capture_output=True)
+    subprocess.run([LLVM + "llvm-objcopy", "--dump-section", ".hip_fatbin=" + fb, lib, t + "/lib_copy"], check=True, capture_output=True)   # an output file: without one objcopy rewrites its input in place
     subprocess.run([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--" + ARCH,
                     "--input=" + fb, "--output=" + co], check=True, capture_output=True)
     txt = subprocess.run([LLVM + "llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
