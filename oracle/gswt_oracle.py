@@ -315,7 +315,8 @@ def default_camera(width: int, height: int) -> Camera:
 # --------------------------------------------------------------------------
 def scene_load(verts62: np.ndarray) -> np.ndarray:
     """Scene::load, scene.rs:115-212 -> [n, 32] uint8 rows."""
-    verts62 = np.ascontiguousarray(verts62, dtype=np.float32).reshape(-1, 62)
+    # "A": a PLY body viewed in place (scene_from_ply: np.frombuffer behind an odd-length header) is contiguous but not 4-byte aligned
+    verts62 = np.require(verts62, dtype=np.float32, requirements=["C", "A"]).reshape(-1, 62)
     rows = np.zeros((verts62.shape[0], 32), dtype=np.uint8)
     lib().orc_scene_load(_ptr(verts62), verts62.shape[0], _ptr(rows))
     return rows
