@@ -98,6 +98,17 @@ def test_k3_scene_load_packing_and_importance_order():
     assert np.allclose(orc.rows_scales(rows)[0], 1.0)
 
 
+def test_k3_ply_body_behind_a_header_of_any_length():
+    """scene.rs:72-212: the PLY body starts wherever `end_header\n` ends, so a body viewed in place is 4-byte aligned only by luck;
+    the rows must not depend on it (and the C oracle must be handed an aligned array: tools/host_sanitizers.sh watches that)."""
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=(5, 62)).astype(np.float32)
+    want = orc.scene_load(v)
+    for pad in range(4):
+        head = b"ply\nformat binary_little_endian 1.0\ncomment " + b"x" * pad + b"\nelement vertex 5\nend_header\n"
+        assert np.array_equal(orc.scene_from_ply(head + v.tobytes()), want)
+
+
 # ---- K5 counting sort (scene.rs:655-698) ----------------------------------------------------------
 def test_k5_counting_sort_descending_reverse_stable():
     seg, idx = orc.sort_raw_depth_vec([np.array([5, 1, 9, 5, 1], dtype=np.int32)])
