@@ -56,6 +56,22 @@ def test_ply_header_errors():
         orc.parse_ply(bad)
 
 
+def test_ply_body_at_any_alignment():
+    """scene.rs:72-212 reads the body with read_exact from wherever `end_header\n` ends: the loader must not care how the header's length
+    or the caller's buffer aligns the floats (tools/host_sanitizers.sh runs this under UBSan)."""
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(7, 62)).astype(np.float32)
+    want = orc.scene_load(v)
+    lib = host.load()
+    ts = host.TileSet.from_vertices([[np.zeros((1, 62), np.float32)]])
+    for pad in range(4):
+        for shift in range(2):
+            ply = b"\0" * shift + b"ply\nformat binary_little_endian 1.0\ncomment " + b"x" * pad + b"\nelement vertex 7\nend_header\n" + v.tobytes()
+            buf = np.frombuffer(ply, dtype=np.uint8)[shift:]
+            assert lib.gswt_tileset_set_ply(ts._h, 0, 0, buf.ctypes.data, buf.shape[0]) == 0
+            assert np.array_equal(ts.rows(0, 0), want)
+
+
 def test_texture_halves_and_counting_sort(tiles):
     _, rows_o, _ = tiles
     rows = np.concatenate([rows_o[0][0], rows_o[2][5]])
