@@ -1298,7 +1298,7 @@ try {
     if (hs > 65535) return fail(GSWT_ERR_IO, "Scene::parse_file_header(): header of %zu bytes overflows the reference's u16", hs);
     if (hs > len || n > (len - hs) / 248) return fail(GSWT_ERR_IO, "Scene::load(): file holds fewer than %zu vertices (read_exact fails)", n);
     std::vector<float> verts(62 * n);
-    memcpy(verts.data(), bytes + hs, n * 248);
+    if (n) memcpy(verts.data(), bytes + hs, n * 248);     // (an empty vector's data() may be null: memcpy must not see it even for 0 bytes)
     scene_load(*sc, verts.data(), n);
     return GSWT_OK;
 } GSWT_CATCH("gswt_tileset_set_ply")

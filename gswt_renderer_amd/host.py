@@ -149,7 +149,7 @@ def load():
 
 def _check(rc):
     if rc < 0:
-        raise GSWTHostError(rc, load().gswt_host_last_error().decode())
+        raise GSWTHostError(rc, load().gswt_host_last_error().decode("utf-8", "replace"))
     return rc
 
 
