@@ -323,3 +323,47 @@ def test_loader_rejects_crafted_counts_without_unwinding():
             zf.writestr(name, good)
         with pytest.raises(host.GSWTHostError):
             host.TileSet.from_zip(bio.getvalue())
+
+
+def test_zero_vertex_ply_is_an_empty_scene():
+    """`element vertex 0` is a legal header (scene.rs:72-212 reads zero rows): the loader returns an empty scene, touching no body bytes."""
+    lib = host.load()
+    ts = host.TileSet.from_vertices([[np.zeros((3, 62), np.float32)]])
+    ply = b"ply\nformat binary_little_endian 1.0\nelement vertex 0\nend_header\n"
+    buf = np.frombuffer(ply, dtype=np.uint8)
+    assert lib.gswt_tileset_set_ply(ts._h, 0, 0, buf.ctypes.data, len(ply)) == 0
+    assert ts.rows(0, 0).shape == (0, 32)
+    assert orc.scene_load(np.zeros((0, 62), np.float32)).shape[0] == 0
+
+
+def test_mutated_zips_return_a_status():
+    """A bounded run of tools/fuzz_zip_loader.py's mutations (byte flips, truncation, central-directory damage, extreme 32-bit fields):
+    every mutated tile zip either loads or raises GSWTHostError -- where the reference's loader panics (scene.rs:1030-1141)."""
+    rng = np.random.default_rng(11)
+    verts = [[rng.normal(size=(int(rng.integers(1, 6)), 62)).astype(np.float32) for _ in range(4)] for _ in range(2)]
+    good = bytearray(synth.tile_zip_bytes(verts))
+    seen = set()
+    for it in range(300):
+        b = bytearray(good)
+        kind = it % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 8))):
+                b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        elif kind == 1:
+            b = b[:int(rng.integers(0, len(b)))]
+        elif kind == 2:
+            for _ in range(int(rng.integers(1, 6))):
+                b[len(b) - 1 - int(rng.integers(0, min(200, len(b))))] = int(rng.integers(0, 256))
+        else:
+            p = int(rng.integers(0, len(b) - 4))
+            b[p:p + 4] = int(rng.choice([0, 1, 0x7FFFFFFF, 0xFFFFFFFF, 0xFFFFFFFE, len(b), len(b) + 1])).to_bytes(4, "little")
+        try:
+            ts = host.TileSet.from_zip(bytes(b))
+            l, t = ts.dims()
+            for i in range(l):
+                for j in range(t):
+                    assert ts.rows(i, j).shape[1] == 32
+            seen.add("loaded")
+        except host.GSWTHostError:
+            seen.add("rejected")
+    assert seen == {"loaded", "rejected"}
